@@ -1,0 +1,13 @@
+"""MI355X-native CrossCLR contrastive-loss hot path (drop-in for
+amazon-science/crossmodal-contrastive-learning `trainer/loss.py: CrossCLR_onlyIntraModality`).
+
+The directory name carries a hyphen (it mirrors the reference repository's name), so it is imported
+through the `crossclr_amd` alias module at the repository root:
+
+    import crossclr_amd
+    criterion = crossclr_amd.CrossCLR_onlyIntraModality(temperature=0.03, negative_weight=0.8)
+"""
+from . import _native
+from .loss import AUTO_BF16_MIN_GLOBAL_BATCH, CrossCLR_onlyIntraModality, crossclr_loss
+
+__all__ = ["CrossCLR_onlyIntraModality", "crossclr_loss", "AUTO_BF16_MIN_GLOBAL_BATCH", "_native"]

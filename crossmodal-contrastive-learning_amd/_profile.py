@@ -1,0 +1,57 @@
+"""Per-stage HIP-event timing of the hot path (used by bench.py for the roofline object).
+
+Every stage is one C-ABI call = one kernel launch on torch's current stream, so torch.cuda.Event
+(which records on that stream) brackets exactly that kernel."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict
+
+import torch
+
+from . import _native as nat
+from . import loss as L
+
+
+def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
+                compute_mode: str, iters: int = 10, warmup: int = 2) -> Dict[str, float]:
+    """Average milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
+    backward, backward_finish)."""
+    lib = nat.library()
+    _, ws = L._forward_impl(video, text, temperature, negative_w, compute_mode, None)
+    plan, pp = ws.plan, ctypes.byref(ws.plan)
+    dev = video.device
+    p = L._ptr
+    stream = L._stream_for(video)
+    part = torch.empty(plan.fwd_slots * 2 * plan.bpad, dtype=torch.float32, device=dev)
+    gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
+    go = torch.ones(1, dtype=torch.float64, device=dev)
+    gv, gt = torch.empty_like(video), torch.empty_like(text)
+    t, w = ws.temperature, ws.negative_w
+
+    stages = {
+        "normalize": lambda: lib.crossclr_normalize(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                                    p(ws.xhat), p(ws.inv_norm), p(ws.diag), stream),
+        "forward": lambda: lib.crossclr_forward(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(part), 0, stream),
+        "forward_finish": lambda: lib.crossclr_forward_finish(pp, p(part), plan.fwd_slots, p(ws.diag), t, w, p(ws.logz),
+                                                              p(ws.rz), p(ws.wrz), p(ws.loss_sum), stream),
+        "backward": lambda: lib.crossclr_backward(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(ws.rz), p(ws.wrz),
+                                                  p(ws.rz), p(ws.wrz), p(gbuf), 0, stream),
+        "backward_finish": lambda: lib.crossclr_backward_finish(pp, p(gbuf), p(video), p(text), video.stride(0),
+                                                                text.stride(0), ws.in_dtype, p(ws.inv_norm), t, p(go),
+                                                                p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
+    }
+    out = {}
+    for name, fn in stages.items():
+        for _ in range(warmup):
+            nat.check(fn())
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        for i in range(iters):
+            e0[i].record()
+            nat.check(fn())
+            e1[i].record()
+        torch.cuda.synchronize(dev)
+        out[name] = sum(a.elapsed_time(b) for a, b in zip(e0, e1)) / iters
+    out["fast_path"] = float(plan.fast_path)
+    return out

@@ -1,0 +1,247 @@
+// crossclr_api.cpp -- the extern "C" boundary declared in include/crossclr.h.
+// Built by hipcc for gfx950 into libcrossclr_hip.so (the product).  The same file is built by the
+// host clang with -DCROSSCLR_EMU into tests/emu/libcrossclr_emu.so, where "launch" means running
+// the kernel source lane by lane on CPU threads -- test infrastructure only.
+#include "../../include/crossclr.h"
+#include "crossclr_kernels_generic.h"
+#ifndef CROSSCLR_NO_FAST
+#include "crossclr_kernels_fast.h"
+#endif
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+using namespace crossclr;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#ifdef CROSSCLR_EMU
+#define LAUNCH(kernel, grid, block, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)
+static int launch_status(const char*) { return CROSSCLR_OK; }
+#else
+#define LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
+static int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CROSSCLR_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return CROSSCLR_OK;
+}
+#endif
+
+extern "C" int crossclr_abi_version(void) { return CROSSCLR_ABI_VERSION; }
+extern "C" const char* crossclr_last_error(void) { return g_err; }
+extern "C" const char* crossclr_backend(void) {
+#ifdef CROSSCLR_EMU
+    return "emu-host";
+#else
+    return "hip-gfx950";
+#endif
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, crossclr_plan* plan) {
+    if (!plan) return fail(CROSSCLR_E_ARG, "plan is NULL");
+    if (b < 1 || D < 1) return fail(CROSSCLR_E_ARG, "need b >= 1 and D >= 1 (got b=%d D=%d)", b, D);
+    if (world < 1 || rank < 0 || rank >= world) return fail(CROSSCLR_E_ARG, "bad world/rank %d/%d", world, rank);
+    if (mode != CROSSCLR_MODE_FP32 && mode != CROSSCLR_MODE_BF16) return fail(CROSSCLR_E_ARG, "bad mode %d", mode);
+    if ((long long)b * world > (1 << 22)) return fail(CROSSCLR_E_ARG, "global batch too large");
+    memset(plan, 0, sizeof(*plan));
+    plan->b = b; plan->D = D; plan->world = world; plan->rank = rank; plan->mode = mode;
+    plan->bpad = round_up(b, kRowPad);
+    plan->fast_path = 0;
+    int dpad = round_up(D, 64);
+#ifndef CROSSCLR_NO_FAST
+    if (mode == CROSSCLR_MODE_BF16) {
+        int fp = fast_dpad(D);
+        if (fp > 0) { dpad = fp; plan->fast_path = 1; }
+    }
+#endif
+    if (!plan->fast_path && dpad > 256) dpad = round_up(D, 256);  // generic backward slices D by 256
+    plan->Dpad = dpad;
+    // forward column splits: enough (row block x split) work items to fill 256 CUs a few times over
+    const int row_blocks = 2 * plan->bpad / 128;
+    const int col_tiles = 2 * plan->bpad / 128;  // per column rank
+    int nsplit = (1024 + row_blocks - 1) / row_blocks;
+    if (nsplit > col_tiles) nsplit = col_tiles;
+    if (nsplit < 1) nsplit = 1;
+    plan->fwd_slots = nsplit;
+    const size_t esz = mode == CROSSCLR_MODE_FP32 ? 4 : 2;
+    plan->operand_bytes = (size_t)2 * plan->bpad * plan->Dpad * esz;
+    plan->gbuf_bytes = (size_t)2 * plan->bpad * plan->Dpad * 4;
+    return CROSSCLR_OK;
+}
+
+static int make_geo(const crossclr_plan* p, int col_ranks, int col_rank0, int skip_rank, float temperature,
+                    float negative_weight, Geo* g) {
+    if (!p) return fail(CROSSCLR_E_ARG, "plan is NULL");
+    if (!(temperature > 0.f) || !isfinite(temperature)) return fail(CROSSCLR_E_ARG, "temperature must be > 0");
+    if (!isfinite(negative_weight)) return fail(CROSSCLR_E_ARG, "negative_weight must be finite");
+    if (col_ranks < 1) return fail(CROSSCLR_E_ARG, "col_ranks must be >= 1");
+    g->b = p->b; g->bpad = p->bpad; g->D = p->D; g->Dpad = p->Dpad;
+    g->col_ranks = col_ranks; g->col_rank0 = col_rank0; g->row_rank = p->rank; g->skip_rank = skip_rank;
+    const double it = 1.0 / (double)temperature;
+    const double aw = fabs((double)negative_weight);
+    const double bound = it * (aw > 1.0 ? aw : 1.0);  // |logit| <= bound because the rows are unit vectors
+    // fixed soft-max shift: exp(logit - shift) must neither overflow (<= e^64 per term) nor push the
+    // always-present exp(0 - shift) self term out of fp32 range (shift <= 64)
+    double shift = bound > 64.0 ? bound - 64.0 : 0.0;
+    if (shift > 64.0)
+        return fail(CROSSCLR_E_RANGE, "temperature %g too small for the fixed-shift soft-max (max |logit| %g > 128)",
+                    (double)temperature, bound);
+    g->c_inter = (float)(it * (double)kLog2e);
+    g->c_intra = (float)(it * (double)negative_weight * (double)kLog2e);
+    g->m2 = (float)(shift * (double)kLog2e);
+    return CROSSCLR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename TIN>
+static int normalize_t(const crossclr_plan* p, const void* v, const void* t, long ldv, long ldt, void* xhat,
+                       float* inv_norm, float* diag, void* stream) {
+    Geo g; memset(&g, 0, sizeof(g));
+    g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
+    dim3 grid((p->bpad + 3) / 4), block(256);
+    if (p->mode == CROSSCLR_MODE_FP32)
+        LAUNCH((normalize_kernel<TIN, float>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+               (float*)xhat, inv_norm, diag);
+    else
+        LAUNCH((normalize_kernel<TIN, bf16_t>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+               (bf16_t*)xhat, inv_norm, diag);
+    return launch_status("normalize_kernel");
+}
+
+extern "C" int crossclr_normalize(const crossclr_plan* plan, const void* video, const void* text, long ld_video,
+                                  long ld_text, int in_dtype, void* xhat, float* inv_norm, float* diag_cos,
+                                  void* stream) {
+    if (!plan || !video || !text || !xhat || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (ld_video < plan->D || ld_text < plan->D) return fail(CROSSCLR_E_ARG, "row stride smaller than D");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return normalize_t<float>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F64: return normalize_t<double>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F16: return normalize_t<in_f16>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_BF16: return normalize_t<in_bf16>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                                int col_ranks, int col_rank0, int skip_rank, float temperature,
+                                float negative_weight, float* part, int slot0, void* stream) {
+    if (!plan || !xhat_rows || !xhat_cols || !part || slot0 < 0) return fail(CROSSCLR_E_ARG, "NULL/negative argument");
+    Geo g;
+    int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
+    if (rc) return rc;
+    float* out = part + (size_t)slot0 * 2 * plan->bpad;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->fast_path) return fast_forward(plan, g, xhat_rows, xhat_cols, out, stream);
+#endif
+    const int ntiles = col_ranks * 2 * plan->bpad / 128;
+    const int nsplit = plan->fwd_slots;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    dim3 grid(2 * plan->bpad / 128, nsplit), block(256);
+    if (plan->mode == CROSSCLR_MODE_FP32)
+        LAUNCH((fwd_sums_kernel<float>), grid, block, stream, (const float*)xhat_rows, (const float*)xhat_cols, g, tps, out);
+    else
+        LAUNCH((fwd_sums_kernel<bf16_t>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out);
+    return launch_status("fwd_sums_kernel");
+}
+
+extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int nslots,
+                                       const float* diag_cos, float temperature, float negative_weight,
+                                       float* logz, float* rz, float* wrz, double* loss_sum, void* stream) {
+    if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum || nslots < 1)
+        return fail(CROSSCLR_E_ARG, "NULL argument / nslots < 1");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
+    if (rc) return rc;
+    LAUNCH(fwd_finish_kernel, dim3(1), dim3(1024), stream, part, nslots, g, diag_cos, 1.0f / temperature,
+           negative_weight, logz, rz, wrz, loss_sum);
+    return launch_status("fwd_finish_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int backward_generic(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
+                            const float* rz_rows, const float* wrz_rows, const float* rz_cols,
+                            const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
+    dim3 block(256);
+    const int rb = 2 * p->bpad / 64;
+    if (p->Dpad % 256 == 0) {
+        LAUNCH((bwd_kernel<T, 256>), dim3(rb, p->Dpad / 256), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
+               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate);
+    } else if (p->Dpad % 128 == 0) {
+        LAUNCH((bwd_kernel<T, 128>), dim3(rb, p->Dpad / 128), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
+               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate);
+    } else {
+        LAUNCH((bwd_kernel<T, 64>), dim3(rb, p->Dpad / 64), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
+               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate);
+    }
+    return launch_status("bwd_kernel");
+}
+
+extern "C" int crossclr_backward(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                                 int col_ranks, int col_rank0, int skip_rank, float temperature,
+                                 float negative_weight, const float* rz_rows, const float* wrz_rows,
+                                 const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
+                                 void* stream) {
+    if (!plan || !xhat_rows || !xhat_cols || !rz_rows || !wrz_rows || !rz_cols || !wrz_cols || !gbuf)
+        return fail(CROSSCLR_E_ARG, "NULL argument");
+    Geo g;
+    int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
+    if (rc) return rc;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->fast_path)
+        return fast_backward(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+#endif
+    if (plan->mode == CROSSCLR_MODE_FP32)
+        return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+}
+
+template <typename TIN>
+static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const void* v, const void* t, long ldv, long ldt,
+                             const float* inv_norm, float temperature, const double* grad_out, void* gv, void* gt,
+                             long ldgv, long ldgt, void* stream) {
+    Geo g; memset(&g, 0, sizeof(g));
+    g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
+    dim3 grid((2 * p->b + 3) / 4), block(256);
+    LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,
+           1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt);
+    return launch_status("bwd_finish_kernel");
+}
+
+extern "C" int crossclr_backward_finish(const crossclr_plan* plan, const float* gbuf, const void* video,
+                                        const void* text, long ld_video, long ld_text, int in_dtype,
+                                        const float* inv_norm, float temperature, const double* grad_out,
+                                        void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext,
+                                        void* stream) {
+    if (!plan || !gbuf || !video || !text || !inv_norm || !grad_out || !grad_video || !grad_text)
+        return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (!(temperature > 0.f)) return fail(CROSSCLR_E_ARG, "temperature must be > 0");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return backward_finish_t<float>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
+        case CROSSCLR_IN_F64: return backward_finish_t<double>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
+        case CROSSCLR_IN_F16: return backward_finish_t<in_f16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
+        case CROSSCLR_IN_BF16: return backward_finish_t<in_bf16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+extern "C" int crossclr_selftest(int which, const void* in, void* out, void* stream) {
+    if (which < 0 || which > 2 || !in || !out) return fail(CROSSCLR_E_ARG, "bad selftest arguments");
+    LAUNCH(selftest_kernel, dim3(1), dim3(64), stream, which, in, out);
+    return launch_status("selftest_kernel");
+}

@@ -1,0 +1,168 @@
+// crossclr_device.h -- device-side building blocks shared by every kernel.
+//
+// Written for gfx950 (CDNA4): 64-lane wavefronts, v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32,
+// 160 KiB LDS with 16-byte-chunk XOR swizzles sized for ds_read_b128's 64-bank rows,
+// ds_read_b64_tr_b16 for operands that are contracted over their ROW index.
+//
+// The same source is also compiled by the host clang against tests/emu/hip_emu.h (CROSSCLR_EMU):
+// that build is test infrastructure (lane-level index-math checks on CPU), never the product.
+#pragma once
+
+#ifdef CROSSCLR_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace crossclr {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned short bf16_t;  // storage type of a bf16 element in memory
+
+constexpr int kRowPad = 128;     // rows of every packed operand are padded to this
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ---------------------------------------------------------------------------------------------
+// geometry of one launch (passed by value)
+// ---------------------------------------------------------------------------------------------
+struct Geo {
+    int b;          // valid rows per modality per rank
+    int bpad;       // padded rows per modality
+    int D, Dpad;
+    int col_ranks;  // rank segments in the column operand
+    int col_rank0;  // rank id of column segment 0
+    int row_rank;   // rank id owning the row operand
+    int skip_rank;  // column rank to skip (-1: none)
+    float c_inter;  // log2(e)/tau
+    float c_intra;  // negative_weight*log2(e)/tau
+    float m2;       // soft-max shift, log2 domain
+};
+
+// ---------------------------------------------------------------------------------------------
+// portability layer: the handful of gfx950 builtins the kernels use
+// ---------------------------------------------------------------------------------------------
+#ifndef CROSSCLR_EMU
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// 16-lane-group transpose read: lane i of a group receives element (i&3) of the 8-byte pieces
+// addressed by lanes 4j+(i>>2), j = 0..3  (i.e. column i of the 4x16 b16 matrix whose row j is
+// made of the four pieces addressed by lanes 4j..4j+3).
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float wave_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double wave_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+#define CROSSCLR_SHARED __shared__
+#endif
+
+__device__ __forceinline__ bf16_t f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(bf16_t h) {
+    return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+
+// C/D fragment of a 32x32 MFMA: lane l, register r holds C[row][col] with
+__device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// col = l & 31, half = l >> 5.
+
+// ---------------------------------------------------------------------------------------------
+// operand traits: how a 128-byte K-chunk of an LDS tile row turns into MFMA operands
+// ---------------------------------------------------------------------------------------------
+// LDS "K-tile": R rows x 128 bytes; 16-byte chunk c of row r lives at r*128 + ((c ^ ((r>>1)&7)) << 4).
+// ds_read_b128 is serviced per 16-lane group over a 256-byte (64-bank) row, i.e. TWO tile rows:
+// a group reading chunk c of 16 rows that are distinct mod 16 hits 16 distinct (row parity, slot)
+// pairs -> conflict-free (the linear layout would be 8-way).
+__device__ __forceinline__ int ktile_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T> struct Operand;
+
+template <> struct Operand<float> {
+    typedef float elem;
+    static constexpr int kChunkElems = 32;  // 128 B
+    typedef f32x4 frag;                     // 4 consecutive k values of one row
+    // one step s (0..3) of a chunk consumes 16-byte piece 2*s+half of each row and issues 4 MFMAs
+    static __device__ __forceinline__ frag load(const unsigned char* tile, int row, int s, int half) {
+        return *reinterpret_cast<const f32x4*>(tile + ktile_off(row, 2 * s + half));
+    }
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = mfma_32x32x2_f32(a[j], b[j], c);
+        return c;
+    }
+};
+
+template <> struct Operand<bf16_t> {
+    typedef bf16_t elem;
+    static constexpr int kChunkElems = 64;  // 128 B
+    typedef bf16x8 frag;                    // 8 consecutive k values of one row
+    static __device__ __forceinline__ frag load(const unsigned char* tile, int row, int s, int half) {
+        return *reinterpret_cast<const bf16x8*>(tile + ktile_off(row, 2 * s + half));
+    }
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return mfma_32x32x16_bf16(a, b, c); }
+};
+
+// Stage R rows x 128 bytes (byte column kb of rows r0.. of a row-major array with row pitch
+// `pitch` bytes) into registers, then into a swizzled K-tile.  NT threads cooperate.
+template <int R, int NT> struct KTileStage {
+    static constexpr int kPieces = R * 8 / NT;  // 16-byte pieces per thread
+    u32x4 v[kPieces];
+    __device__ __forceinline__ void fetch(const unsigned char* base, size_t pitch, int kb, int tid) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            int id = tid + i * NT;
+            int row = id >> 3, c = id & 7;
+            v[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * pitch + kb + c * 16);
+        }
+    }
+    __device__ __forceinline__ void commit(unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            int id = tid + i * NT;
+            int row = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4*>(tile + ktile_off(row, c)) = v[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// column-tile bookkeeping shared by forward and backward
+// ---------------------------------------------------------------------------------------------
+struct ColTile {
+    int rank;     // global rank of the segment
+    int mod;      // modality of the columns
+    int in_mod0;  // index of the first column inside its modality block
+    size_t row0;  // first row of the tile inside the column operand
+    size_t stat0; // first index of the tile inside column statistics arrays
+};
+// tile t of width W over a column operand Xcols[col_ranks][2][bpad][Dpad]
+__device__ __forceinline__ ColTile col_tile(const Geo& g, int t, int W) {
+    int per_rank = 2 * g.bpad / W;
+    int seg = t / per_rank, in_seg = t - seg * per_rank;
+    int per_mod = g.bpad / W;
+    ColTile ct;
+    ct.rank = g.col_rank0 + seg;
+    ct.mod = in_seg / per_mod;
+    ct.in_mod0 = (in_seg - ct.mod * per_mod) * W;
+    ct.row0 = (size_t)seg * 2 * g.bpad + (size_t)in_seg * W;
+    ct.stat0 = ct.row0;
+    return ct;
+}
+
+}  // namespace crossclr

@@ -1,0 +1,509 @@
+// crossclr_kernels_generic.h -- the tiled kernels that work for every shape and both operand
+// types (exact-fp32 MFMA and bf16 MFMA): normalisation, forward denominators, forward finish,
+// backward, backward finish.  The register-resident bf16 fast path lives in
+// crossclr_kernels_fast.h; this file is what it falls back to and what compute_mode="fp32" runs.
+#pragma once
+#include "crossclr_device.h"
+
+namespace crossclr {
+
+// ---------------------------------------------------------------------------------------------
+// input element access (any float dtype of the reference's inputs)
+// ---------------------------------------------------------------------------------------------
+struct in_f16 { unsigned short bits; };
+struct in_bf16 { unsigned short bits; };
+__device__ __forceinline__ double in_load(const float* p, size_t i) { return (double)p[i]; }
+__device__ __forceinline__ double in_load(const double* p, size_t i) { return p[i]; }
+__device__ __forceinline__ double in_load(const in_bf16* p, size_t i) { return (double)bf16_bits_to_f32(p[i].bits); }
+__device__ __forceinline__ double in_load(const in_f16* p, size_t i) {
+    return (double)(float)__builtin_bit_cast(_Float16, p[i].bits);
+}
+__device__ __forceinline__ void in_store(float* p, size_t i, double v) { p[i] = (float)v; }
+__device__ __forceinline__ void in_store(double* p, size_t i, double v) { p[i] = v; }
+__device__ __forceinline__ void in_store(in_bf16* p, size_t i, double v) { p[i].bits = f32_to_bf16_bits((float)v); }
+__device__ __forceinline__ void in_store(in_f16* p, size_t i, double v) {
+    p[i].bits = __builtin_bit_cast(unsigned short, (_Float16)(float)v);
+}
+__device__ __forceinline__ void op_store(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void op_store(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16_bits(v); }
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += wave_xor_f64(v, m);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: row L2-normalisation of both modalities  (reference trainer/loss.py:79-80)
+// one wavefront per row index i: video row i and text row i together, so the diagonal cosine
+// vhat_i . that_i (the positive-pair logit of loss.py:83 before /tau) comes out in fp32 for free.
+// ---------------------------------------------------------------------------------------------
+template <typename TIN, typename T>
+__global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const TIN* text, long ldv, long ldt,
+                                                        Geo g, T* X, float* inv_norm, float* diag_cos) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= g.bpad) return;
+    T* xv = X + (size_t)i * g.Dpad;
+    T* xt = X + ((size_t)g.bpad + i) * g.Dpad;
+    if (i >= g.b) {  // padding rows: zeros, so they add exp(-shift) terms that are masked/ignored
+        for (int d = lane; d < g.Dpad; d += 64) { op_store(xv, d, 0.f); op_store(xt, d, 0.f); }
+        if (lane == 0) { inv_norm[i] = 0.f; inv_norm[g.bpad + i] = 0.f; diag_cos[i] = 0.f; }
+        return;
+    }
+    const TIN* pv = video + (size_t)i * ldv;
+    const TIN* pt = text + (size_t)i * ldt;
+    double ssv = 0, sst = 0, dot = 0;
+    for (int d = lane; d < g.D; d += 64) {
+        double a = in_load(pv, d), c = in_load(pt, d);
+        ssv += a * a; sst += c * c; dot += a * c;
+    }
+    ssv = wave_sum_f64(ssv); sst = wave_sum_f64(sst); dot = wave_sum_f64(dot);
+    // x / max(||x||, eps), eps = 1e-12 (F.normalize default)
+    double nv = sqrt(ssv), nt = sqrt(sst);
+    double iv = 1.0 / (nv > 1e-12 ? nv : 1e-12), it = 1.0 / (nt > 1e-12 ? nt : 1e-12);
+    for (int d = lane; d < g.Dpad; d += 64) {
+        float a = 0.f, c = 0.f;
+        if (d < g.D) { a = (float)(in_load(pv, d) * iv); c = (float)(in_load(pt, d) * it); }
+        op_store(xv, d, a); op_store(xt, d, c);
+    }
+    if (lane == 0) {
+        inv_norm[i] = (float)iv; inv_norm[g.bpad + i] = (float)it;
+        diag_cos[i] = (float)(dot * iv * it);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: forward denominators, generic tiled version.
+//   block = 256 threads (4 waves as 2x2), tile = 128 rows x 128 columns, K-chunks of 128 bytes.
+//   MFMA operands are SWAPPED (A = column rows, B = row rows) so that a lane owns one output ROW
+//   p = lane&31 of each 32x32 fragment and 16 of its columns: the running row sum is one
+//   register per fragment row-block, no cross-lane traffic until the very end.
+//   grid = (2*bpad/128 row blocks, nsplit column splits); each (row block, split) writes its own
+//   slot -> no atomics, deterministic.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
+                                                       float* part) {
+    typedef Operand<T> Op;
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
+    unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
+    unsigned char* tileQ = lds + 128 * 128;     // column operand chunk [128][128 B]
+    float* red = reinterpret_cast<float*>(lds + 2 * 128 * 128);  // [2][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wr = wave & 1, wc = wave >> 1;
+    const size_t pitch = (size_t)g.Dpad * sizeof(T);
+    const int nchunks = g.Dpad / Op::kChunkElems;
+
+    const int row0 = blockIdx.x * 128;           // first row of the block inside [2][bpad]
+    const int rmod = row0 / g.bpad;
+    const int r_in_mod0 = row0 - rmod * g.bpad;
+    const unsigned char* rbase = reinterpret_cast<const unsigned char*>(rows) + (size_t)row0 * pitch;
+
+    const int ntiles = g.col_ranks * 2 * g.bpad / 128;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    int t_end = t_begin + tiles_per_split;
+    if (t_end > ntiles) t_end = ntiles;
+
+    float rowacc[2] = {0.f, 0.f};
+    KTileStage<128, 256> sp, sq;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const ColTile ct = col_tile(g, t, 128);
+        if (ct.rank == g.skip_rank) continue;
+        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(cols) + ct.row0 * pitch;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+        sp.fetch(rbase, pitch, 0, tid);
+        sq.fetch(cbase, pitch, 0, tid);
+        for (int kc = 0; kc < nchunks; ++kc) {
+            sp.commit(tileP, tid);
+            sq.commit(tileQ, tid);
+            __syncthreads();
+            if (kc + 1 < nchunks) {
+                sp.fetch(rbase, pitch, (kc + 1) * 128, tid);
+                sq.fetch(cbase, pitch, (kc + 1) * 128, tid);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                typename Op::frag a[2], bfr[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    a[x] = Op::load(tileQ, 64 * wc + 32 * x + l31, s, half);
+                    bfr[x] = Op::load(tileP, 64 * wr + 32 * x + l31, s, half);
+                }
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi) acc[qi][pi] = Op::mma(a[qi], bfr[pi], acc[qi][pi]);
+            }
+            __syncthreads();
+        }
+        // epilogue: e = exp2(c*g - m2), masked, summed into the lane's row
+        const bool same_mod = (ct.mod == rmod);
+        const float c2 = same_mod ? g.c_intra : g.c_inter;
+        const bool diag_tile = same_mod && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
+        const bool ragged = ct.in_mod0 + 128 > g.b;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                const int p_t = 64 * wr + 32 * pi + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q_t = 64 * wc + 32 * qi + frag_row(r, half);
+                    float e = fast_exp2(acc[qi][pi][r] * c2 - g.m2);
+                    if (ragged && ct.in_mod0 + q_t >= g.b) e = 0.f;
+                    if (diag_tile && q_t == p_t) e = 0.f;
+                    rowacc[pi] += e;
+                }
+            }
+    }
+    // combine the two lane halves, then the two column waves
+    rowacc[0] += wave_xor_f32(rowacc[0], 32);
+    rowacc[1] += wave_xor_f32(rowacc[1], 32);
+    if (half == 0) {
+        red[wc * 128 + 64 * wr + l31] = rowacc[0];
+        red[wc * 128 + 64 * wr + 32 + l31] = rowacc[1];
+    }
+    __syncthreads();
+    if (tid < 128) part[(size_t)blockIdx.y * 2 * g.bpad + row0 + tid] = red[tid] + red[128 + tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: forward finish: slots -> logZ, 1/Z, w/Z, and the loss sum (double), one block.
+//   log Z = shift + ln(sum_slots + exp(-shift));  the "+exp(-shift)" is the masked intra-modal
+//   diagonal whose logit the reference sets to 0.0 (trainer/loss.py:96-97), i.e. exp(0) = 1.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) fwd_finish_kernel(const float* part, int nslots, Geo g, const float* diag_cos,
+                                                          float inv_tau, float neg_w, float* logz, float* rz,
+                                                          float* wrz, double* loss_sum) {
+    CROSSCLR_SHARED double red[16];
+    const int n = 2 * g.bpad;
+    const double shift = (double)g.m2 * (double)kLn2;
+    const double self_term = exp(-shift);
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < n; p += 1024) {
+        const int mod = p / g.bpad, i = p - mod * g.bpad;
+        double s = self_term;
+        for (int k = 0; k < nslots; ++k) s += (double)part[(size_t)k * n + p];
+        const bool valid = i < g.b;
+        const double lz = shift + log(s);
+        logz[p] = valid ? (float)lz : 0.f;
+        const float r = valid ? (float)(1.0 / s) : 0.f;
+        rz[p] = r;
+        wrz[p] = neg_w * r;
+        if (valid) {
+            acc += lz;
+            if (mod == 0) acc -= 2.0 * (double)diag_cos[i] * (double)inv_tau;
+        }
+    }
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += red[k];
+        loss_sum[0] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: backward, generic tiled version.  For a block of 64 rows P and an output slice of DC
+// embedding columns it walks every 64-column tile Q:
+//   phase A  S^T[q][p] = xhat_Q . xhat_P          (MFMA, contraction over D, operands via LDS)
+//   phase B  W[p][q]   = s * exp2(c S - m2) * (rz_p + rz_q), self pair -> 0, to LDS in operand type
+//   phase C  G[p][d]  += W[p][:] . xhat_Q[:, d]   (MFMA, contraction over the 64 columns q;
+//            the q-contiguous operand comes from ds_read_b64_tr_b16 for bf16, plain ds_read_b32 for fp32)
+// grid = (2*bpad/64, Dpad/DC).  Accumulators: 64 x DC fp32 per block (64 VGPRs per lane at DC=256).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DC> struct BwdLds {
+    static constexpr int kTileP = 0;
+    static constexpr int kTileQ = 64 * 128;
+    static constexpr int kW = 2 * 64 * 128;                         // W tile  [64][64] of T
+    static constexpr int kWBytes = 64 * 64 * (int)sizeof(T);
+    static constexpr int kXQ = kW + kWBytes;                        // column slice [64][DC] of T
+    static constexpr int kXQBytes = 64 * DC * (int)sizeof(T);
+    static constexpr int kTotal = kXQ + kXQBytes;
+};
+
+// byte offset of element (q, d) inside the [64][DC] column slice
+template <typename T, int DC> __device__ __forceinline__ int xq_off(int q, int d);
+template <> __device__ __forceinline__ int xq_off<float, 64>(int q, int d) { return (q * 64 + d) * 4; }
+template <> __device__ __forceinline__ int xq_off<float, 128>(int q, int d) { return (q * 128 + d) * 4; }
+template <> __device__ __forceinline__ int xq_off<float, 256>(int q, int d) { return (q * 256 + d) * 4; }
+// bf16: 16-byte chunks XOR-swizzled by (q&3)<<2 so the four rows a transpose-read touches land in
+// four different 64-byte bank groups (needs >= 16 chunks per row, i.e. DC >= 128)
+template <int DC> __device__ __forceinline__ int xq_off_bf16(int q, int d) {
+    int chunk = d >> 3, inner = (d & 7) * 2;
+    if (DC >= 128) chunk ^= (q & 3) << 2;
+    return q * DC * 2 + chunk * 16 + inner;
+}
+template <> __device__ __forceinline__ int xq_off<bf16_t, 64>(int q, int d) { return xq_off_bf16<64>(q, d); }
+template <> __device__ __forceinline__ int xq_off<bf16_t, 128>(int q, int d) { return xq_off_bf16<128>(q, d); }
+template <> __device__ __forceinline__ int xq_off<bf16_t, 256>(int q, int d) { return xq_off_bf16<256>(q, d); }
+
+// phase B store of 4 consecutive-q weights of row p (q0 multiple of 4)
+__device__ __forceinline__ void w_store4(unsigned char* wt, int p, int q0, f32x4 w, float*) {
+    // fp32 W tile = two K-tiles of 32 columns each
+    unsigned char* t = wt + (q0 >> 5) * (64 * 128);
+    *reinterpret_cast<f32x4*>(t + ktile_off(p, (q0 & 31) >> 2)) = w;
+}
+__device__ __forceinline__ void w_store4(unsigned char* wt, int p, int q0, f32x4 w, bf16_t*) {
+    u32x2 pk;
+    pk[0] = (uint32_t)f32_to_bf16_bits(w[0]) | ((uint32_t)f32_to_bf16_bits(w[1]) << 16);
+    pk[1] = (uint32_t)f32_to_bf16_bits(w[2]) | ((uint32_t)f32_to_bf16_bits(w[3]) << 16);
+    *reinterpret_cast<u32x2*>(wt + ktile_off(p, q0 >> 3) + (q0 & 4) * 2) = pk;
+}
+
+// phase C inner products for one wave: rows 32*wr.., DC/2 embedding columns starting at dw0
+template <int DC>
+__device__ __forceinline__ void bwd_gemm2(const unsigned char* wt, const unsigned char* xq, int wr, int dw0,
+                                          int lane, f32x16 (&acc)[DC / 64], float*) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {  // 8 columns q per step: k-slot `half` covers q = 8kk+4half+j
+        const unsigned char* t = wt + (kk >> 2) * (64 * 128);
+        f32x4 a = *reinterpret_cast<const f32x4*>(t + ktile_off(32 * wr + l31, 2 * (kk & 3) + half));
+#pragma unroll
+        for (int dt = 0; dt < DC / 64; ++dt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float b = *reinterpret_cast<const float*>(xq + xq_off<float, DC>(8 * kk + 4 * half + j, dw0 + 32 * dt + l31));
+                acc[dt] = mfma_32x32x2_f32(a[j], b, acc[dt]);
+            }
+        }
+    }
+}
+template <int DC>
+__device__ __forceinline__ void bwd_gemm2(const unsigned char* wt, const unsigned char* xq, int wr, int dw0,
+                                          int lane, f32x16 (&acc)[DC / 64], bf16_t*) {
+    const int half = lane >> 5, l31 = lane & 31;
+    // transpose-read roles inside a 16-lane group: lane 4j+c addresses row j, 8-byte piece c
+    const int grp = lane >> 4, i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3;
+    const int dsub = grp & 1;  // which 16-column half of the 32-wide fragment this group delivers
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // 16 columns q per step: k-slot (half, j8) <-> q = 16ks+8half+j8
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(wt + ktile_off(32 * wr + l31, 2 * ks + half));
+#pragma unroll
+        for (int dt = 0; dt < DC / 64; ++dt) {
+            const int dcol = dw0 + 32 * dt + 16 * dsub + 4 * piece;
+            const int q0 = 16 * ks + 8 * half + jrow;
+            s16x4 lo = lds_read_tr16_b64(xq + xq_off<bf16_t, DC>(q0, dcol));
+            s16x4 hi = lds_read_tr16_b64(xq + xq_off<bf16_t, DC>(q0 + 4, dcol));
+            struct { s16x4 lo, hi; } pair = {lo, hi};  // k-slots 0..3 <- rows q0.., 4..7 <- rows q0+4..
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, pair);
+            acc[dt] = mfma_32x32x16_bf16(a, bfr, acc[dt]);
+        }
+    }
+}
+
+template <typename T, int DC>
+__global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, Geo g, const float* rz_rows,
+                                                  const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
+                                                  float* gbuf, int accumulate) {
+    typedef Operand<T> Op;
+    typedef BwdLds<T, DC> L;
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[L::kTotal];
+    unsigned char* tileP = lds + L::kTileP;
+    unsigned char* tileQ = lds + L::kTileQ;
+    unsigned char* wt = lds + L::kW;
+    unsigned char* xq = lds + L::kXQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const size_t pitch = (size_t)g.Dpad * sizeof(T);
+    const int nchunks = g.Dpad / Op::kChunkElems;
+
+    const int row0 = blockIdx.x * 64;
+    const int rmod = row0 / g.bpad;
+    const int r_in_mod0 = row0 - rmod * g.bpad;
+    const int d0 = blockIdx.y * DC;
+    const unsigned char* rbase = reinterpret_cast<const unsigned char*>(rows) + (size_t)row0 * pitch;
+
+    // phase A/B roles: wave computes S^T for columns 32*wq.., rows 32*wp..
+    const int wq = wave & 1, wp = wave >> 1;
+    // phase C roles: rows 32*wr.., embedding columns wc*(DC/2)..
+    const int wr = wave & 1, wc = wave >> 1;
+
+    f32x16 acc2[DC / 64];
+#pragma unroll
+    for (int dt = 0; dt < DC / 64; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
+
+    const int p_t = 32 * wp + l31;  // this lane's row inside the block (phase B)
+    const float rzp_inter = rz_rows[row0 + p_t];
+    const float rzp_intra = wrz_rows[row0 + p_t];
+
+    const int ntiles = g.col_ranks * 2 * g.bpad / 64;
+    KTileStage<64, 256> sp, sq;
+    for (int t = 0; t < ntiles; ++t) {
+        const ColTile ct = col_tile(g, t, 64);
+        if (ct.rank == g.skip_rank) continue;
+        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(cols) + ct.row0 * pitch;
+        // ---------------- phase A ----------------
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        sp.fetch(rbase, pitch, 0, tid);
+        sq.fetch(cbase, pitch, 0, tid);
+        for (int kc = 0; kc < nchunks; ++kc) {
+            sp.commit(tileP, tid);
+            sq.commit(tileQ, tid);
+            __syncthreads();  // also: every wave is past phase C of the previous tile
+            if (kc == 0) {
+                // column slice for phase C: [64][DC] elements, 16-byte pieces
+                constexpr int kPiecesPerRow = DC * (int)sizeof(T) / 16;
+                constexpr int kElemsPerPiece = 16 / (int)sizeof(T);
+                for (int id = tid; id < 64 * kPiecesPerRow; id += 256) {
+                    const int q = id / kPiecesPerRow, c = id - q * kPiecesPerRow;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(cbase + (size_t)q * pitch +
+                                                             ((size_t)d0 + c * kElemsPerPiece) * sizeof(T));
+                    *reinterpret_cast<u32x4*>(xq + xq_off<T, DC>(q, c * kElemsPerPiece)) = v;
+                }
+            }
+            if (kc + 1 < nchunks) {
+                sp.fetch(rbase, pitch, (kc + 1) * 128, tid);
+                sq.fetch(cbase, pitch, (kc + 1) * 128, tid);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                typename Op::frag a = Op::load(tileQ, 32 * wq + l31, s, half);
+                typename Op::frag bfr = Op::load(tileP, 32 * wp + l31, s, half);
+                acc = Op::mma(a, bfr, acc);
+            }
+            __syncthreads();
+        }
+        // ---------------- phase B ----------------
+        const bool same_mod = (ct.mod == rmod);
+        const float c2 = same_mod ? g.c_intra : g.c_inter;
+        const float rzp = same_mod ? rzp_intra : rzp_inter;
+        const float* rzq = (same_mod ? wrz_cols : rz_cols) + ct.stat0;
+        const bool diag_tile = same_mod && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int q0 = 32 * wq + 8 * r4 + 4 * half;  // frag_row(4*r4 + j, half) = q0 - 32wq + j
+            const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
+            f32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float e = fast_exp2(acc[4 * r4 + j] * c2 - g.m2);
+                float v = e * (rzp + rq[j]);
+                if (diag_tile && q0 + j == p_t) v = 0.f;
+                w[j] = v;
+            }
+            w_store4(wt, p_t, q0, w, (T*)nullptr);
+        }
+        __syncthreads();
+        // ---------------- phase C ----------------
+        bwd_gemm2<DC>(wt, xq, wr, wc * (DC / 2), lane, acc2, (T*)nullptr);
+    }
+    // G[row][d]: lane holds column d = l31 of each fragment, 16 rows
+#pragma unroll
+    for (int dt = 0; dt < DC / 64; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 32 * wr + frag_row(r, half);
+            const int d = d0 + wc * (DC / 2) + 32 * dt + l31;
+            float* dst = gbuf + (size_t)row * g.Dpad + d;
+            *dst = accumulate ? (*dst + acc2[dt][r]) : acc2[dt][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: backward finish (autograd of loss.py:79-80 + analytic positive-pair term), one wave per row
+//   ghat = gbuf/(2 B tau) - partner_hat/(B tau);  gx = (ghat - xhat (xhat.ghat)) * inv_norm * grad_out
+// ---------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, const TIN* video, const TIN* text, long ldv,
+                                                         long ldt, Geo g, const float* inv_norm, float inv_tau,
+                                                         int Bglobal, const double* grad_out, TIN* gvideo,
+                                                         TIN* gtext, long ldgv, long ldgt) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + wave;  // 0 .. 2*b-1
+    if (idx >= 2 * g.b) return;
+    const int mod = idx / g.b, i = idx - mod * g.b;
+    const TIN* own = (mod == 0 ? video + (size_t)i * ldv : text + (size_t)i * ldt);
+    const TIN* oth = (mod == 0 ? text + (size_t)i * ldt : video + (size_t)i * ldv);
+    TIN* out = (mod == 0 ? gvideo + (size_t)i * ldgv : gtext + (size_t)i * ldgt);
+    const double io = (double)inv_norm[mod * g.bpad + i];
+    const double ip = (double)inv_norm[(1 - mod) * g.bpad + i];
+    const float* grow = gbuf + ((size_t)mod * g.bpad + i) * g.Dpad;
+    const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
+    const double pc = (double)inv_tau / (double)Bglobal;
+    double dot = 0.0;
+    for (int d = lane; d < g.D; d += 64) {
+        double gh = (double)grow[d] * sc - in_load(oth, d) * ip * pc;
+        dot += in_load(own, d) * io * gh;
+    }
+    dot = wave_sum_f64(dot);
+    const bool clamped = io >= 1e12;  // ||x|| < eps: x/eps, no projection term
+    const double go = grad_out[0];
+    for (int d = lane; d < g.D; d += 64) {
+        double gh = (double)grow[d] * sc - in_load(oth, d) * ip * pc;
+        double xh = in_load(own, d) * io;
+        double v = clamped ? gh : (gh - xh * dot);
+        in_store(out, d, v * io * go);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hardware assumption probes (run once on the GPU by tests/test_hw_assumptions.py)
+// ---------------------------------------------------------------------------------------------
+// which = 0: C = A(32x16 bf16) * B(16x32 bf16) through the documented fragment maps -> out f32[32][32]
+//            in = A row-major [32][16] bf16 then B row-major [16][32] bf16
+// which = 1: C = A(32x2 f32) * B(2x32 f32) -> out f32[32][32];  in = A [32][2] f32 then B [2][32] f32
+// which = 2: transpose read: LDS holds bf16 M[r][c] = in[r*64+c] for a [16][64] matrix; every lane
+//            issues lds_read_tr16_b64 at row 4*(lane>>5)... exactly like bwd_gemm2 (ks=0, dt=0, DC=64)
+//            out s16[64][8] = the B fragment each lane assembled.
+__global__ void __launch_bounds__(64) selftest_kernel(int which, const void* in, void* out) {
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[64 * 64 * 2];
+    const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+    if (which == 0) {
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(in);
+        const bf16_t* B = A + 32 * 16;
+        struct { bf16_t e[8]; } ta, tb;
+        for (int j = 0; j < 8; ++j) {
+            ta.e[j] = A[l31 * 16 + 8 * half + j];
+            tb.e[j] = B[(8 * half + j) * 32 + l31];
+        }
+        const bf16x8 a = __builtin_bit_cast(bf16x8, ta), b = __builtin_bit_cast(bf16x8, tb);
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = mfma_32x32x16_bf16(a, b, c);
+        float* C = reinterpret_cast<float*>(out);
+        for (int r = 0; r < 16; ++r) C[frag_row(r, half) * 32 + l31] = c[r];
+    } else if (which == 1) {
+        const float* A = reinterpret_cast<const float*>(in);
+        const float* B = A + 32 * 2;
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = mfma_32x32x2_f32(A[l31 * 2 + half], B[half * 32 + l31], c);
+        float* C = reinterpret_cast<float*>(out);
+        for (int r = 0; r < 16; ++r) C[frag_row(r, half) * 32 + l31] = c[r];
+    } else {
+        const bf16_t* M = reinterpret_cast<const bf16_t*>(in);
+        for (int e = lane; e < 64 * 64; e += 64) {
+            int q = e >> 6, d = e & 63;
+            *reinterpret_cast<bf16_t*>(lds + xq_off<bf16_t, 64>(q, d)) = M[e];
+        }
+        __syncthreads();
+        const int grp = lane >> 4, i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3, dsub = grp & 1;
+        const int dcol = 16 * dsub + 4 * piece, q0 = 8 * half + jrow;
+        s16x4 lo = lds_read_tr16_b64(lds + xq_off<bf16_t, 64>(q0, dcol));
+        s16x4 hi = lds_read_tr16_b64(lds + xq_off<bf16_t, 64>(q0 + 4, dcol));
+        short* O = reinterpret_cast<short*>(out);
+        for (int e = 0; e < 4; ++e) { O[lane * 8 + e] = lo[e]; O[lane * 8 + 4 + e] = hi[e]; }
+    }
+}
+
+}  // namespace crossclr

@@ -1,0 +1,187 @@
+// hip_emu.h -- TEST INFRASTRUCTURE.  A minimal lane-level emulation of the HIP/gfx950 features the
+// CrossCLR kernels use, so the *same kernel source* can be executed on CPU threads and checked
+// against the oracle before any GPU time is spent.  One OS thread per lane; __syncthreads and
+// wave-collective operations (MFMA, shuffles, transpose reads) are pthread barriers plus a per-wave
+// exchange area.  Blocks run one after another, so `__shared__` is plain static storage.
+//
+// The MFMA and ds_read_b64_tr_b16 models follow the layouts documented for gfx950; whether the
+// hardware agrees is checked ON the hardware by tests/test_hw_assumptions.py (crossclr_selftest).
+// Nothing in the product package includes this file.
+#pragma once
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <cmath>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define CROSSCLR_SHARED static
+
+namespace emu {
+
+struct WaveCtx {
+    pthread_barrier_t bar;
+    alignas(64) unsigned char slot[64][64];  // per-lane exchange area
+};
+struct BlockCtx {
+    pthread_barrier_t bar;
+    std::vector<WaveCtx*> waves;
+    int nthreads;
+};
+
+extern thread_local dim3 t_threadIdx;
+extern thread_local dim3 t_blockIdx;
+extern thread_local BlockCtx* t_block;
+extern thread_local int t_tid;
+extern dim3 g_blockDim, g_gridDim;
+
+inline WaveCtx& my_wave() { return *t_block->waves[t_tid >> 6]; }
+inline int my_lane() { return t_tid & 63; }
+inline void wave_sync() { pthread_barrier_wait(&my_wave().bar); }
+
+template <typename K, typename... Args>
+void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+    const int nthreads = (int)(block.x * block.y * block.z);
+    const int nwaves = (nthreads + 63) / 64;
+    g_blockDim = block;
+    g_gridDim = grid;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                BlockCtx ctx;
+                ctx.nthreads = nthreads;
+                pthread_barrier_init(&ctx.bar, nullptr, nthreads);
+                for (int w = 0; w < nwaves; ++w) {
+                    WaveCtx* wc = new WaveCtx;
+                    int lanes = nthreads - w * 64 < 64 ? nthreads - w * 64 : 64;
+                    pthread_barrier_init(&wc->bar, nullptr, lanes);
+                    ctx.waves.push_back(wc);
+                }
+                std::vector<std::thread> th;
+                th.reserve(nthreads);
+                for (int t = 0; t < nthreads; ++t) {
+                    th.emplace_back([&, t]() {
+                        t_tid = t;
+                        t_block = &ctx;
+                        t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                        t_blockIdx = dim3(bx, by, bz);
+                        kernel(args...);
+                    });
+                }
+                for (auto& x : th) x.join();
+                for (auto* wc : ctx.waves) {
+                    pthread_barrier_destroy(&wc->bar);
+                    delete wc;
+                }
+                pthread_barrier_destroy(&ctx.bar);
+            }
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+
+inline void __syncthreads() { pthread_barrier_wait(&emu::t_block->bar); }
+
+namespace crossclr {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// exchange helper: every lane publishes `v`, then reads lane `src`'s value
+template <typename T> inline T wave_read_lane(T v, int src) {
+    static_assert(sizeof(T) <= 64, "exchange slot too small");
+    emu::WaveCtx& w = emu::my_wave();
+    memcpy(w.slot[emu::my_lane()], &v, sizeof(T));
+    emu::wave_sync();
+    T r;
+    memcpy(&r, w.slot[src], sizeof(T));
+    emu::wave_sync();
+    return r;
+}
+inline float wave_xor_f32(float v, int mask) { return wave_read_lane(v, emu::my_lane() ^ mask); }
+inline double wave_xor_f64(double v, int mask) { return wave_read_lane(v, emu::my_lane() ^ mask); }
+inline float fast_exp2(float x) { return exp2f(x); }
+
+// v_mfma_f32_32x32x16_bf16: A[i][k] in lane i + 32*(k/8), element k%8; B[k][j] in lane j + 32*(k/8),
+// element k%8; C[i][j] in lane j + 32*((i/4)%2), register (i%4) + 4*(i/8).
+inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    emu::WaveCtx& w = emu::my_wave();
+    const int lane = emu::my_lane();
+    struct AB { bf16x8 a, b; };
+    AB mine{a, b};
+    memcpy(w.slot[lane], &mine, sizeof(mine));
+    emu::wave_sync();
+    const int j = lane & 31, half = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float s = c[r];
+        for (int k = 0; k < 16; ++k) {
+            AB la, lb;
+            memcpy(&la, w.slot[i + 32 * (k >> 3)], sizeof(AB));
+            memcpy(&lb, w.slot[j + 32 * (k >> 3)], sizeof(AB));
+            s += (float)la.a[k & 7] * (float)lb.b[k & 7];
+        }
+        c[r] = s;
+    }
+    emu::wave_sync();
+    return c;
+}
+// v_mfma_f32_32x32x2_f32: A[i][k] in lane i + 32k, B[k][j] in lane j + 32k (k = 0, 1)
+inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    emu::WaveCtx& w = emu::my_wave();
+    const int lane = emu::my_lane();
+    float mine[2] = {a, b};
+    memcpy(w.slot[lane], mine, sizeof(mine));
+    emu::wave_sync();
+    const int j = lane & 31, half = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float s = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float la[2], lb[2];
+            memcpy(la, w.slot[i + 32 * k], sizeof(la));
+            memcpy(lb, w.slot[j + 32 * k], sizeof(lb));
+            s = fmaf(la[0], lb[1], s);
+        }
+        c[r] = s;
+    }
+    emu::wave_sync();
+    return c;
+}
+// ds_read_b64_tr_b16: within each 16-lane group, lane i receives, for j = 0..3, element (i & 3) of
+// the 8-byte piece addressed by lane 4j + (i >> 2) of the same group.
+inline s16x4 lds_read_tr16_b64(const void* p) {
+    emu::WaveCtx& w = emu::my_wave();
+    const int lane = emu::my_lane();
+    memcpy(w.slot[lane], p, 8);
+    emu::wave_sync();
+    const int base = lane & ~15, i = lane & 15;
+    s16x4 r;
+    for (int j = 0; j < 4; ++j) {
+        short piece[4];
+        memcpy(piece, w.slot[base + 4 * j + (i >> 2)], 8);
+        r[j] = piece[i & 3];
+    }
+    emu::wave_sync();
+    return r;
+}
+
+}  // namespace crossclr
