@@ -52,7 +52,9 @@ def test_fp32_mode_matches_golden_loss_and_grads(name):
     assert abs(loss.item() - m["loss"]) <= ltol
     arr = golden_arrays(name)
     scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
-    gtol = (2e-2 if half_in else 2e-4) * scale
+    # + fp32 cancellation floor: the positive-pair term (p_ii - 1)/(B tau) is formed in fp32 here and in
+    # fp64 by the reference's softmax; it matters only where the gradient itself is ~1e-14 (aligned regime)
+    gtol = (2e-2 if half_in else 2e-4) * scale + 1e-7 / (m["B"] * m["temperature"])
     assert np.abs(gv.double().cpu().numpy() - arr["grad_v"].astype(np.float64)).max() <= gtol
     assert np.abs(gt.double().cpu().numpy() - arr["grad_t"].astype(np.float64)).max() <= gtol
 
