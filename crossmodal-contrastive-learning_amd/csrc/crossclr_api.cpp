@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace crossclr;
@@ -63,7 +64,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     plan->fast_path = 0;
     int dpad = round_up(D, 64);
 #ifndef CROSSCLR_NO_FAST
-    if (mode == CROSSCLR_MODE_BF16) {
+    if (mode == CROSSCLR_MODE_BF16 && !getenv("CROSSCLR_DISABLE_FAST")) {  // env knob: A/B against the generic path
         int fp = fast_dpad(D);
         if (fp > 0) { dpad = fp; plan->fast_path = 1; }
     }

@@ -1,0 +1,337 @@
+// crossclr_kernels_fast.h -- register-resident bf16 kernels (the BASELINE headline path).
+//
+// Shape of both kernels (flash-attention-like, nothing O(B^2) ever leaves the CU):
+//   * a wavefront owns 32 rows p of the batch and keeps their normalised embeddings in VGPRs as
+//     MFMA B-fragments for the whole kernel (Dpad/4 VGPRs: 128 at D=512);
+//   * 64-column tiles of the column operand stream through a 2-deep LDS ring filled by LDS-DMA
+//     (global_load_lds, 16 B/lane), one barrier per tile, the next tile in flight during compute;
+//   * S^T = Xq . Xp^T is computed with SWAPPED operands so lane (l&31) owns row p and 16 columns:
+//     row-wise soft-max sums need no cross-lane traffic, and in the backward the 32x32 fragment,
+//     turned into W = s E (1/Z_p + 1/Z_q) and packed to bf16, IS the A operand of the second MFMA
+//     (k <-> q permuted consistently on both operands), so W never touches LDS;
+//   * the second MFMA contracts over q, the ROW index of the LDS tile: its B fragments come from
+//     ds_read_b64_tr_b16 (16-lane-group transpose read) of the same tile -- one tile, two uses.
+// LDS tile layout: row q of the tile at q*RB, 16-byte chunk c at slot (c & ~15) | ((c ^ sigma(q)) & 15),
+// sigma(q) = ((q&3)<<2) | ((q>>2)&3): conflict-free for BOTH the ds_read_b128 column reads of the
+// first MFMA (16 rows distinct mod 16 -> 16 distinct slots) and the transpose reads of the second
+// (4 consecutive rows -> 4 different 64-byte bank groups).  The DMA writes LDS lane-linearly, so the
+// permutation is applied to the per-lane GLOBAL source address (same 16-chunk group of the same row:
+// coalescing is unaffected).
+#pragma once
+#include "crossclr_device.h"
+#include "../../include/crossclr.h"
+
+namespace crossclr {
+
+#ifndef CROSSCLR_EMU
+// 64 lanes x 16 B (or 4 B) from per-lane global addresses to LDS at wave-uniform base + lane*size
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+
+static inline int fast_dpad(int D) {
+    if (D <= 128) return 128;
+    if (D <= 256) return 256;
+    if (D <= 384) return 384;
+    if (D <= 512) return 512;
+    return 0;
+}
+
+__device__ __forceinline__ int sigma16(int q) { return ((q & 3) << 2) | ((q >> 2) & 3); }
+__device__ __forceinline__ int swz_slot(int chunk, int q) { return (chunk & ~15) | ((chunk ^ sigma16(q)) & 15); }
+
+// Issue this wave's share of the LDS-DMA for one 64-row column tile (+ optionally its 64 per-column
+// statistics).  NW waves cooperate; wave-instruction ii fills LDS bytes [ii*1024, ii*1024+1024).
+template <int RB, int NW>
+__device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, unsigned char* buf, int wave, int lane,
+                                               const float* stat_src, unsigned char* stat_dst) {
+    constexpr int kInstr = RB / 16;  // 64 rows * RB bytes / 1024
+#pragma unroll
+    for (int k = 0; k < (kInstr + NW - 1) / NW; ++k) {
+        const int ii = wave + NW * k;
+        if (kInstr % NW == 0 || ii < kInstr) {
+            const int L = ii * 1024 + lane * 16;
+            const int row = L / RB, slot = (L - row * RB) >> 4;
+            lds_dma16(tile_src + (size_t)row * RB + (swz_slot(slot, row) << 4), buf + ii * 1024);
+        }
+    }
+    if (stat_src != nullptr && wave == 0) lds_dma4(stat_src + lane, stat_dst);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward denominators: 8 waves x 32 rows per block, grid = (2*bpad/256, nsplit)
+// ---------------------------------------------------------------------------------------------
+template <int DK>
+__global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
+                                                          int tiles_per_split, float* part) {
+    constexpr int RB = DK * 32;            // bytes per operand row
+    constexpr int TILE = 64 * RB;
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int row0w = blockIdx.x * 256 + 32 * wave;
+    const int rmod = row0w / g.bpad;
+    const int r_in_mod = row0w - rmod * g.bpad + l31;   // this lane's row inside its modality
+
+    bf16x8 pf[DK];
+    {
+        const bf16_t* src = rows + (size_t)(row0w + l31) * (DK * 16) + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
+    }
+    // byte offset of logical chunk (2j + half) + 16*hi of this lane's tile rows (l31 and l31 + 32)
+    int off8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
+
+    const int ntiles = g.col_ranks * 2 * g.bpad / 64;
+    const int per_rank = 2 * g.bpad / 64;
+    int t = blockIdx.y * tiles_per_split;
+    int t_end = t + tiles_per_split;
+    if (t_end > ntiles) t_end = ntiles;
+    auto skip = [&](int x) {  // first tile >= x that is not in the skipped rank
+        if (g.skip_rank >= 0 && x < t_end && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
+        return x;
+    };
+    t = skip(t);
+    float rowacc = 0.f;
+    int cur = 0;
+    const size_t pitch = RB;
+    if (t < t_end)
+        issue_tile_dma<RB, 8>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, t, 64).row0 * pitch, lds, wave,
+                              lane, nullptr, nullptr);
+    while (t < t_end) {
+        const int tn = skip(t + 1);
+        wait_dma();
+        __syncthreads();  // tile t landed everywhere; every wave is done with the other buffer
+        if (tn < t_end)
+            issue_tile_dma<RB, 8>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tn, 64).row0 * pitch,
+                                  lds + (cur ^ 1) * TILE, wave, lane, nullptr, nullptr);
+        const ColTile ct = col_tile(g, t, 64);
+        const unsigned char* bt = lds + cur * TILE;
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            const unsigned char* a = bt + off8[ks & 7] + (ks >> 3) * 256;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
+            acc[0] = mfma_32x32x16_bf16(a0, pf[ks], acc[0]);
+            acc[1] = mfma_32x32x16_bf16(a1, pf[ks], acc[1]);
+        }
+        const bool same_mod = (ct.mod == rmod);
+        const float c2 = same_mod ? g.c_intra : g.c_inter;
+        const bool diag_tile = same_mod && ct.rank == g.row_rank;
+        const bool ragged = ct.in_mod0 + 64 > g.b;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q_in_mod = ct.in_mod0 + 32 * qi + frag_row(r, half);
+                float e = fast_exp2(acc[qi][r] * c2 - g.m2);
+                if (ragged && q_in_mod >= g.b) e = 0.f;
+                if (diag_tile && q_in_mod == r_in_mod) e = 0.f;
+                rowacc += e;
+            }
+        cur ^= 1;
+        t = tn;
+    }
+    rowacc += wave_xor_f32(rowacc, 32);
+    if (half == 0) part[(size_t)blockIdx.y * 2 * g.bpad + row0w + l31] = rowacc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: 4 waves x 32 rows per block, ONE wave per SIMD so each wave owns the whole 512-entry
+// register file: 32 x Dpad fp32 gradient accumulators (256 at D=512) + Dpad/4 operand VGPRs.
+// grid = 2*bpad/128 blocks; every block walks all column tiles.
+// ---------------------------------------------------------------------------------------------
+template <int DK>
+__global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
+                                                          const float* rz_rows, const float* wrz_rows,
+                                                          const float* rz_cols, const float* wrz_cols, float* gbuf,
+                                                          int accumulate) {
+    constexpr int RB = DK * 32;
+    constexpr int TILE = 64 * RB;
+    constexpr int DT = DK / 2;             // 32-wide output fragments
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * TILE + 2 * 256];
+    unsigned char* stat = lds + 2 * TILE;  // [2][64] floats: 1/Z (or w/Z) of the tile's columns
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int row0w = blockIdx.x * 128 + 32 * wave;
+    const int rmod = row0w / g.bpad;
+    const int r_in_mod = row0w - rmod * g.bpad + l31;
+
+    bf16x8 pf[DK];
+    {
+        const bf16_t* src = rows + (size_t)(row0w + l31) * (DK * 16) + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
+    }
+    const float rzp_inter = rz_rows[row0w + l31];
+    const float rzp_intra = wrz_rows[row0w + l31];
+
+    int off8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
+    // transpose-read roles: in a 16-lane group lane 4j+c addresses row j, 8-byte piece c
+    const int grp = lane >> 4, i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3, dsub = grp & 1;
+    // address of (row q = base + 8u + 4half + jrow, col = 32dt + 16dsub + 4piece):
+    //   q*RB + 256*(dt>>2) + 64*((dt&3)^jrow) + 16*((2dsub + piece/2) ^ (2u + half)) + 8*(piece&1)
+    int comb[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            comb[k][u] = (4 * half + jrow) * RB + 64 * (k ^ jrow) + 16 * ((2 * dsub + (piece >> 1)) ^ (2 * u + half)) +
+                         8 * (piece & 1);
+
+    f32x16 acc2[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
+
+    const int ntiles = g.col_ranks * 2 * g.bpad / 64;
+    const int per_rank = 2 * g.bpad / 64;
+    auto skip = [&](int x) {
+        if (g.skip_rank >= 0 && x < ntiles && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
+        return x;
+    };
+    auto stat_src = [&](const ColTile& ct) { return ((ct.mod == rmod) ? wrz_cols : rz_cols) + ct.stat0; };
+    // NOTE: all four waves of a block must agree on which statistics array a tile uses; a block's 128
+    // rows never straddle the modality boundary because bpad is a multiple of 128.
+    int t = skip(0), cur = 0;
+    const size_t pitch = RB;
+    if (t < ntiles) {
+        const ColTile c0 = col_tile(g, t, 64);
+        issue_tile_dma<RB, 4>(reinterpret_cast<const unsigned char*>(cols) + c0.row0 * pitch, lds, wave, lane,
+                              stat_src(c0), stat);
+    }
+    while (t < ntiles) {
+        const int tn = skip(t + 1);
+        wait_dma();
+        __syncthreads();
+        if (tn < ntiles) {
+            const ColTile cn = col_tile(g, tn, 64);
+            issue_tile_dma<RB, 4>(reinterpret_cast<const unsigned char*>(cols) + cn.row0 * pitch, lds + (cur ^ 1) * TILE,
+                                  wave, lane, stat_src(cn), stat + (cur ^ 1) * 256);
+        }
+        const ColTile ct = col_tile(g, t, 64);
+        const unsigned char* bt = lds + cur * TILE;
+        // ---- S^T = Xq . Xp^T ----
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            const unsigned char* a = bt + off8[ks & 7] + (ks >> 3) * 256;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
+            acc[0] = mfma_32x32x16_bf16(a0, pf[ks], acc[0]);
+            acc[1] = mfma_32x32x16_bf16(a1, pf[ks], acc[1]);
+        }
+        // ---- W = s E (1/Z_p + 1/Z_q), packed to bf16 A fragments in place ----
+        const bool same_mod = (ct.mod == rmod);
+        const float c2 = same_mod ? g.c_intra : g.c_inter;
+        const float rzp = same_mod ? rzp_intra : rzp_inter;
+        const bool diag_tile = same_mod && ct.rank == g.row_rank;
+        const float* rzq = reinterpret_cast<const float*>(stat + cur * 256);
+        bf16x8 af[4];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int th = 0; th < 2; ++th) {
+                struct { bf16_t e[8]; } pk;
+#pragma unroll
+                for (int r4 = 0; r4 < 2; ++r4) {
+                    const int q0 = 32 * qi + 16 * th + 8 * r4 + 4 * half;  // = 32qi + frag_row(8th + 4r4, half)
+                    const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float e = fast_exp2(acc[qi][8 * th + 4 * r4 + j] * c2 - g.m2);
+                        float w = e * (rzp + rq[j]);
+                        if (diag_tile && ct.in_mod0 + q0 + j == r_in_mod) w = 0.f;
+                        pk.e[4 * r4 + j] = f32_to_bf16_bits(w);
+                    }
+                }
+                af[2 * qi + th] = __builtin_bit_cast(bf16x8, pk);
+            }
+        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 64 rows) ----
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const unsigned char* b0 = bt + comb[dt & 3][0] + (16 * tp) * RB + 256 * (dt >> 2);
+                const unsigned char* b1 = bt + comb[dt & 3][1] + (16 * tp + 8) * RB + 256 * (dt >> 2);
+                struct { s16x4 lo, hi; } pair = {lds_read_tr16_b64(b0), lds_read_tr16_b64(b1)};
+                acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, pair), acc2[dt]);
+            }
+        }
+        cur ^= 1;
+        t = tn;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* dst = gbuf + (size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31;
+            *dst = accumulate ? (*dst + acc2[dt][r]) : acc2[dt][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (called from crossclr_api.cpp)
+// ---------------------------------------------------------------------------------------------
+#ifdef CROSSCLR_EMU
+#define CROSSCLR_FAST_LAUNCH(kernel, grid, block, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)
+#else
+#define CROSSCLR_FAST_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
+                               void* stream) {
+    const int ntiles = g.col_ranks * 2 * p->bpad / 64;
+    const int nsplit = p->fwd_slots;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    dim3 grid(2 * p->bpad / 256, nsplit), block(512);
+    const bf16_t* r = (const bf16_t*)rows;
+    const bf16_t* c = (const bf16_t*)cols;
+    switch (p->Dpad) {
+        case 128: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<8>), grid, block, stream, r, c, g, tps, part); break;
+        case 256: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<16>), grid, block, stream, r, c, g, tps, part); break;
+        case 384: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<24>), grid, block, stream, r, c, g, tps, part); break;
+        case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32>), grid, block, stream, r, c, g, tps, part); break;
+        default: return CROSSCLR_E_ARG;
+    }
+    return CROSSCLR_OK;
+}
+
+static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
+                                const float* rz_rows, const float* wrz_rows, const float* rz_cols,
+                                const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
+    dim3 grid(2 * p->bpad / 128), block(256);
+    const bf16_t* r = (const bf16_t*)rows;
+    const bf16_t* c = (const bf16_t*)cols;
+    switch (p->Dpad) {
+        case 128: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<8>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
+        case 256: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<16>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
+        case 384: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<24>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
+        case 512: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<32>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
+        default: return CROSSCLR_E_ARG;
+    }
+    return CROSSCLR_OK;
+}
+
+}  // namespace crossclr

@@ -21,7 +21,7 @@ def sources():
 def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
-    cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DCROSSCLR_EMU", "-DCROSSCLR_NO_FAST", "-I", HERE, "-I", CSRC,
+    cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DCROSSCLR_EMU", "-I", HERE, "-I", CSRC,
            "-Wno-unused-value", "-Wno-psabi", os.path.join(CSRC, "crossclr_api.cpp"), os.path.join(HERE, "emu_runtime.cpp"), "-o", OUT]
     subprocess.check_call(cmd)
     return OUT

@@ -184,4 +184,14 @@ inline s16x4 lds_read_tr16_b64(const void* p) {
     return r;
 }
 
+// LDS-DMA (global_load_lds): lane l's bytes land at the wave-uniform base + l*size
+inline void lds_dma16(const void* gsrc, void* lds_wave_base) {
+    memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * emu::my_lane(), gsrc, 16);
+}
+inline void lds_dma4(const void* gsrc, void* lds_wave_base) {
+    memcpy(static_cast<unsigned char*>(lds_wave_base) + 4 * emu::my_lane(), gsrc, 4);
+}
+inline void wait_dma() {}
+inline int uniform(int x) { return x; }
+
 }  // namespace crossclr
