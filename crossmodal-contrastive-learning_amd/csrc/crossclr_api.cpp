@@ -78,9 +78,20 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     if (nsplit > col_tiles) nsplit = col_tiles;
     if (nsplit < 1) nsplit = 1;
     plan->fwd_slots = nsplit;
+    // backward column slices (fast path only): one block per CU needs >= 256 blocks of 128 rows
+    plan->bwd_slices = 1;
+    if (plan->fast_path) {
+        const int rb = 2 * plan->bpad / 128;
+        int sl = (256 + rb - 1) / rb;
+        const int tiles = 2 * plan->bpad / 32;
+        if (sl > tiles / 8) sl = tiles / 8;   // keep >= 8 column tiles per slice
+        if (sl > 16) sl = 16;
+        if (sl < 1) sl = 1;
+        plan->bwd_slices = sl;
+    }
     const size_t esz = mode == CROSSCLR_MODE_FP32 ? 4 : 2;
     plan->operand_bytes = (size_t)2 * plan->bpad * plan->Dpad * esz;
-    plan->gbuf_bytes = (size_t)2 * plan->bpad * plan->Dpad * 4;
+    plan->gbuf_bytes = (size_t)plan->bwd_slices * 2 * plan->bpad * plan->Dpad * 4;
     return CROSSCLR_OK;
 }
 
@@ -219,7 +230,7 @@ static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const vo
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((2 * p->b + 3) / 4), block(256);
-    LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,
+    LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,
            1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt);
     return launch_status("bwd_finish_kernel");
 }

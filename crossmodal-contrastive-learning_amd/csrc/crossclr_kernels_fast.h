@@ -34,6 +34,8 @@ __device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave_base) 
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's most recent VMEM operations are still in flight
+template <int N> __device__ __forceinline__ void wait_dma_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 #endif
 
@@ -50,10 +52,10 @@ __device__ __forceinline__ int swz_slot(int chunk, int q) { return (chunk & ~15)
 
 // Issue this wave's share of the LDS-DMA for one 64-row column tile (+ optionally its 64 per-column
 // statistics).  NW waves cooperate; wave-instruction ii fills LDS bytes [ii*1024, ii*1024+1024).
-template <int RB, int NW>
+template <int RB, int NW, int QT>
 __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, unsigned char* buf, int wave, int lane,
                                                const float* stat_src, unsigned char* stat_dst) {
-    constexpr int kInstr = RB / 16;  // 64 rows * RB bytes / 1024
+    constexpr int kInstr = QT * RB / 1024;  // wave-instructions per tile
 #pragma unroll
     for (int k = 0; k < (kInstr + NW - 1) / NW; ++k) {
         const int ii = wave + NW * k;
@@ -63,7 +65,9 @@ __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, un
             lds_dma16(tile_src + (size_t)row * RB + (swz_slot(slot, row) << 4), buf + ii * 1024);
         }
     }
-    if (stat_src != nullptr && wave == 0) lds_dma4(stat_src + lane, stat_dst);
+    // every wave issues the (identical) statistics DMA so that all waves have the same VMEM count per tile:
+    // the counted s_waitcnt vmcnt(N) in the backward relies on it
+    if (stat_src != nullptr && lane < QT) lds_dma4(stat_src + lane, stat_dst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -107,14 +111,14 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
     int cur = 0;
     const size_t pitch = RB;
     if (t < t_end)
-        issue_tile_dma<RB, 8>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, t, 64).row0 * pitch, lds, wave,
+        issue_tile_dma<RB, 8, 64>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, t, 64).row0 * pitch, lds, wave,
                               lane, nullptr, nullptr);
     while (t < t_end) {
         const int tn = skip(t + 1);
         wait_dma();
         __syncthreads();  // tile t landed everywhere; every wave is done with the other buffer
         if (tn < t_end)
-            issue_tile_dma<RB, 8>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tn, 64).row0 * pitch,
+            issue_tile_dma<RB, 8, 64>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tn, 64).row0 * pitch,
                                   lds + (cur ^ 1) * TILE, wave, lane, nullptr, nullptr);
         const ColTile ct = col_tile(g, t, 64);
         const unsigned char* bt = lds + cur * TILE;
@@ -153,18 +157,22 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
 // ---------------------------------------------------------------------------------------------
 // backward: 4 waves x 32 rows per block, ONE wave per SIMD so each wave owns the whole 512-entry
 // register file: 32 x Dpad fp32 gradient accumulators (256 at D=512) + Dpad/4 operand VGPRs.
-// grid = 2*bpad/128 blocks; every block walks all column tiles.
+// Column tiles are 32 rows (32 KiB at D=512) in a 3-deep LDS-DMA ring.  grid = (2*bpad/128, slices):
+// slice y walks its share of the column tiles and writes its own gradient slice (summed by the
+// finish kernel) -- that is what fills all 256 CUs at B=8192 without atomics.
 // ---------------------------------------------------------------------------------------------
 template <int DK>
 __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
                                                           const float* rz_rows, const float* wrz_rows,
                                                           const float* rz_cols, const float* wrz_cols, float* gbuf,
-                                                          int accumulate) {
+                                                          int accumulate, int tiles_per_slice) {
     constexpr int RB = DK * 32;
-    constexpr int TILE = 64 * RB;
+    constexpr int QT = 32;                 // columns per tile
+    constexpr int TILE = QT * RB;
+    constexpr int NST = 3;                 // ring depth
     constexpr int DT = DK / 2;             // 32-wide output fragments
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * TILE + 2 * 256];
-    unsigned char* stat = lds + 2 * TILE;  // [2][64] floats: 1/Z (or w/Z) of the tile's columns
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128];
+    unsigned char* stat = lds + NST * TILE;  // [NST][32] floats: 1/Z (or w/Z) of the tile's columns
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -202,90 +210,101 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
 
-    const int ntiles = g.col_ranks * 2 * g.bpad / 64;
-    const int per_rank = 2 * g.bpad / 64;
+    const int ntiles = g.col_ranks * 2 * g.bpad / QT;
+    const int per_rank = 2 * g.bpad / QT;
+    int t = blockIdx.y * tiles_per_slice;
+    int t_end = t + tiles_per_slice;
+    if (t_end > ntiles) t_end = ntiles;
     auto skip = [&](int x) {
-        if (g.skip_rank >= 0 && x < ntiles && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
+        if (g.skip_rank >= 0 && x < t_end && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
         return x;
     };
-    auto stat_src = [&](const ColTile& ct) { return ((ct.mod == rmod) ? wrz_cols : rz_cols) + ct.stat0; };
-    // NOTE: all four waves of a block must agree on which statistics array a tile uses; a block's 128
-    // rows never straddle the modality boundary because bpad is a multiple of 128.
-    int t = skip(0), cur = 0;
     const size_t pitch = RB;
-    if (t < ntiles) {
-        const ColTile c0 = col_tile(g, t, 64);
-        issue_tile_dma<RB, 4>(reinterpret_cast<const unsigned char*>(cols) + c0.row0 * pitch, lds, wave, lane,
-                              stat_src(c0), stat);
-    }
-    while (t < ntiles) {
-        const int tn = skip(t + 1);
-        wait_dma();
-        __syncthreads();
-        if (tn < ntiles) {
-            const ColTile cn = col_tile(g, tn, 64);
-            issue_tile_dma<RB, 4>(reinterpret_cast<const unsigned char*>(cols) + cn.row0 * pitch, lds + (cur ^ 1) * TILE,
-                                  wave, lane, stat_src(cn), stat + (cur ^ 1) * 256);
-        }
-        const ColTile ct = col_tile(g, t, 64);
-        const unsigned char* bt = lds + cur * TILE;
-        // ---- S^T = Xq . Xp^T ----
-        f32x16 acc[2];
+    // a block's 128 rows never straddle the modality boundary (bpad is a multiple of 128), so all four
+    // waves agree on which per-column statistics array (1/Z or w/Z) a tile needs
+    auto issue = [&](int tile, int stage) {
+        const ColTile c = col_tile(g, tile, QT);
+        issue_tile_dma<RB, 4, QT>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE, wave,
+                                  lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128);
+    };
+    t = skip(t);
+    int t1 = t < t_end ? skip(t + 1) : t_end;   // the tile after t
+    if (t < t_end) issue(t, 0);
+    if (t1 < t_end) issue(t1, 1);
+    int stage = 0;
+    while (t < t_end) {
+        const int t2 = t1 < t_end ? skip(t1 + 1) : t_end;
+        // tile t must have landed: at most the DMA of tile t1 (issued after it) may stay in flight
+        if (t1 < t_end) wait_dma_keep<DK / 4 + 1>(); else wait_dma();
+        __syncthreads();  // tile t visible to all; all waves finished tile t-1 -> its stage is free
+        if (t2 < t_end) issue(t2, stage == 0 ? 2 : stage - 1);
+        const ColTile ct = col_tile(g, t, QT);
+        const unsigned char* bt = lds + stage * TILE;
+        // ---- S^T = Xq . Xp^T : C[q][p], lane owns row p = l31 ----
+        f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            bf16x8 a_nxt = *reinterpret_cast<const bf16x8*>(bt + off8[0]);
 #pragma unroll
-        for (int ks = 0; ks < DK; ++ks) {
-            const unsigned char* a = bt + off8[ks & 7] + (ks >> 3) * 256;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
-            acc[0] = mfma_32x32x16_bf16(a0, pf[ks], acc[0]);
-            acc[1] = mfma_32x32x16_bf16(a1, pf[ks], acc[1]);
+            for (int ks = 0; ks < DK; ++ks) {
+                const bf16x8 a_cur = a_nxt;
+                if (ks + 1 < DK)
+                    a_nxt = *reinterpret_cast<const bf16x8*>(bt + off8[(ks + 1) & 7] + ((ks + 1) >> 3) * 256);
+                acc = mfma_32x32x16_bf16(a_cur, pf[ks], acc);
+            }
         }
         // ---- W = s E (1/Z_p + 1/Z_q), packed to bf16 A fragments in place ----
         const bool same_mod = (ct.mod == rmod);
         const float c2 = same_mod ? g.c_intra : g.c_inter;
         const float rzp = same_mod ? rzp_intra : rzp_inter;
-        const bool diag_tile = same_mod && ct.rank == g.row_rank;
-        const float* rzq = reinterpret_cast<const float*>(stat + cur * 256);
-        bf16x8 af[4];
+        const bool diag_tile = same_mod && ct.rank == g.row_rank && ct.in_mod0 == (r_in_mod - l31);
+        const float* rzq = reinterpret_cast<const float*>(stat + stage * 128);
+        bf16x8 af[2];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
+        for (int th = 0; th < 2; ++th) {
+            struct { bf16_t e[8]; } pk;
 #pragma unroll
-            for (int th = 0; th < 2; ++th) {
-                struct { bf16_t e[8]; } pk;
+            for (int r4 = 0; r4 < 2; ++r4) {
+                const int q0 = 16 * th + 8 * r4 + 4 * half;  // = frag_row(8th + 4r4, half)
+                const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
 #pragma unroll
-                for (int r4 = 0; r4 < 2; ++r4) {
-                    const int q0 = 32 * qi + 16 * th + 8 * r4 + 4 * half;  // = 32qi + frag_row(8th + 4r4, half)
-                    const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float e = fast_exp2(acc[qi][8 * th + 4 * r4 + j] * c2 - g.m2);
-                        float w = e * (rzp + rq[j]);
-                        if (diag_tile && ct.in_mod0 + q0 + j == r_in_mod) w = 0.f;
-                        pk.e[4 * r4 + j] = f32_to_bf16_bits(w);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    float e = fast_exp2(acc[8 * th + 4 * r4 + j] * c2 - g.m2);
+                    float w = e * (rzp + rq[j]);
+                    if (diag_tile && q0 + j == l31) w = 0.f;
+                    pk.e[4 * r4 + j] = f32_to_bf16_bits(w);
                 }
-                af[2 * qi + th] = __builtin_bit_cast(bf16x8, pk);
             }
-        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 64 rows) ----
+            af[th] = __builtin_bit_cast(bf16x8, pk);
+        }
+        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows) ----
 #pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
+        for (int tp = 0; tp < 2; ++tp) {
+            struct Pair { s16x4 lo, hi; };
+            Pair nxt = {lds_read_tr16_b64(bt + comb[0][0] + (16 * tp) * RB),
+                        lds_read_tr16_b64(bt + comb[0][1] + (16 * tp + 8) * RB)};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const unsigned char* b0 = bt + comb[dt & 3][0] + (16 * tp) * RB + 256 * (dt >> 2);
-                const unsigned char* b1 = bt + comb[dt & 3][1] + (16 * tp + 8) * RB + 256 * (dt >> 2);
-                struct { s16x4 lo, hi; } pair = {lds_read_tr16_b64(b0), lds_read_tr16_b64(b1)};
-                acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, pair), acc2[dt]);
+                const Pair curp = nxt;
+                if (dt + 1 < DT) {
+                    const int d1 = dt + 1;
+                    nxt.lo = lds_read_tr16_b64(bt + comb[d1 & 3][0] + (16 * tp) * RB + 256 * (d1 >> 2));
+                    nxt.hi = lds_read_tr16_b64(bt + comb[d1 & 3][1] + (16 * tp + 8) * RB + 256 * (d1 >> 2));
+                }
+                acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, curp), acc2[dt]);
             }
         }
-        cur ^= 1;
-        t = tn;
+        stage = stage == NST - 1 ? 0 : stage + 1;
+        t = t1;
+        t1 = t2;
     }
+    float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (DK * 16);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float* dst = gbuf + (size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31;
+            float* dst = gslice + (size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31;
             *dst = accumulate ? (*dst + acc2[dt][r]) : acc2[dt][r];
         }
 }
@@ -321,14 +340,16 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
 static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                                 const float* rz_rows, const float* wrz_rows, const float* rz_cols,
                                 const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
-    dim3 grid(2 * p->bpad / 128), block(256);
+    const int ntiles = g.col_ranks * 2 * p->bpad / 32;
+    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+    dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
     switch (p->Dpad) {
-        case 128: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<8>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
-        case 256: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<16>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
-        case 384: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<24>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
-        case 512: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<32>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate); break;
+        case 128: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<8>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
+        case 256: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<16>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
+        case 384: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<24>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
+        case 512: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<32>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
         default: return CROSSCLR_E_ARG;
     }
     return CROSSCLR_OK;

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
 //   ghat = gbuf/(2 B tau) - partner_hat/(B tau);  gx = (ghat - xhat (xhat.ghat)) * inv_norm * grad_out
 // ---------------------------------------------------------------------------------------------
 template <typename TIN>
-__global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, const TIN* video, const TIN* text, long ldv,
+__global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int nslices, const TIN* video, const TIN* text, long ldv,
                                                          long ldt, Geo g, const float* inv_norm, float inv_tau,
                                                          int Bglobal, const double* grad_out, TIN* gvideo,
                                                          TIN* gtext, long ldgv, long ldgt) {
@@ -438,18 +438,24 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, cons
     const double io = (double)inv_norm[mod * g.bpad + i];
     const double ip = (double)inv_norm[(1 - mod) * g.bpad + i];
     const float* grow = gbuf + ((size_t)mod * g.bpad + i) * g.Dpad;
+    const size_t slice = (size_t)2 * g.bpad * g.Dpad;
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
     const double pc = (double)inv_tau / (double)Bglobal;
+    auto graw = [&](int d) {  // sum of the column slices, fixed order
+        float s = grow[d];
+        for (int k = 1; k < nslices; ++k) s += grow[k * slice + d];
+        return (double)s;
+    };
     double dot = 0.0;
     for (int d = lane; d < g.D; d += 64) {
-        double gh = (double)grow[d] * sc - in_load(oth, d) * ip * pc;
+        double gh = graw(d) * sc - in_load(oth, d) * ip * pc;
         dot += in_load(own, d) * io * gh;
     }
     dot = wave_sum_f64(dot);
     const bool clamped = io >= 1e12;  // ||x|| < eps: x/eps, no projection term
     const double go = grad_out[0];
     for (int d = lane; d < g.D; d += 64) {
-        double gh = (double)grow[d] * sc - in_load(oth, d) * ip * pc;
+        double gh = graw(d) * sc - in_load(oth, d) * ip * pc;
         double xh = in_load(own, d) * io;
         double v = clamped ? gh : (gh - xh * dot);
         in_store(out, d, v * io * go);

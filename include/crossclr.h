@@ -62,8 +62,9 @@ typedef struct crossclr_plan {
     int Dpad;       /* D rounded up to what the selected kernels need       */
     int fast_path;  /* 1: register-resident bf16 kernels, 0: generic tiled  */
     int fwd_slots;  /* partial-sum slots one crossclr_forward launch writes */
+    int bwd_slices; /* gradient slices crossclr_backward writes (summed by _finish) */
     size_t operand_bytes;   /* one packed operand X[2][bpad][Dpad]          */
-    size_t gbuf_bytes;      /* fp32 d(loss)/d(xhat) accumulator [2][bpad][Dpad] */
+    size_t gbuf_bytes;      /* fp32 d(loss)/d(xhat) accumulator [bwd_slices][2][bpad][Dpad] */
 } crossclr_plan;
 
 int crossclr_abi_version(void);
@@ -97,7 +98,8 @@ int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int ns
                             const float* diag_cos, float temperature, float negative_weight,
                             float* logz, float* rz, float* wrz, double* loss_sum, void* stream);
 
-/* gbuf[2][bpad][Dpad] (+)= sum_q s E(p,q) (rz_p + rz_q) xhat_q   (unscaled).    */
+/* gbuf[slice][2][bpad][Dpad] (+)= sum over the slice's columns q of s E(p,q) (rz_p + rz_q) xhat_q
+ * (unscaled); the slices are disjoint column ranges, summed by crossclr_backward_finish. */
 int crossclr_backward(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
                       int col_ranks, int col_rank0, int skip_rank,
                       float temperature, float negative_weight,

@@ -192,6 +192,7 @@ inline void lds_dma4(const void* gsrc, void* lds_wave_base) {
     memcpy(static_cast<unsigned char*>(lds_wave_base) + 4 * emu::my_lane(), gsrc, 4);
 }
 inline void wait_dma() {}
+template <int N> inline void wait_dma_keep() {}
 inline int uniform(int x) { return x; }
 
 }  // namespace crossclr

@@ -1,0 +1,133 @@
+"""CPU tests: the REAL kernel sources (crossmodal-contrastive-learning_amd/csrc) executed lane by
+lane on host threads through the emulation shim in tests/emu/ and checked against the reference's
+golden vectors.  Shapes are tiny (the emulation runs one OS thread per GPU lane); the same code at
+full size is covered by the `-m gpu` tests.  The emulated library is injected explicitly here --
+the product binding never selects it."""
+import numpy as np
+import pytest
+import torch
+
+import crossclr_amd
+from conftest import golden_arrays, golden_index, golden_inputs
+from crossclr_amd import _native as nat
+from oracle import crossclr_oracle as orc
+
+IDX = golden_index()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulated_library():
+    from emu import build_emu
+    nat.use_library_for_testing(build_emu.build())
+    assert nat.backend() == "emu-host"
+    yield
+    nat.use_library_for_testing(None)
+
+
+def run(v, t, tau, w, mode, scale=1.0):
+    vv = v.clone().requires_grad_(True)
+    tt = t.clone().requires_grad_(True)
+    loss = crossclr_amd.crossclr_loss(vv, tt, tau, w, compute_mode=mode)
+    (loss * scale).backward()
+    return loss, vv.grad, tt.grad
+
+
+TINY = ["g2_b8_d16_s1", "g4_b16_d32_s3_float32", "g4_b16_d32_s3_float64", "g4_b16_d32_s3_float16",
+        "g4_b16_d32_s3_bfloat16", "g5_zero_row_b16_d32", "g5_b1_d32", "g5_w0_tau01_b16_d32", "g5_tau01_b16_d32",
+        "g5_tau002_b32_d64"]
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_fp32_kernels_match_reference(name):
+    m = IDX[name]
+    v, t = golden_inputs(m)
+    loss, gv, gt = run(v, t, m["temperature"], m["negative_weight"], "fp32")
+    assert loss.dtype == torch.float64 and loss.dim() == 0
+    assert gv.dtype == v.dtype
+    half_in = m["dtype"] in ("float16", "bfloat16")
+    assert abs(loss.item() - m["loss"]) <= (5e-3 if half_in else 2e-5 * max(1.0, abs(m["loss"])))
+    arr = golden_arrays(name)
+    scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
+    tol = (2e-2 if half_in else 2e-4) * scale
+    assert np.abs(gv.double().numpy() - arr["grad_v"].astype(np.float64)).max() <= tol
+    assert np.abs(gt.double().numpy() - arr["grad_t"].astype(np.float64)).max() <= tol
+
+
+@pytest.mark.parametrize("name", ["g2_b8_d16_s1", "g4_b16_d32_s3_float32", "g5_b1_d32", "g5_tau002_b32_d64"])
+def test_bf16_fast_kernels_match_bf16_model(name):
+    m = IDX[name]
+    v, t = golden_inputs(m)
+    plan = nat.make_plan(m["B"], m["D"], 1, 0, nat.MODE_BF16)
+    assert plan.fast_path == 1 and plan.Dpad == 128
+    loss, gv, gt = run(v, t, m["temperature"], m["negative_weight"], "bf16")
+    model = float(orc.bf16_operand_model_loss(v, t, m["temperature"], m["negative_weight"]))
+    assert abs(loss.item() - model) <= 5e-5 * max(1.0, abs(model))
+    arr = golden_arrays(name)
+    scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
+    assert np.abs(gv.numpy() - arr["grad_v"]).max() <= 2e-2 * scale
+    assert np.abs(gt.numpy() - arr["grad_t"]).max() <= 2e-2 * scale
+
+
+def test_bf16_generic_kernels_match_bf16_model(monkeypatch):
+    monkeypatch.setenv("CROSSCLR_DISABLE_FAST", "1")
+    m = IDX["g4_b16_d32_s3_float32"]
+    v, t = golden_inputs(m)
+    assert nat.make_plan(16, 32, 1, 0, nat.MODE_BF16).fast_path == 0
+    loss, gv, gt = run(v, t, m["temperature"], m["negative_weight"], "bf16")
+    model = float(orc.bf16_operand_model_loss(v, t, m["temperature"], m["negative_weight"]))
+    assert abs(loss.item() - model) <= 5e-5 * max(1.0, abs(model))
+    arr = golden_arrays("g4_b16_d32_s3_float32")
+    assert np.abs(gv.numpy() - arr["grad_v"]).max() <= 2e-2 * m["grad_v_absmax"]
+
+
+def test_ragged_batch_crossing_a_tile_boundary():
+    # B = 70: one full 64-column tile + a ragged one in the fast path; a ragged 128 tile in the generic path
+    v, t = orc.make_inputs("randn", 70, 24, 17)
+    ref = orc.streaming_loss_and_grads(v, t, 0.07, 0.6)
+    for mode, ltol, gtol in (("fp32", 1e-5, 2e-4), ("bf16", 3e-3, 2e-2)):
+        loss, gv, gt = run(v, t, 0.07, 0.6, mode)
+        assert abs(loss.item() - float(ref["loss"])) <= ltol
+        scale = ref["grad_v"].abs().max().item()
+        assert (gv.double() - ref["grad_v"]).abs().max().item() <= gtol * scale
+        assert (gt.double() - ref["grad_t"]).abs().max().item() <= gtol * scale
+
+
+def test_grad_output_scaling_and_noncontiguous_rows():
+    v, t = orc.make_inputs("randn", 12, 20, 5)
+    _, g1, _ = run(v, t, 0.05, 0.8, "fp32", 1.0)
+    _, g2, _ = run(v, t, 0.05, 0.8, "fp32", -2.5)
+    assert torch.allclose(g2, -2.5 * g1, rtol=1e-5, atol=1e-12)
+    wide = torch.zeros(12, 40)
+    wide[:, ::2] = v
+    vs = wide[:, ::2]  # column stride 2 -> host makes it row-major
+    l1 = crossclr_amd.crossclr_loss(vs, t, 0.05, 0.8, compute_mode="fp32")
+    l0 = crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="fp32")
+    assert l1.item() == l0.item()
+    padded = torch.zeros(12, 32)
+    padded[:, :20] = v
+    lp = crossclr_amd.crossclr_loss(padded[:, :20], t, 0.05, 0.8, compute_mode="fp32")  # row stride 32, unit col stride
+    assert lp.item() == l0.item()
+
+
+def test_temperature_outside_fixed_shift_range_fails_loudly():
+    v, t = orc.make_inputs("randn", 8, 16, 1)
+    with pytest.raises(nat.CrossCLRNativeError, match="too small"):
+        crossclr_amd.crossclr_loss(v, t, temperature=0.005, negative_weight=0.8, compute_mode="fp32")
+    # small but inside the range: shift is active (1/tau = 100 > 64), result must still be right
+    ref = orc.streaming_stats(v, t, 0.01, 0.8)
+    out = crossclr_amd.crossclr_loss(v, t, temperature=0.01, negative_weight=0.8, compute_mode="fp32")
+    assert abs(out.item() - float(ref["loss"])) <= 1e-4 * float(ref["loss"])
+
+
+def test_plan_geometry():
+    p = nat.make_plan(8192, 512, 1, 0, nat.MODE_BF16)
+    assert (p.bpad, p.Dpad, p.fast_path) == (8192, 512, 1)
+    assert p.operand_bytes == 2 * 8192 * 512 * 2 and p.bwd_slices == 2 and p.gbuf_bytes == 2 * 2 * 8192 * 512 * 4
+    p = nat.make_plan(100, 300, 8, 3, nat.MODE_FP32)
+    assert (p.bpad, p.Dpad, p.fast_path, p.world, p.rank) == (128, 512, 0, 8, 3)
+    p = nat.make_plan(100, 700, 1, 0, nat.MODE_BF16)
+    assert (p.Dpad, p.fast_path) == (768, 0)      # D > 512: bf16 falls back to the generic tiled kernels
+    with pytest.raises(nat.CrossCLRNativeError):
+        nat.make_plan(0, 16, 1, 0, nat.MODE_FP32)
+    with pytest.raises(nat.CrossCLRNativeError):
+        nat.make_plan(8, 16, 2, 2, nat.MODE_FP32)

@@ -1,0 +1,111 @@
+"""Drop-in surface of the nn.Module -- no kernels involved, CPU only."""
+import os
+import re
+
+import pytest
+import torch
+
+import crossclr_amd
+from crossclr_amd import _native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_constructor_signature_and_state():
+    import inspect
+    sig = inspect.signature(crossclr_amd.CrossCLR_onlyIntraModality.__init__)
+    names = list(sig.parameters)
+    assert names[:4] == ["self", "temperature", "negative_weight", "logger"]
+    assert sig.parameters["temperature"].default == 0.03
+    assert sig.parameters["negative_weight"].default == 0.8
+    assert sig.parameters["logger"].default is None
+    for extra in names[4:]:
+        assert sig.parameters[extra].kind is inspect.Parameter.KEYWORD_ONLY
+    fsig = inspect.signature(crossclr_amd.CrossCLR_onlyIntraModality.forward)
+    assert list(fsig.parameters) == ["self", "video_features", "text_features"]
+
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(temperature=0.05, negative_weight=0.7, logger="L")
+    sd = crit.state_dict()
+    assert list(sd) == ["logit_scale"] and sd["logit_scale"].item() == 1.0 and sd["logit_scale"].dim() == 0
+    assert [n for n, _ in crit.named_parameters()] == ["logit_scale"]
+    assert [(n, type(m).__name__) for n, m in crit.named_children()] == [("criterion", "CrossEntropyLoss")]
+    assert crit.criterion.reduction == "none"
+    assert (crit.temperature, crit.negative_w, crit.logger) == (0.05, 0.7, "L")
+    # a checkpoint written by the reference loads strictly
+    crit.load_state_dict({"logit_scale": torch.tensor(3.0)}, strict=True)
+    assert crit.logit_scale.item() == 3.0
+    with pytest.raises(ValueError):
+        crossclr_amd.CrossCLR_onlyIntraModality(compute_mode="fp8")
+
+
+def test_helper_methods():
+    crit = crossclr_amd.CrossCLR_onlyIntraModality()
+    m = crit._get_positive_mask(4)
+    assert m.dtype == torch.float64 and torch.equal(m, 1 - torch.eye(4, dtype=torch.float64))
+    logits = torch.tensor([[1.0, 2.0], [0.5, 0.1]])
+    mask = torch.eye(2)
+    assert torch.allclose(crit.compute_loss(logits, mask), -torch.log_softmax(logits, 1).diag())
+
+
+def test_input_validation_errors_match_reference_types():
+    crit = crossclr_amd.CrossCLR_onlyIntraModality()
+    v, t = torch.randn(8, 16), torch.randn(8, 16)
+    with pytest.raises(RuntimeError, match="must match the size"):
+        crit(v, t[:4])
+    with pytest.raises(RuntimeError, match="2 dimensions"):
+        crit(v[None], t[None])
+    with pytest.raises(RuntimeError):
+        crit(v, t[:, :8])
+    with pytest.raises(RuntimeError):
+        crit(v, t.double())
+
+
+def test_cpu_tensors_are_refused_by_the_product_library():
+    """No CPU fallback: with the HIP library loaded, CPU inputs raise instead of being computed elsewhere."""
+    nat.use_library_for_testing(None)
+    if not os.path.exists(nat.HIP_LIBRARY):
+        pytest.skip("HIP library not built")
+    crit = crossclr_amd.CrossCLR_onlyIntraModality()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        crit(torch.randn(8, 16), torch.randn(8, 16))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    nat.use_library_for_testing(None)
+    monkeypatch.setattr(nat, "HIP_LIBRARY", "/nonexistent/libcrossclr_hip.so")
+    with pytest.raises(nat.CrossCLRNativeError, match="not built"):
+        nat.library()
+    monkeypatch.undo()
+    nat.use_library_for_testing(None)
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "crossclr.h")).read()
+    declared = set(re.findall(r"\b(crossclr_[a-z_]+)\s*\(", hdr))
+    declared.discard("crossclr_plan")
+    assert declared == set(nat.EXPORTED_SYMBOLS), (declared ^ set(nat.EXPORTED_SYMBOLS))
+    if not os.path.exists(nat.HIP_LIBRARY):
+        pytest.skip("HIP library not built")
+    import ctypes
+    lib = ctypes.CDLL(nat.HIP_LIBRARY)  # loads without a GPU; no compute call is made
+    for sym in declared:
+        assert hasattr(lib, sym), f"libcrossclr_hip.so does not export {sym}"
+    lib.crossclr_backend.restype = ctypes.c_char_p
+    assert lib.crossclr_backend() == b"hip-gfx950"
+
+
+def test_product_package_never_imports_the_oracle_or_the_emulator():
+    pkg = os.path.join(ROOT, "crossmodal-contrastive-learning_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                if f.endswith(".py"):
+                    assert "libcrossclr_emu" not in src, f
+
+
+def test_reference_import_path_works():
+    import importlib
+    mod = importlib.import_module("trainer.loss")
+    assert mod.CrossCLR_onlyIntraModality is crossclr_amd.CrossCLR_onlyIntraModality

@@ -1,0 +1,14 @@
+"""`from trainer.loss import CrossCLR_onlyIntraModality` -- the import path a training loop written
+against amazon-science/crossmodal-contrastive-learning already uses (README.md:24-28 there).
+Put this repository ahead of the reference on sys.path and that line picks up the MI355X path."""
+import os
+import sys
+
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+import crossclr_amd  # noqa: E402
+
+CrossCLR_onlyIntraModality = crossclr_amd.CrossCLR_onlyIntraModality
+crossclr_loss = crossclr_amd.crossclr_loss
+__all__ = ["CrossCLR_onlyIntraModality", "crossclr_loss"]
