@@ -36,6 +36,26 @@ PEAK_F32_TFLOPS = 157.3
 GOLDEN_LOSS_B8192_SEED1234 = 10.627098744839678  # tests/golden/index.json: g7_b8192_d512_s1234
 
 
+def measured_traffic(b, d, mode, kernel_substr):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes).
+    bench.py cannot run the profiler on itself; None when no summary matches this workload."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        c = j.get("config", {})
+        if (c.get("B"), c.get("D"), c.get("mode")) != (b, d, mode):
+            continue
+        for name, e in j.get("kernels", {}).items():
+            if kernel_substr in name:
+                best = {"bytes": e["hbm_bytes_corrected"], "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def cpu_baseline(b, d):
     """The oracle's op-for-op restatement of the reference (bit-identical to it, see
     tests/golden/make_golden.py) timed on this box's host cores: bounded sample."""
@@ -149,6 +169,7 @@ def main():
             kernels[k].update(algorithmic_tflops=round(tf, 2), frac=round(tf / peak, 4))
     dom = "backward"
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
+    traffic = measured_traffic(b, d, args.mode, "fast_bwd_kernel" if st["fast_path"] else "bwd_kernel") if world == 1 else None
     step_tf = 14.0 * b * B * d / t_step / 1e12  # per-GPU algorithmic fwd+bwd flops over the whole step
     out = {
         "metric": "contrastive-pairs/sec (fwd+bwd)", "value": B * B / t_step, "unit": "pairs/s",
@@ -165,7 +186,9 @@ def main():
         "loss": loss_val,
         "roofline": {"bound": "mfma", "kernel": "crossclr_backward (dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
-                     "traffic": None,
+                     "traffic": traffic["bytes"] if traffic else None,
+                     "traffic_source": traffic["source"] if traffic else None,
+                     "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
                      "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
                      "whole_step_algorithmic_tflops_per_gpu": round(step_tf, 2),
                      "whole_step_frac": round(step_tf / peak, 4)},
