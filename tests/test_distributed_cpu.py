@@ -1,0 +1,69 @@
+"""World-size-2 (and 3) `gloo` tests of the sharded loss: every rank must return the GLOBAL loss and
+the exact gradient of the global loss w.r.t. its own rows.  The host logic under
+test is the product's (`loss._forward_impl/_backward_impl`: async all-gather of the packed operands,
+local-block launch, skip_rank launch over the gathered operand, statistics all-gather, loss
+all-reduce); on this GPU-less box the kernels behind the C-ABI are the emulated build of the same
+sources.  The checker is the oracle's sharded form."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, B, D, mode, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import crossclr_amd
+        from crossclr_amd import _native as nat
+        from emu import build_emu
+        from oracle import crossclr_oracle as orc
+        nat.use_library_for_testing(build_emu.OUT)
+        v, t = orc.make_inputs("randn", B, D, 77)
+        b = B // world
+        vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        tl = t[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.7, compute_mode=mode, process_group=dist.group.WORLD)
+        loss = crit(vl, tl)
+        loss.backward()
+        ref = orc.sharded_loss_and_grads(v, t, world, rank, 0.05, 0.7)
+        scale = ref["grad_v"].abs().max().item()
+        q.put((rank, float(loss), float(ref["loss"]),
+               (vl.grad.double() - ref["grad_v"]).abs().max().item() / scale,
+               (tl.grad.double() - ref["grad_t"]).abs().max().item() / scale))
+        dist.destroy_process_group()
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), 0, 0))
+
+
+@pytest.mark.parametrize("world,B,D,mode,ltol,gtol", [(2, 24, 20, "fp32", 1e-5, 2e-4),
+                                                       (2, 40, 48, "bf16", 5e-3, 2e-2),
+                                                       (3, 18, 16, "fp32", 1e-5, 2e-4)])
+def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
+    from emu import build_emu
+    build_emu.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, D, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    losses = []
+    for rank, loss, ref, ev, et in sorted(results):
+        assert loss != "error", ref
+        assert abs(loss - ref) <= ltol * max(1.0, abs(ref)), (rank, loss, ref)
+        assert ev <= gtol and et <= gtol, (rank, ev, et)
+        losses.append(loss)
+    assert max(losses) - min(losses) <= 1e-12, "every rank must see the same global loss"
