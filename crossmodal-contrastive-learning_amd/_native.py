@@ -12,7 +12,9 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIBRARY = os.path.join(_HERE, "libcrossclr_hip.so")
+# CROSSCLR_HIP_LIBRARY: kernel-tuning knob -- point the binding at another hipcc build of the same
+# sources (tools/build_variant.py) for A/B timing.  It must still be a "hip-gfx950" library.
+HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcrossclr_hip.so"))
 
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3

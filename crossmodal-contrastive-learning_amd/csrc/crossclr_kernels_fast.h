@@ -39,6 +39,63 @@ template <int N> __device__ __forceinline__ void wait_dma_keep() { asm volatile(
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 #endif
 
+// Tuning switches (compile-time; defaults = best measured on MI355X, see profiles/):
+//   CROSSCLR_PF     LDS fragment reads kept in flight ahead of the MFMA that consumes them
+//   CROSSCLR_SCHED  0 none, 1 iglp_opt(0), 2 iglp_opt(1), 3 explicit sched_group_barrier pipeline
+//                   {PF x reads ; (1 MFMA ; reads)*}: without it hipcc re-places the reads right in
+//                   front of their MFMA (lgkmcnt(0) before every MFMA)
+//   CROSSCLR_ABL    timing ablations of the fast backward (results are WRONG; tuning only):
+//                   bit0 skip second product, bit1 skip exp/weights, bit2 skip first product, bit3 skip DMA+barriers,
+//                   bit4 second product without its LDS reads, bit5 first product without its LDS reads
+#ifndef CROSSCLR_PF
+#define CROSSCLR_PF 4
+#endif
+#ifndef CROSSCLR_SCHED
+#define CROSSCLR_SCHED 3
+#endif
+#ifndef CROSSCLR_ABL
+#define CROSSCLR_ABL 0
+#endif
+#if defined(CROSSCLR_EMU) || CROSSCLR_SCHED == 0
+#define SCHED_PIPELINE(nmfma, reads_per_mfma, pf) do {} while (0)
+#elif CROSSCLR_SCHED == 1
+#define SCHED_PIPELINE(nmfma, reads_per_mfma, pf) __builtin_amdgcn_iglp_opt(0)
+#elif CROSSCLR_SCHED == 2
+#define SCHED_PIPELINE(nmfma, reads_per_mfma, pf) __builtin_amdgcn_iglp_opt(1)
+#else
+#define SCHED_PIPELINE(nmfma, reads_per_mfma, pf)                                                      \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, (reads_per_mfma) * (pf), 0);                       \
+        _Pragma("unroll") for (int _i = 0; _i < (nmfma); ++_i) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+            if (_i + (pf) < (nmfma)) __builtin_amdgcn_sched_group_barrier(0x100, (reads_per_mfma), 0); \
+        }                                                                                              \
+    } while (0)
+#endif
+
+#ifndef CROSSCLR_FABL
+#define CROSSCLR_FABL 0   // forward timing ablations (WRONG results): bit0 no exp epilogue, bit1 no MFMA loop, bit2 no DMA/barrier
+#endif
+#ifndef CROSSCLR_FWD_PF
+#define CROSSCLR_FWD_PF 2
+#endif
+#ifndef CROSSCLR_FWD_SCHED
+#define CROSSCLR_FWD_SCHED 1
+#endif
+// forward: per k-step 2 reads feed 2 MFMAs
+#if defined(CROSSCLR_EMU) || CROSSCLR_FWD_SCHED == 0
+#define SCHED_PIPELINE_FWD(nsteps, pf) do {} while (0)
+#else
+#define SCHED_PIPELINE_FWD(nsteps, pf)                                                       \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (pf), 0);                            \
+        _Pragma("unroll") for (int _i = 0; _i < (nsteps); ++_i) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                               \
+            if (_i + (pf) < (nsteps)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     \
+        }                                                                                    \
+    } while (0)
+#endif
+
 static inline int fast_dpad(int D) {
     if (D <= 128) return 128;
     if (D <= 256) return 256;
@@ -115,38 +172,71 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
                               lane, nullptr, nullptr);
     while (t < t_end) {
         const int tn = skip(t + 1);
-        wait_dma();
-        __syncthreads();  // tile t landed everywhere; every wave is done with the other buffer
-        if (tn < t_end)
-            issue_tile_dma<RB, 8, 64>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tn, 64).row0 * pitch,
-                                  lds + (cur ^ 1) * TILE, wave, lane, nullptr, nullptr);
+        if (!(CROSSCLR_FABL & 4)) {
+            wait_dma();
+            __syncthreads();  // tile t landed everywhere; every wave is done with the other buffer
+            if (tn < t_end)
+                issue_tile_dma<RB, 8, 64>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tn, 64).row0 * pitch,
+                                          lds + (cur ^ 1) * TILE, wave, lane, nullptr, nullptr);
+        }
         const ColTile ct = col_tile(g, t, 64);
         const unsigned char* bt = lds + cur * TILE;
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        if (CROSSCLR_FABL & 2) {
 #pragma unroll
-        for (int ks = 0; ks < DK; ++ks) {
-            const unsigned char* a = bt + off8[ks & 7] + (ks >> 3) * 256;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
-            acc[0] = mfma_32x32x16_bf16(a0, pf[ks], acc[0]);
-            acc[1] = mfma_32x32x16_bf16(a1, pf[ks], acc[1]);
+            for (int r = 0; r < 16; ++r) { acc[0][r] = bt[r] * 0.01f; acc[1][r] = bt[r + 16] * 0.01f; }
+        } else {
+            constexpr int FPF = (CROSSCLR_FWD_PF < DK / 2) ? CROSSCLR_FWD_PF : DK / 2;
+            bf16x8 r0[FPF], r1[FPF];
+#pragma unroll
+            for (int i = 0; i < FPF; ++i) {
+                const unsigned char* a = bt + off8[i & 7] + (i >> 3) * 256;
+                r0[i] = *reinterpret_cast<const bf16x8*>(a);
+                r1[i] = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
+            }
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                const bf16x8 a0 = r0[ks % FPF], a1 = r1[ks % FPF];
+                if (ks + FPF < DK) {
+                    const unsigned char* a = bt + off8[(ks + FPF) & 7] + ((ks + FPF) >> 3) * 256;
+                    r0[ks % FPF] = *reinterpret_cast<const bf16x8*>(a);
+                    r1[ks % FPF] = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
+                }
+                acc[0] = mfma_32x32x16_bf16(a0, pf[ks], acc[0]);
+                acc[1] = mfma_32x32x16_bf16(a1, pf[ks], acc[1]);
+            }
+            SCHED_PIPELINE_FWD(DK, FPF);
         }
         const bool same_mod = (ct.mod == rmod);
         const float c2 = same_mod ? g.c_intra : g.c_inter;
-        const bool diag_tile = same_mod && ct.rank == g.row_rank;
-        const bool ragged = ct.in_mod0 + 64 > g.b;
+        // scaled logits x = log2(e)/tau * s * cos - shift, in place
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q_in_mod = ct.in_mod0 + 32 * qi + frag_row(r, half);
-                float e = fast_exp2(acc[qi][r] * c2 - g.m2);
-                if (ragged && q_in_mod >= g.b) e = 0.f;
-                if (diag_tile && q_in_mod == r_in_mod) e = 0.f;
-                rowacc += e;
-            }
+            for (int r = 0; r < 16; ++r) acc[qi][r] = acc[qi][r] * c2 - g.m2;
+        // masks as patches on the (rare) tiles that need them, so the common tile pays fma + exp + add
+        // per element and no compare/select: exp2(-inf) = 0 whatever the sign of negative_weight
+        const float ninf = -__builtin_inff();
+        if (ct.in_mod0 + 64 > g.b) {  // ragged tile: columns beyond the valid batch
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ct.in_mod0 + 32 * qi + frag_row(r, half) >= g.b) acc[qi][r] = ninf;
+        }
+        if (same_mod && ct.rank == g.row_rank && ct.in_mod0 == ((r_in_mod - l31) & ~63)) {  // holds the diagonal
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ct.in_mod0 + 32 * qi + frag_row(r, half) == r_in_mod) acc[qi][r] = ninf;
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rowacc += (CROSSCLR_FABL & 1) ? acc[qi][r] : fast_exp2(acc[qi][r]);
         cur ^= 1;
         t = tn;
     }
@@ -157,7 +247,7 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
 // ---------------------------------------------------------------------------------------------
 // backward: 4 waves x 32 rows per block, ONE wave per SIMD so each wave owns the whole 512-entry
 // register file: 32 x Dpad fp32 gradient accumulators (256 at D=512) + Dpad/4 operand VGPRs.
-// Column tiles are 32 rows (32 KiB at D=512) in a 3-deep LDS-DMA ring.  grid = (2*bpad/128, slices):
+// Column tiles are 32 rows (32 KiB at D=512) in a 4-deep LDS-DMA ring.  grid = (2*bpad/128, slices):
 // slice y walks its share of the column tiles and writes its own gradient slice (summed by the
 // finish kernel) -- that is what fills all 256 CUs at B=8192 without atomics.
 // ---------------------------------------------------------------------------------------------
@@ -169,7 +259,8 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
     constexpr int RB = DK * 32;
     constexpr int QT = 32;                 // columns per tile
     constexpr int TILE = QT * RB;
-    constexpr int NST = 3;                 // ring depth
+    constexpr int NST = 4;                 // ring depth (power of two): one tile consumed, up to three in flight
+    constexpr int PF = (CROSSCLR_PF < DK / 2) ? CROSSCLR_PF : DK / 2;
     constexpr int DT = DK / 2;             // 32-wide output fragments
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128];
     unsigned char* stat = lds + NST * TILE;  // [NST][32] floats: 1/Z (or w/Z) of the tile's columns
@@ -215,11 +306,13 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
     int t = blockIdx.y * tiles_per_slice;
     int t_end = t + tiles_per_slice;
     if (t_end > ntiles) t_end = ntiles;
-    auto skip = [&](int x) {
-        if (g.skip_rank >= 0 && x < t_end && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
-        return x;
+    auto next = [&](int x) {  // first tile >= x outside the skipped rank; t_end if none
+        if (x >= t_end) return t_end;
+        if (g.skip_rank >= 0 && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
+        return x < t_end ? x : t_end;
     };
     const size_t pitch = RB;
+    constexpr int NOPS = DK / 4 + 1;  // VMEM operations one tile costs each wave (DMA pieces + statistics)
     // a block's 128 rows never straddle the modality boundary (bpad is a multiple of 128), so all four
     // waves agree on which per-column statistics array (1/Z or w/Z) a tile needs
     auto issue = [&](int tile, int stage) {
@@ -227,40 +320,54 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         issue_tile_dma<RB, 4, QT>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE, wave,
                                   lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128);
     };
-    t = skip(t);
-    int t1 = t < t_end ? skip(t + 1) : t_end;   // the tile after t
-    if (t < t_end) issue(t, 0);
-    if (t1 < t_end) issue(t1, 1);
-    int stage = 0;
-    while (t < t_end) {
-        const int t2 = t1 < t_end ? skip(t1 + 1) : t_end;
-        // tile t must have landed: at most the DMA of tile t1 (issued after it) may stay in flight
-        if (t1 < t_end) wait_dma_keep<DK / 4 + 1>(); else wait_dma();
-        __syncthreads();  // tile t visible to all; all waves finished tile t-1 -> its stage is free
-        if (t2 < t_end) issue(t2, stage == 0 ? 2 : stage - 1);
-        const ColTile ct = col_tile(g, t, QT);
-        const unsigned char* bt = lds + stage * TILE;
-        // ---- S^T = Xq . Xp^T : C[q][p], lane owns row p = l31 ----
+    auto wait_keep = [&](int tiles_in_flight) {  // block until all but the newest `tiles_in_flight` tiles landed
+        if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
+        else if (tiles_in_flight == 1) wait_dma_keep<NOPS>();
+        else wait_dma();
+    };
+    // ---- S^T = Xq . Xp^T : C[q][p], lane owns row p = l31 ----
+    auto gemm1 = [&](const unsigned char* bt, const ColTile& ct) {
         f32x16 acc;
+        if (CROSSCLR_ABL & 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bt[r] * 0.001f;
+            return acc;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        {
-            bf16x8 a_nxt = *reinterpret_cast<const bf16x8*>(bt + off8[0]);
+        bf16x8 ring[PF];
 #pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                const bf16x8 a_cur = a_nxt;
-                if (ks + 1 < DK)
-                    a_nxt = *reinterpret_cast<const bf16x8*>(bt + off8[(ks + 1) & 7] + ((ks + 1) >> 3) * 256);
-                acc = mfma_32x32x16_bf16(a_cur, pf[ks], acc);
+        for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(bt + off8[i & 7] + (i >> 3) * 256);
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            if (CROSSCLR_ABL & 32) {
+                acc = mfma_32x32x16_bf16(pf[(ks + 1) % DK], pf[ks], acc);
+                continue;
             }
+            const bf16x8 a_cur = ring[ks % PF];
+            if (ks + PF < DK)
+                ring[ks % PF] = *reinterpret_cast<const bf16x8*>(bt + off8[(ks + PF) & 7] + ((ks + PF) >> 3) * 256);
+            acc = mfma_32x32x16_bf16(a_cur, pf[ks], acc);
         }
-        // ---- W = s E (1/Z_p + 1/Z_q), packed to bf16 A fragments in place ----
+        if (!(CROSSCLR_ABL & 32)) SCHED_PIPELINE(DK, 1, PF);
+        return acc;
+    };
+    // ---- W = s E (1/Z_p + 1/Z_q), packed to bf16: the A fragments of the second product ----
+    auto weights = [&](f32x16 x, const ColTile& ct, const float* rzq, bf16x8 (&af)[2]) {
         const bool same_mod = (ct.mod == rmod);
         const float c2 = same_mod ? g.c_intra : g.c_inter;
         const float rzp = same_mod ? rzp_intra : rzp_inter;
-        const bool diag_tile = same_mod && ct.rank == g.row_rank && ct.in_mod0 == (r_in_mod - l31);
-        const float* rzq = reinterpret_cast<const float*>(stat + stage * 128);
-        bf16x8 af[2];
+        if (!(CROSSCLR_ABL & 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = x[r] * c2 - g.m2;
+            // the intra-modal self pair is excluded (its exp(0) is added analytically by the forward):
+            // only on the one tile that holds the diagonal, send that scaled logit to -inf
+            if (same_mod && ct.rank == g.row_rank && ct.in_mod0 == (r_in_mod - l31)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (frag_row(r, half) == l31) x[r] = -__builtin_inff();
+            }
+        }
 #pragma unroll
         for (int th = 0; th < 2; ++th) {
             struct { bf16_t e[8]; } pk;
@@ -270,34 +377,65 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
                 const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float e = fast_exp2(acc[8 * th + 4 * r4 + j] * c2 - g.m2);
-                    float w = e * (rzp + rq[j]);
-                    if (diag_tile && q0 + j == l31) w = 0.f;
-                    pk.e[4 * r4 + j] = f32_to_bf16_bits(w);
+                    const float v = x[8 * th + 4 * r4 + j];
+                    pk.e[4 * r4 + j] = f32_to_bf16_bits((CROSSCLR_ABL & 2) ? v : fast_exp2(v) * (rzp + rq[j]));
                 }
             }
             af[th] = __builtin_bit_cast(bf16x8, pk);
         }
-        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows) ----
+    };
+    struct Pair { s16x4 lo, hi; };
+    auto trpair = [&](const unsigned char* bt, int tp, int dt) {
+        if (CROSSCLR_ABL & 16) return __builtin_bit_cast(Pair, pf[(2 * dt + tp) % DK]);
+        Pair p;
+        p.lo = lds_read_tr16_b64(bt + comb[dt & 3][0] + (16 * tp) * RB + 256 * (dt >> 2));
+        p.hi = lds_read_tr16_b64(bt + comb[dt & 3][1] + (16 * tp + 8) * RB + 256 * (dt >> 2));
+        return p;
+    };
+
+    // ring of NST stages: tile t being consumed, t1 and t2 in flight
+    t = next(t);
+    int t1 = next(t + 1), t2 = next(t1 + 1);
+    if (t < t_end) issue(t, 0);
+    if (t1 < t_end) issue(t1, 1);
+    if (t2 < t_end) issue(t2, 2);
+    int stage = 0;
+    while (t < t_end) {
+        const int t3 = next(t2 + 1);
+        if (!(CROSSCLR_ABL & 8)) {
+            wait_keep((t1 < t_end) + (t2 < t_end));   // tile t landed (its DMA was issued before t1's and t2's)
+            __syncthreads();                            // ... everywhere; and every wave finished tile t-1
+            if (t3 < t_end) issue(t3, (stage + 3) & (NST - 1));
+        }
+        const unsigned char* bt = lds + stage * TILE;
+        const ColTile ct = col_tile(g, t, QT);
+        const f32x16 acc = gemm1(bt, ct);
+        bf16x8 af[2];
+        weights(acc, ct, reinterpret_cast<const float*>(stat + stage * 128), af);
+        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows), PF-deep fragment ring ----
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-            struct Pair { s16x4 lo, hi; };
-            Pair nxt = {lds_read_tr16_b64(bt + comb[0][0] + (16 * tp) * RB),
-                        lds_read_tr16_b64(bt + comb[0][1] + (16 * tp + 8) * RB)};
+            if (CROSSCLR_ABL & 1) {
+#ifndef CROSSCLR_EMU
+                asm volatile("" ::"v"(af[tp]));
+#endif
+                continue;
+            }
+            Pair ring[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) ring[i] = trpair(bt, tp, i);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const Pair curp = nxt;
-                if (dt + 1 < DT) {
-                    const int d1 = dt + 1;
-                    nxt.lo = lds_read_tr16_b64(bt + comb[d1 & 3][0] + (16 * tp) * RB + 256 * (d1 >> 2));
-                    nxt.hi = lds_read_tr16_b64(bt + comb[d1 & 3][1] + (16 * tp + 8) * RB + 256 * (d1 >> 2));
-                }
+                const Pair curp = ring[dt % PF];
+                if (dt + PF < DT) ring[dt % PF] = trpair(bt, tp, dt + PF);
                 acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, curp), acc2[dt]);
             }
+            if (!(CROSSCLR_ABL & 16)) SCHED_PIPELINE(DT, 2, PF);
         }
-        stage = stage == NST - 1 ? 0 : stage + 1;
+        stage = (stage + 1) & (NST - 1);
         t = t1;
         t1 = t2;
+        t2 = t3;
     }
     float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (DK * 16);
 #pragma unroll

@@ -80,6 +80,19 @@ def test_bf16_generic_kernels_match_bf16_model(monkeypatch):
     assert np.abs(gv.numpy() - arr["grad_v"]).max() <= 2e-2 * m["grad_v_absmax"]
 
 
+@pytest.mark.parametrize("w", [0.0, -0.5, 1.7])
+def test_zero_negative_and_large_negative_weight(w):
+    # the masks are applied to the SCALED logit (-inf), so the sign / zero of negative_weight must not matter
+    v, t = orc.make_inputs("randn", 40, 24, 23)
+    ref = orc.streaming_loss_and_grads(v, t, 0.1, w)
+    for mode, ltol, gtol in (("fp32", 1e-5, 2e-4), ("bf16", 3e-3, 2e-2)):
+        loss, gv, gt = run(v, t, 0.1, w, mode)
+        assert abs(loss.item() - float(ref["loss"])) <= ltol * max(1.0, abs(float(ref["loss"])))
+        scale = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+        assert (gv.double() - ref["grad_v"]).abs().max().item() <= gtol * scale
+        assert (gt.double() - ref["grad_t"]).abs().max().item() <= gtol * scale
+
+
 def test_ragged_batch_crossing_a_tile_boundary():
     # B = 70: one full 64-column tile + a ragged one in the fast path; a ragged 128 tile in the generic path
     v, t = orc.make_inputs("randn", 70, 24, 17)
