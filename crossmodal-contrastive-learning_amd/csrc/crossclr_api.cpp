@@ -89,6 +89,11 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         if (sl < 1) sl = 1;
         plan->bwd_slices = sl;
     }
+    {
+        int nb = (2 * plan->bpad + 255) / 256;
+        if (nb > 512) nb = 512;
+        plan->loss_ws_doubles = 1 + nb;
+    }
     const size_t esz = mode == CROSSCLR_MODE_FP32 ? 4 : 2;
     plan->operand_bytes = (size_t)2 * plan->bpad * plan->Dpad * esz;
     plan->gbuf_bytes = (size_t)plan->bwd_slices * 2 * plan->bpad * plan->Dpad * 4;
@@ -179,8 +184,10 @@ extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* p
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
     if (rc) return rc;
-    LAUNCH(fwd_finish_kernel, dim3(1), dim3(1024), stream, part, nslots, g, diag_cos, 1.0f / temperature,
+    const int nb = plan->loss_ws_doubles - 1;
+    LAUNCH(fwd_finish_kernel, dim3(nb), dim3(256), stream, part, nslots, g, diag_cos, 1.0f / temperature,
            negative_weight, logz, rz, wrz, loss_sum);
+    LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb);
     return launch_status("fwd_finish_kernel");
 }
 

@@ -34,9 +34,64 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// row access helpers for the memory-bound row kernels: a lane owns 4 consecutive elements of every
+// 256-element stretch of its row (16-byte accesses when the row is fp32 and 16-byte aligned),
+// and keeps them in registers so the row is read from HBM exactly once.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowCache = 4;  // stretches of 256 elements cached per lane (D <= 1024)
+
+template <typename TIN>
+__device__ __forceinline__ void row_load4(const TIN* row, int d, int D, double (&out)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (d + j < D) ? in_load(row, d + j) : 0.0;
+}
+template <>
+__device__ __forceinline__ void row_load4<float>(const float* row, int d, int D, double (&out)[4]) {
+    if (d + 3 < D && ((reinterpret_cast<uintptr_t>(row + d) & 15) == 0)) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (double)v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (d + j < D) ? (double)row[d + j] : 0.0;
+    }
+}
+template <typename TIN>
+__device__ __forceinline__ void row_store4(TIN* row, int d, int D, const double (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (d + j < D) in_store(row, d + j, v[j]);
+}
+template <>
+__device__ __forceinline__ void row_store4<float>(float* row, int d, int D, const double (&v)[4]) {
+    if (d + 3 < D && ((reinterpret_cast<uintptr_t>(row + d) & 15) == 0)) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (float)v[j];
+        *reinterpret_cast<f32x4*>(row + d) = o;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (d + j < D) row[d + j] = (float)v[j];
+    }
+}
+// packed-operand rows are padded to a multiple of 64 elements and 16-byte aligned: whole 4-element stores
+__device__ __forceinline__ void op_store4(float* row, int d, const float (&v)[4]) {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(row + d) = o;
+}
+__device__ __forceinline__ void op_store4(bf16_t* row, int d, const float (&v)[4]) {
+    u32x2 o;
+    o[0] = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+    o[1] = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<u32x2*>(row + d) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K0: row L2-normalisation of both modalities  (reference trainer/loss.py:79-80)
 // one wavefront per row index i: video row i and text row i together, so the diagonal cosine
 // vhat_i . that_i (the positive-pair logit of loss.py:83 before /tau) comes out in fp32 for free.
+// HBM-bound: reads 2*B*D inputs once, writes the packed operand once.
 // ---------------------------------------------------------------------------------------------
 template <typename TIN, typename T>
 __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const TIN* text, long ldv, long ldt,
@@ -46,26 +101,58 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
     if (i >= g.bpad) return;
     T* xv = X + (size_t)i * g.Dpad;
     T* xt = X + ((size_t)g.bpad + i) * g.Dpad;
-    if (i >= g.b) {  // padding rows: zeros, so they add exp(-shift) terms that are masked/ignored
-        for (int d = lane; d < g.Dpad; d += 64) { op_store(xv, d, 0.f); op_store(xt, d, 0.f); }
+    const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i >= g.b) {  // padding rows: zeros (their columns are masked, their rows ignored)
+        for (int d = 4 * lane; d < g.Dpad; d += 256) { op_store4(xv, d, zero4); op_store4(xt, d, zero4); }
         if (lane == 0) { inv_norm[i] = 0.f; inv_norm[g.bpad + i] = 0.f; diag_cos[i] = 0.f; }
         return;
     }
     const TIN* pv = video + (size_t)i * ldv;
     const TIN* pt = text + (size_t)i * ldt;
+    const bool cached = g.D <= 256 * kRowCache;
+    double cv[kRowCache][4], ct[kRowCache][4];
     double ssv = 0, sst = 0, dot = 0;
-    for (int d = lane; d < g.D; d += 64) {
-        double a = in_load(pv, d), c = in_load(pt, d);
-        ssv += a * a; sst += c * c; dot += a * c;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < kRowCache; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.D) {
+                row_load4(pv, d, g.D, cv[k]);
+                row_load4(pt, d, g.D, ct[k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ssv += cv[k][j] * cv[k][j]; sst += ct[k][j] * ct[k][j]; dot += cv[k][j] * ct[k][j]; }
+            }
+        }
+    } else {
+        for (int d = lane; d < g.D; d += 64) {
+            double a = in_load(pv, d), c = in_load(pt, d);
+            ssv += a * a; sst += c * c; dot += a * c;
+        }
     }
     ssv = wave_sum_f64(ssv); sst = wave_sum_f64(sst); dot = wave_sum_f64(dot);
     // x / max(||x||, eps), eps = 1e-12 (F.normalize default)
     double nv = sqrt(ssv), nt = sqrt(sst);
     double iv = 1.0 / (nv > 1e-12 ? nv : 1e-12), it = 1.0 / (nt > 1e-12 ? nt : 1e-12);
-    for (int d = lane; d < g.Dpad; d += 64) {
-        float a = 0.f, c = 0.f;
-        if (d < g.D) { a = (float)(in_load(pv, d) * iv); c = (float)(in_load(pt, d) * it); }
-        op_store(xv, d, a); op_store(xt, d, c);
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < kRowCache; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.Dpad) {
+                float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+                if (d < g.D) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[j] = (float)(cv[k][j] * iv); c[j] = (float)(ct[k][j] * it); }
+                }
+                op_store4(xv, d, a); op_store4(xt, d, c);
+            }
+        }
+        for (int d = 4 * lane + 256 * kRowCache; d < g.Dpad; d += 256) { op_store4(xv, d, zero4); op_store4(xt, d, zero4); }
+    } else {
+        for (int d = lane; d < g.Dpad; d += 64) {
+            float a = 0.f, c = 0.f;
+            if (d < g.D) { a = (float)(in_load(pv, d) * iv); c = (float)(in_load(pt, d) * it); }
+            op_store(xv, d, a); op_store(xt, d, c);
+        }
     }
     if (lane == 0) {
         inv_norm[i] = (float)iv; inv_norm[g.bpad + i] = (float)it;
@@ -179,19 +266,21 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: forward finish: slots -> logZ, 1/Z, w/Z, and the loss sum (double), one block.
+// K3: forward finish: slots -> logZ, 1/Z, w/Z, and the loss sum (double).
 //   log Z = shift + ln(sum_slots + exp(-shift));  the "+exp(-shift)" is the masked intra-modal
 //   diagonal whose logit the reference sets to 0.0 (trainer/loss.py:96-97), i.e. exp(0) = 1.
+//   Two launches: rows in parallel (each block leaves its partial loss sum in loss_ws[1 + block]),
+//   then one wave adds the block partials in index order -> deterministic, no atomics, no memset.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) fwd_finish_kernel(const float* part, int nslots, Geo g, const float* diag_cos,
-                                                          float inv_tau, float neg_w, float* logz, float* rz,
-                                                          float* wrz, double* loss_sum) {
-    CROSSCLR_SHARED double red[16];
+__global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nslots, Geo g, const float* diag_cos,
+                                                         float inv_tau, float neg_w, float* logz, float* rz,
+                                                         float* wrz, double* loss_ws) {
+    CROSSCLR_SHARED double red[4];
     const int n = 2 * g.bpad;
     const double shift = (double)g.m2 * (double)kLn2;
     const double self_term = exp(-shift);
     double acc = 0.0;
-    for (int p = threadIdx.x; p < n; p += 1024) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         const int mod = p / g.bpad, i = p - mod * g.bpad;
         double s = self_term;
         for (int k = 0; k < nslots; ++k) s += (double)part[(size_t)k * n + p];
@@ -209,11 +298,13 @@ __global__ void __launch_bounds__(1024) fwd_finish_kernel(const float* part, int
     acc = wave_sum_f64(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int k = 0; k < 16; ++k) tot += red[k];
-        loss_sum[0] = tot;
-    }
+    if (threadIdx.x == 0) loss_ws[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(64) fwd_finish_reduce_kernel(double* loss_ws, int nblocks) {
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 64) acc += loss_ws[1 + k];
+    acc = wave_sum_f64(acc);
+    if (threadIdx.x == 0) loss_ws[0] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -421,7 +512,9 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
 
 // ---------------------------------------------------------------------------------------------
 // K4: backward finish (autograd of loss.py:79-80 + analytic positive-pair term), one wave per row
-//   ghat = gbuf/(2 B tau) - partner_hat/(B tau);  gx = (ghat - xhat (xhat.ghat)) * inv_norm * grad_out
+//   ghat = sum_slices(gbuf)/(2 B tau) - partner_hat/(B tau);  gx = (ghat - xhat (xhat.ghat)) * inv_norm * grad_out
+// HBM-bound: slices + both input rows read once (kept in registers between the dot product and the
+// output pass for D <= 1024), gradient row written once, 16-byte accesses where alignment allows.
 // ---------------------------------------------------------------------------------------------
 template <typename TIN>
 __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int nslices, const TIN* video, const TIN* text, long ldv,
@@ -441,6 +534,41 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     const size_t slice = (size_t)2 * g.bpad * g.Dpad;
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
     const double pc = (double)inv_tau / (double)Bglobal;
+    const bool clamped = io >= 1e12;  // ||x|| < eps: x/eps, no projection term
+    const double go = grad_out[0];
+    if (g.D <= 256 * kRowCache) {
+        double gh[kRowCache][4], xh[kRowCache][4];
+        double dot = 0.0;
+#pragma unroll
+        for (int k = 0; k < kRowCache; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.D) {
+                f32x4 sum = *reinterpret_cast<const f32x4*>(grow + d);  // Dpad is a multiple of 64: aligned, in range
+                for (int sl = 1; sl < nslices; ++sl) sum += *reinterpret_cast<const f32x4*>(grow + sl * slice + d);
+                double o[4], x[4];
+                row_load4(oth, d, g.D, o);
+                row_load4(own, d, g.D, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gh[k][j] = (d + j < g.D) ? ((double)sum[j] * sc - o[j] * ip * pc) : 0.0;
+                    xh[k][j] = x[j] * io;
+                    dot += xh[k][j] * gh[k][j];
+                }
+            }
+        }
+        dot = wave_sum_f64(dot);
+#pragma unroll
+        for (int k = 0; k < kRowCache; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.D) {
+                double v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (clamped ? gh[k][j] : (gh[k][j] - xh[k][j] * dot)) * io * go;
+                row_store4(out, d, g.D, v);
+            }
+        }
+        return;
+    }
     auto graw = [&](int d) {  // sum of the column slices, fixed order
         float s = grow[d];
         for (int k = 1; k < nslices; ++k) s += grow[k * slice + d];
@@ -448,16 +576,14 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     };
     double dot = 0.0;
     for (int d = lane; d < g.D; d += 64) {
-        double gh = graw(d) * sc - in_load(oth, d) * ip * pc;
-        dot += in_load(own, d) * io * gh;
+        double ghd = graw(d) * sc - in_load(oth, d) * ip * pc;
+        dot += in_load(own, d) * io * ghd;
     }
     dot = wave_sum_f64(dot);
-    const bool clamped = io >= 1e12;  // ||x|| < eps: x/eps, no projection term
-    const double go = grad_out[0];
     for (int d = lane; d < g.D; d += 64) {
-        double gh = graw(d) * sc - in_load(oth, d) * ip * pc;
-        double xh = in_load(own, d) * io;
-        double v = clamped ? gh : (gh - xh * dot);
+        double ghd = graw(d) * sc - in_load(oth, d) * ip * pc;
+        double x = in_load(own, d) * io;
+        double v = clamped ? ghd : (ghd - x * dot);
         in_store(out, d, v * io * go);
     }
 }

@@ -90,7 +90,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.logz = torch.empty(2 * plan.bpad, **f32)
     ws.rz = torch.empty(2 * plan.bpad, **f32)
     ws.wrz = torch.empty(2 * plan.bpad, **f32)
-    ws.loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
+    ws.loss_sum = torch.empty(plan.loss_ws_doubles, dtype=torch.float64, device=dev)
     pp = ctypes.byref(plan)
 
     nat.check(lib.crossclr_normalize(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
@@ -119,11 +119,11 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         allstats = allstats.view(world, 2, 2 * plan.bpad)
         ws.rz_cols = allstats[:, 0].contiguous()
         ws.wrz_cols = allstats[:, 1].contiguous()
-        total = ws.loss_sum.clone()
+        total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
     else:
         ws.rz_cols, ws.wrz_cols = ws.rz, ws.wrz
-        total = ws.loss_sum
+        total = ws.loss_sum[:1]
     loss = (total / (2.0 * b * world)).reshape(())
     return loss, ws
 

@@ -63,6 +63,7 @@ typedef struct crossclr_plan {
     int fast_path;  /* 1: register-resident bf16 kernels, 0: generic tiled  */
     int fwd_slots;  /* partial-sum slots one crossclr_forward launch writes */
     int bwd_slices; /* gradient slices crossclr_backward writes (summed by _finish) */
+    int loss_ws_doubles; /* doubles in the loss_sum buffer of crossclr_forward_finish: [0] = result */
     size_t operand_bytes;   /* one packed operand X[2][bpad][Dpad]          */
     size_t gbuf_bytes;      /* fp32 d(loss)/d(xhat) accumulator [bwd_slices][2][bpad][Dpad] */
 } crossclr_plan;
@@ -93,7 +94,8 @@ int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const voi
 
 /* Reduce `nslots` partial slots: logz[2][bpad] (natural log of the full denominator),
  * rz = 1/Z_shifted, wrz = negative_weight * rz (both 0 on padding rows) and
- * loss_sum[0] = sum over valid rows of (logZv + logZt - 2 A_ii)  (double).                     */
+ * loss_sum[0] = sum over valid rows of (logZv + logZt - 2 A_ii)  (double); loss_sum must hold
+ * plan->loss_ws_doubles doubles ([1..] are per-block partials, added in index order).          */
 int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int nslots,
                             const float* diag_cos, float temperature, float negative_weight,
                             float* logz, float* rz, float* wrz, double* loss_sum, void* stream);

@@ -191,10 +191,10 @@ def _shard_via_cabi(v, t, world, mode):
         nat.check(lib.crossclr_forward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(part), 0, stream))
         nat.check(lib.crossclr_forward(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(part), pl.fwd_slots, stream))
         logz = torch.empty(2 * pl.bpad, **f32)
-        ls = torch.empty(1, dtype=torch.float64, device=dev)
+        ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device=dev)
         nat.check(lib.crossclr_forward_finish(pp, p(part), 2 * pl.fwd_slots, p(diag[r]), 0.03, 0.8, p(logz), p(rz[r]),
                                               p(wrz[r]), p(ls), stream))
-        total += ls
+        total += ls[:1]
     loss = total / (2.0 * B)
     gv = torch.empty_like(v)
     gt = torch.empty_like(t)
