@@ -23,7 +23,7 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
     dev = video.device
     p = L._ptr
     stream = L._stream_for(video)
-    part = torch.empty(plan.fwd_slots * 2 * plan.bpad, dtype=torch.float32, device=dev)
+    part = torch.empty(plan.fwd_ws_floats, dtype=torch.float32, device=dev)
     gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
     go = torch.ones(1, dtype=torch.float64, device=dev)
     gv, gt = torch.empty_like(video), torch.empty_like(text)

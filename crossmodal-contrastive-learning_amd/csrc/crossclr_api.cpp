@@ -52,6 +52,22 @@ extern "C" const char* crossclr_backend(void) {
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// forward workspace ("part") layout, in floats:  [2*fwd_slots slots][2*bpad] | colpart [2*bpad/256][2*bpad] | flag
+static size_t ws_colpart_off(const crossclr_plan* p) { return (size_t)2 * p->fwd_slots * 2 * p->bpad; }
+static size_t ws_flag_off(const crossclr_plan* p) { return ws_colpart_off(p) + (size_t)(2 * p->bpad / 256 + 1) * 2 * p->bpad; }
+
+static int device_zero_header(int* where, void* stream) {  // kind 0 = dense slots (generic kernels)
+#ifdef CROSSCLR_EMU
+    (void)stream;
+    memset(where, 0, 16);
+    return CROSSCLR_OK;
+#else
+    hipError_t e = hipMemsetAsync(where, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CROSSCLR_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return CROSSCLR_OK;
+#endif
+}
+
 extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, crossclr_plan* plan) {
     if (!plan) return fail(CROSSCLR_E_ARG, "plan is NULL");
     if (b < 1 || D < 1) return fail(CROSSCLR_E_ARG, "need b >= 1 and D >= 1 (got b=%d D=%d)", b, D);
@@ -71,13 +87,34 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
 #endif
     if (!plan->fast_path && dpad > 256) dpad = round_up(D, 256);  // generic backward slices D by 256
     plan->Dpad = dpad;
-    // forward column splits: enough (row block x split) work items to fill 256 CUs a few times over
+    // forward partial-sum slots.  generic kernels: (row block x column split) grid, enough work items to
+    // fill 256 CUs a few times over.  fast path: persistent blocks over a flat work list (see FwdWork);
+    // a row block's slots = the thread blocks whose range touches it.
     const int row_blocks = 2 * plan->bpad / 128;
     const int col_tiles = 2 * plan->bpad / 128;  // per column rank
     int nsplit = (1024 + row_blocks - 1) / row_blocks;
     if (nsplit > col_tiles) nsplit = col_tiles;
     if (nsplit < 1) nsplit = 1;
+    plan->fwd_blocks = 0;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->fast_path) {
+        plan->fwd_blocks = 256;  // one persistent block per MI355X CU (LDS-limited to one block per CU)
+        if (const char* e = getenv("CROSSCLR_FWD_BLOCKS")) {  // tuning knob
+            int v = atoi(e);
+            if (v >= 1 && v <= 4096) plan->fwd_blocks = v;
+        }
+        int slots = fwd_max_slots(fast_forward_work(plan, 1, -1, true));
+        int s2 = fwd_max_slots(fast_forward_work(plan, 1, -1, false));
+        if (s2 > slots) slots = s2;
+        if (world > 1) {
+            int s3 = fwd_max_slots(fast_forward_work(plan, world, 0, false));
+            if (s3 > slots) slots = s3;
+        }
+        nsplit = slots;
+    }
+#endif
     plan->fwd_slots = nsplit;
+    plan->fwd_ws_floats = 0;  // set below
     // backward column slices (fast path only): one block per CU needs >= 256 blocks of 128 rows
     plan->bwd_slices = 1;
     if (plan->fast_path) {
@@ -94,6 +131,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         if (nb > 512) nb = 512;
         plan->loss_ws_doubles = 1 + nb;
     }
+    plan->fwd_ws_floats = ws_flag_off(plan) + 16;
     const size_t esz = mode == CROSSCLR_MODE_FP32 ? 4 : 2;
     plan->operand_bytes = (size_t)2 * plan->bpad * plan->Dpad * esz;
     plan->gbuf_bytes = (size_t)plan->bwd_slices * 2 * plan->bpad * plan->Dpad * 4;
@@ -161,10 +199,21 @@ extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows
     Geo g;
     int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
     if (rc) return rc;
+    if (slot0 != 0 && slot0 != plan->fwd_slots) return fail(CROSSCLR_E_ARG, "slot0 must be 0 or plan->fwd_slots");
     float* out = part + (size_t)slot0 * 2 * plan->bpad;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + (slot0 == 0 ? 0 : 4);
 #ifndef CROSSCLR_NO_FAST
-    if (plan->fast_path) return fast_forward(plan, g, xhat_rows, xhat_cols, out, stream);
+    if (plan->fast_path) {
+        // rows and columns are the same packed operand (the single-GPU case and the local block of a
+        // sharded run): evaluate only the upper triangle of the symmetric matrix
+        const bool symmetric = xhat_rows == xhat_cols && col_ranks == 1 && col_rank0 == plan->rank && skip_rank < 0 &&
+                               !getenv("CROSSCLR_DISABLE_SYMMETRIC");
+        rc = fast_forward(plan, g, xhat_rows, xhat_cols, out, part + ws_colpart_off(plan), header, symmetric, stream);
+        return rc ? fail(rc, "fast_forward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_fwd_kernel");
+    }
 #endif
+    rc = device_zero_header(header, stream);
+    if (rc) return rc;
     const int ntiles = col_ranks * 2 * plan->bpad / 128;
     const int nsplit = plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
@@ -179,14 +228,17 @@ extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows
 extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int nslots,
                                        const float* diag_cos, float temperature, float negative_weight,
                                        float* logz, float* rz, float* wrz, double* loss_sum, void* stream) {
-    if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum || nslots < 1)
-        return fail(CROSSCLR_E_ARG, "NULL argument / nslots < 1");
+    if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum ||
+        (nslots != plan->fwd_slots && nslots != 2 * plan->fwd_slots))
+        return fail(CROSSCLR_E_ARG, "NULL argument / nslots must be fwd_slots (one launch) or 2*fwd_slots (two)");
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
     if (rc) return rc;
     const int nb = plan->loss_ws_doubles - 1;
-    LAUNCH(fwd_finish_kernel, dim3(nb), dim3(256), stream, part, nslots, g, diag_cos, 1.0f / temperature,
-           negative_weight, logz, rz, wrz, loss_sum);
+    const int nlaunch = nslots / plan->fwd_slots;
+    LAUNCH(fwd_finish_kernel, dim3(nb), dim3(256), stream, part, nlaunch, plan->fwd_slots, g, diag_cos, 1.0f / temperature,
+           negative_weight, logz, rz, wrz, loss_sum, part + ws_colpart_off(plan),
+           reinterpret_cast<const int*>(part + ws_flag_off(plan)));
     LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb);
     return launch_status("fwd_finish_kernel");
 }
@@ -260,7 +312,7 @@ extern "C" int crossclr_backward_finish(const crossclr_plan* plan, const float* 
 }
 
 extern "C" int crossclr_selftest(int which, const void* in, void* out, void* stream) {
-    if (which < 0 || which > 2 || !in || !out) return fail(CROSSCLR_E_ARG, "bad selftest arguments");
+    if (which < 0 || which > 3 || !in || !out) return fail(CROSSCLR_E_ARG, "bad selftest arguments");
     LAUNCH(selftest_kernel, dim3(1), dim3(64), stream, which, in, out);
     return launch_status("selftest_kernel");
 }

@@ -65,6 +65,18 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(const void* p) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float wave_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ double wave_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+// value of lane (l ^ MASK) for MASK in {1, 2, 7, 15, 16}: DPP quad_perm / row_half_mirror / row_mirror
+// (one VALU slot, no LDS) and a ds_swizzle for the cross-row 16
+template <int MASK> __device__ __forceinline__ float lane_xor(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    int r;
+    if (MASK == 1) r = __builtin_amdgcn_mov_dpp(b, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if (MASK == 2) r = __builtin_amdgcn_mov_dpp(b, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if (MASK == 7) r = __builtin_amdgcn_mov_dpp(b, 0x141, 0xF, 0xF, true);  // row_half_mirror: i <-> 7-i
+    else if (MASK == 15) r = __builtin_amdgcn_mov_dpp(b, 0x140, 0xF, 0xF, true); // row_mirror: i <-> 15-i
+    else r = __builtin_amdgcn_ds_swizzle(b, 0x401F);                             // bit mode: xor 16 within 32 lanes
+    return __builtin_bit_cast(float, r);
+}
 #define CROSSCLR_SHARED __shared__
 #endif
 

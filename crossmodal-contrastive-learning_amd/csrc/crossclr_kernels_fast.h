@@ -74,7 +74,7 @@ __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirs
 #endif
 
 #ifndef CROSSCLR_FABL
-#define CROSSCLR_FABL 0   // forward timing ablations (WRONG results): bit0 no exp epilogue, bit1 no MFMA loop, bit2 no DMA/barrier
+#define CROSSCLR_FABL 0   // forward timing ablations (WRONG results): bit0 no exp epilogue, bit1 no MFMA loop, bit2 no DMA/barrier, bit3 no column-sum butterfly
 #endif
 #ifndef CROSSCLR_FWD_PF
 #define CROSSCLR_FWD_PF 2
@@ -128,120 +128,277 @@ __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, un
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward denominators: 8 waves x 32 rows per block, grid = (2*bpad/256, nsplit)
+// Sum e[0..15] over the 32 lanes of each wave half by recursive halving: after step k a lane keeps
+// only the half of its values selected by one bit of its lane id and adds the partner's copy of that
+// half (16 adds + 30 selects instead of 80 adds for 16 independent butterflies; fp32, fixed order).
+// Every lane ends up with the total of element  8*b3 + 4*b2 + 2*b1 + b0  (b_k = bit k of l31).
+// Partners: l^15, l^7 (DPP row_mirror / row_half_mirror: they also flip the lower bits, which have
+// not been used as selectors yet at that point), l^2, l^1 (DPP quad_perm), l^16 (ds_swizzle).
 // ---------------------------------------------------------------------------------------------
-template <int DK>
-__global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
-                                                          int tiles_per_split, float* part) {
+__device__ __forceinline__ float halving_sum16(const float (&e)[16], int l31) {
+    float k8[8], k4[4], k2[2];
+    {
+        const bool up = (l31 >> 3) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k8[i] = (up ? e[8 + i] : e[i]) + lane_xor<15>(up ? e[i] : e[8 + i]);
+    }
+    {
+        const bool up = (l31 >> 2) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k4[i] = (up ? k8[4 + i] : k8[i]) + lane_xor<7>(up ? k8[i] : k8[4 + i]);
+    }
+    {
+        const bool up = (l31 >> 1) & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) k2[i] = (up ? k4[2 + i] : k4[i]) + lane_xor<2>(up ? k4[i] : k4[2 + i]);
+    }
+    const bool up = l31 & 1;
+    const float k1 = (up ? k2[1] : k2[0]) + lane_xor<1>(up ? k2[0] : k2[1]);
+    return k1 + lane_xor<16>(k1);
+}
+__device__ __forceinline__ int halving_elem16(int l31) {
+    return 8 * ((l31 >> 3) & 1) + 4 * ((l31 >> 2) & 1) + 2 * ((l31 >> 1) & 1) + (l31 & 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work list of the persistent forward.  Row block I = 256 rows of the stacked operand; column tile
+// t = 32 columns.  kind 1 (symmetric: rows and columns are the same operand): row block I owns tiles
+// 8I .. NT-1;  kind 2 (rectangular): every row block owns all NC column tiles that are not in the
+// skipped rank.  The (I, t) pairs, row-block major, form a flat list of `total` items that is cut
+// into `nblk` equal contiguous ranges of `per` items -- one persistent thread block each.
+// A row block's partial row sums land in slot (block - first block touching that row block).
+// ---------------------------------------------------------------------------------------------
+struct FwdWork {
+    int kind;   // 1 symmetric, 2 rectangular (0 in the workspace header = dense slots of the generic kernel)
+    int NB;     // row blocks
+    int NT;     // symmetric: column tiles of the operand; rectangular: usable column tiles
+    int per;    // items per thread block
+    int nblk;   // thread blocks
+    int total;
+};
+__host__ __device__ __forceinline__ int fwd_prefix(const FwdWork& w, int rb) {  // items before row block rb
+    return w.kind == 1 ? rb * w.NT - 4 * rb * (rb - 1) : rb * w.NT;
+}
+__host__ __device__ __forceinline__ int fwd_first_block(const FwdWork& w, int rb) { return fwd_prefix(w, rb) / w.per; }
+__host__ __device__ __forceinline__ int fwd_last_block(const FwdWork& w, int rb) { return (fwd_prefix(w, rb + 1) - 1) / w.per; }
+static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, int max_blocks) {
+    FwdWork w;
+    w.kind = kind;
+    w.NB = 2 * bpad / 256;
+    w.NT = kind == 1 ? 2 * bpad / 32 : usable_col_tiles;
+    w.total = fwd_prefix(w, w.NB);
+    int nb = w.total / 8;                     // at least ~8 tiles per block
+    if (nb > max_blocks) nb = max_blocks;
+    if (nb < 1) nb = 1;
+    w.per = (w.total + nb - 1) / nb;
+    w.nblk = (w.total + w.per - 1) / w.per;
+    return w;
+}
+static inline int fwd_max_slots(const FwdWork& w) {
+    int m = 1;
+    for (int rb = 0; rb < w.NB; ++rb) {
+        const int n = fwd_last_block(w, rb) - fwd_first_block(w, rb) + 1;
+        if (n > m) m = n;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward denominators, persistent: 8 waves x 32 rows per block (two waves per SIMD), 32-column tiles
+// in a 4-deep LDS-DMA ring that keeps running across row-block boundaries, counted s_waitcnt vmcnt(N),
+// one barrier per tile.  A block re-reads its row fragments only when its range of the work list
+// crosses into the next row block.
+//  SYM: the stacked 2B x 2B matrix of exponentiated logits is symmetric, so only tiles at or right of
+//    a row block's own 256 columns are evaluated; a tile strictly right of the diagonal block also
+//    yields the COLUMN sums of its 32 columns over the block's 256 rows -- the row sums of the
+//    mirrored tile that is never computed.  Column sums: per-wave halving_sum16 in registers, then
+//    the 8 waves' values meet in a 1 KiB LDS slot and are written by 32 threads one barrier later
+//    (the ring barrier of the next tile) to colpart[row block][column]: fixed order, no atomics,
+//    nothing to zero.
+// ---------------------------------------------------------------------------------------------
+template <int DK, bool SYM>
+__global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
+                                                          float* part, float* colpart, int* header) {
     constexpr int RB = DK * 32;            // bytes per operand row
-    constexpr int TILE = 64 * RB;
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * TILE];
+    constexpr int QT = 32;
+    constexpr int TILE = QT * RB;
+    constexpr int NST = 4;
+    constexpr int NOPS = DK / 8;           // DMA wave-instructions per tile per wave (8 waves)
+    constexpr int CS = 8 * QT * 4;         // one column-sum slot: [8 waves][32 columns] floats
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + (SYM ? 2 * CS : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int row0w = blockIdx.x * 256 + 32 * wave;
-    const int rmod = row0w / g.bpad;
-    const int r_in_mod = row0w - rmod * g.bpad + l31;   // this lane's row inside its modality
-
-    bf16x8 pf[DK];
-    {
-        const bf16_t* src = rows + (size_t)(row0w + l31) * (DK * 16) + 8 * half;
-#pragma unroll
-        for (int ks = 0; ks < DK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
+    if (blockIdx.x == 0 && tid == 0) {  // tell crossclr_forward_finish how this launch laid out its slots
+        header[0] = wk.kind; header[1] = wk.NB; header[2] = wk.NT; header[3] = wk.per;
     }
-    // byte offset of logical chunk (2j + half) + 16*hi of this lane's tile rows (l31 and l31 + 32)
-    int off8[8];
+    const int per_rank = 2 * g.bpad / QT;
+    const int skip_seg = (!SYM && g.skip_rank >= 0) ? g.skip_rank - g.col_rank0 : -1;
+    // flat work items [w, w_end): item -> (row block, column tile)
+    int w = blockIdx.x * wk.per;
+    int w_end = w + wk.per;
+    if (w_end > wk.total) w_end = wk.total;
+    struct Cursor { int rb, j; };  // j = index inside the row block's tile list
+    auto tile_of = [&](const Cursor& c) {
+        if (SYM) return 8 * c.rb + c.j;
+        return (skip_seg >= 0 && c.j >= skip_seg * per_rank) ? c.j + per_rank : c.j;
+    };
+    auto advance = [&](Cursor& c) {
+        const int n = SYM ? wk.NT - 8 * c.rb : wk.NT;
+        if (++c.j == n) { c.j = 0; ++c.rb; }
+    };
+    Cursor cur;
+    {
+        int rb = 0;
+        while (fwd_prefix(wk, rb + 1) <= w) ++rb;
+        cur.rb = rb;
+        cur.j = w - fwd_prefix(wk, rb);
+    }
+    const size_t pitch = RB;
+    auto issue = [&](const Cursor& c, int stage) {
+        issue_tile_dma<RB, 8, QT>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tile_of(c), QT).row0 * pitch,
+                                  lds + stage * TILE, wave, lane, nullptr, nullptr);
+    };
+    auto wait_keep = [&](int tiles_in_flight) {
+        if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
+        else if (tiles_in_flight == 1) wait_dma_keep<NOPS>();
+        else wait_dma();
+    };
+    int off8[8];  // byte offset of logical chunk (2j + half) + 16*hi of this lane's tile row
 #pragma unroll
     for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
 
-    const int ntiles = g.col_ranks * 2 * g.bpad / 64;
-    const int per_rank = 2 * g.bpad / 64;
-    int t = blockIdx.y * tiles_per_split;
-    int t_end = t + tiles_per_split;
-    if (t_end > ntiles) t_end = ntiles;
-    auto skip = [&](int x) {  // first tile >= x that is not in the skipped rank
-        if (g.skip_rank >= 0 && x < t_end && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
-        return x;
-    };
-    t = skip(t);
-    float rowacc = 0.f;
-    int cur = 0;
-    const size_t pitch = RB;
-    if (t < t_end)
-        issue_tile_dma<RB, 8, 64>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, t, 64).row0 * pitch, lds, wave,
-                              lane, nullptr, nullptr);
-    while (t < t_end) {
-        const int tn = skip(t + 1);
-        if (!(CROSSCLR_FABL & 4)) {
-            wait_dma();
-            __syncthreads();  // tile t landed everywhere; every wave is done with the other buffer
-            if (tn < t_end)
-                issue_tile_dma<RB, 8, 64>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tn, 64).row0 * pitch,
-                                          lds + (cur ^ 1) * TILE, wave, lane, nullptr, nullptr);
-        }
-        const ColTile ct = col_tile(g, t, 64);
-        const unsigned char* bt = lds + cur * TILE;
-        f32x16 acc[2];
+    // symmetric mode: column sums of the previous tile wait in cs[pbuf] for the next barrier
+    float* cs = reinterpret_cast<float*>(lds + NST * TILE);
+    bool pending = false;
+    int ptile = 0, pbuf = 0, prb = 0;
+    auto flush = [&]() {
+        if (tid < QT) {
+            const float* c = cs + pbuf * (8 * QT);
+            float sum = c[tid];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            for (int k = 1; k < 8; ++k) sum += c[k * QT + tid];
+            colpart[(size_t)prb * 2 * g.bpad + QT * ptile + tid] = sum;
+        }
+    };
+    // ring: item w being consumed, w+1 and w+2 in flight
+    Cursor c1 = cur, c2, c3;
+    advance(c1);
+    c2 = c1; advance(c2);
+    c3 = c2; advance(c3);
+    if (w < w_end) issue(cur, 0);
+    if (w + 1 < w_end) issue(c1, 1);
+    if (w + 2 < w_end) issue(c2, 2);
+    int stage = 0;
+    int my_rb = -1, row0w = 0, rmod = 0, r_in_mod = 0;
+    float rowacc = 0.f;
+    bf16x8 pf[DK];
+    auto store_rows = [&]() {
+        float v = rowacc + wave_xor_f32(rowacc, 32);
+        if (half == 0) part[(size_t)(blockIdx.x - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + l31] = v;
+    };
+    while (w < w_end) {
+        if (cur.rb != my_rb) {  // (re)load this wave's 32 rows as MFMA B fragments
+            if (my_rb >= 0) store_rows();
+            my_rb = cur.rb;
+            rowacc = 0.f;
+            row0w = my_rb * 256 + 32 * wave;
+            rmod = row0w / g.bpad;
+            r_in_mod = row0w - rmod * g.bpad + l31;
+            if (CROSSCLR_FABL & 16) {
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) {
+                    u32x4 v = {(unsigned)lane, (unsigned)ks, (unsigned)wave, 7u};
+                    pf[ks] = __builtin_bit_cast(bf16x8, v);
+                }
+            } else {
+                const bf16_t* src = rows + (size_t)(row0w + l31) * (DK * 16) + 8 * half;
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
+            }
+        }
+        const int t = tile_of(cur);
+        if (!(CROSSCLR_FABL & 4)) {
+            wait_keep((w + 1 < w_end) + (w + 2 < w_end));
+            __syncthreads();  // item w landed everywhere; every wave is done with item w-1's stage
+            if (w + 3 < w_end) issue(c3, (stage + 3) & (NST - 1));
+        }
+        if (SYM && pending) { flush(); pending = false; }
+        const ColTile ct = col_tile(g, t, QT);
+        const unsigned char* bt = lds + stage * TILE;
+        f32x16 acc, acc_odd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_odd[r] = 0.f; }
         if (CROSSCLR_FABL & 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[0][r] = bt[r] * 0.01f; acc[1][r] = bt[r + 16] * 0.01f; }
+            for (int r = 0; r < 16; ++r) acc[r] = bt[r] * 0.01f;
         } else {
+            // two accumulator chains (even / odd k-steps) so consecutive MFMAs are independent
             constexpr int FPF = (CROSSCLR_FWD_PF < DK / 2) ? CROSSCLR_FWD_PF : DK / 2;
-            bf16x8 r0[FPF], r1[FPF];
+            bf16x8 ring[FPF];
 #pragma unroll
-            for (int i = 0; i < FPF; ++i) {
-                const unsigned char* a = bt + off8[i & 7] + (i >> 3) * 256;
-                r0[i] = *reinterpret_cast<const bf16x8*>(a);
-                r1[i] = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
-            }
+            for (int i = 0; i < FPF; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(bt + off8[i & 7] + (i >> 3) * 256);
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
-                const bf16x8 a0 = r0[ks % FPF], a1 = r1[ks % FPF];
-                if (ks + FPF < DK) {
-                    const unsigned char* a = bt + off8[(ks + FPF) & 7] + ((ks + FPF) >> 3) * 256;
-                    r0[ks % FPF] = *reinterpret_cast<const bf16x8*>(a);
-                    r1[ks % FPF] = *reinterpret_cast<const bf16x8*>(a + 32 * RB);
-                }
-                acc[0] = mfma_32x32x16_bf16(a0, pf[ks], acc[0]);
-                acc[1] = mfma_32x32x16_bf16(a1, pf[ks], acc[1]);
+                const bf16x8 a = ring[ks % FPF];
+                if (ks + FPF < DK)
+                    ring[ks % FPF] = *reinterpret_cast<const bf16x8*>(bt + off8[(ks + FPF) & 7] + ((ks + FPF) >> 3) * 256);
+                if (ks & 1) acc_odd = mfma_32x32x16_bf16(a, pf[ks], acc_odd);
+                else acc = mfma_32x32x16_bf16(a, pf[ks], acc);
             }
-            SCHED_PIPELINE_FWD(DK, FPF);
+            SCHED_PIPELINE(DK, 1, FPF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc_odd[r];
         }
         const bool same_mod = (ct.mod == rmod);
-        const float c2 = same_mod ? g.c_intra : g.c_inter;
+        const float c2s = same_mod ? g.c_intra : g.c_inter;
         // scaled logits x = log2(e)/tau * s * cos - shift, in place
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[qi][r] = acc[qi][r] * c2 - g.m2;
+        for (int r = 0; r < 16; ++r) acc[r] = acc[r] * c2s - g.m2;
         // masks as patches on the (rare) tiles that need them, so the common tile pays fma + exp + add
         // per element and no compare/select: exp2(-inf) = 0 whatever the sign of negative_weight
         const float ninf = -__builtin_inff();
-        if (ct.in_mod0 + 64 > g.b) {  // ragged tile: columns beyond the valid batch
+        if (ct.in_mod0 + QT > g.b) {  // ragged tile: columns beyond the valid batch
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ct.in_mod0 + 32 * qi + frag_row(r, half) >= g.b) acc[qi][r] = ninf;
+            for (int r = 0; r < 16; ++r)
+                if (ct.in_mod0 + frag_row(r, half) >= g.b) acc[r] = ninf;
         }
-        if (same_mod && ct.rank == g.row_rank && ct.in_mod0 == ((r_in_mod - l31) & ~63)) {  // holds the diagonal
+        if (same_mod && ct.rank == g.row_rank && ct.in_mod0 == (r_in_mod - l31)) {  // holds the diagonal
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ct.in_mod0 + 32 * qi + frag_row(r, half) == r_in_mod) acc[qi][r] = ninf;
+            for (int r = 0; r < 16; ++r)
+                if (frag_row(r, half) == l31) acc[r] = ninf;
         }
+        const bool upper = SYM && t >= 8 * (my_rb + 1);  // strictly right of the diagonal block
+        if (upper && (r_in_mod - l31) + 32 > g.b) {      // padding ROWS must not reach the column sums
+            if (r_in_mod >= g.b) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
+                for (int r = 0; r < 16; ++r) acc[r] = ninf;
+            }
+        }
+        float e[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rowacc += (CROSSCLR_FABL & 1) ? acc[qi][r] : fast_exp2(acc[qi][r]);
-        cur ^= 1;
-        t = tn;
+        for (int r = 0; r < 16; ++r) {
+            e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
+            rowacc += e[r];
+        }
+        if (upper) {
+            const float colsum = (CROSSCLR_FABL & 8) ? e[l31 & 15] : halving_sum16(e, l31);
+            pbuf ^= 1;
+            if (l31 < 16) cs[pbuf * (8 * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
+            pending = true;
+            ptile = t;
+            prb = my_rb;
+        }
+        stage = (stage + 1) & (NST - 1);
+        ++w;
+        cur = c1; c1 = c2; c2 = c3;
+        advance(c3);
     }
-    rowacc += wave_xor_f32(rowacc, 32);
-    if (half == 0) part[(size_t)blockIdx.y * 2 * g.bpad + row0w + l31] = rowacc;
+    if (SYM) {
+        __syncthreads();
+        if (pending) flush();
+    }
+    if (my_rb >= 0) store_rows();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,19 +614,34 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
     hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 #endif
 
+static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, int skip_rank, bool symmetric) {
+    const int usable = (col_ranks - (skip_rank >= 0 ? 1 : 0)) * (2 * p->bpad / 32);
+    return fwd_make_work(symmetric ? 1 : 2, p->bpad, usable, p->fwd_blocks);
+}
+
 static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
-                               void* stream) {
-    const int ntiles = g.col_ranks * 2 * p->bpad / 64;
-    const int nsplit = p->fwd_slots;
-    const int tps = (ntiles + nsplit - 1) / nsplit;
-    dim3 grid(2 * p->bpad / 256, nsplit), block(512);
+                               float* colpart, int* header, bool symmetric, void* stream) {
+    const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
+    const FwdWork wk = fast_forward_work(p, g.col_ranks, skipping ? g.skip_rank : -1, symmetric);
+    if (wk.total <= 0) return CROSSCLR_OK;
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
+    dim3 block(512), grid(wk.nblk);
+    if (symmetric) {
+        switch (p->Dpad) {
+            case 128: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<8, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+            case 256: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<16, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+            case 384: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<24, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+            case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+            default: return CROSSCLR_E_ARG;
+        }
+        return CROSSCLR_OK;
+    }
     switch (p->Dpad) {
-        case 128: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<8>), grid, block, stream, r, c, g, tps, part); break;
-        case 256: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<16>), grid, block, stream, r, c, g, tps, part); break;
-        case 384: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<24>), grid, block, stream, r, c, g, tps, part); break;
-        case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32>), grid, block, stream, r, c, g, tps, part); break;
+        case 128: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<8, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+        case 256: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<16, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+        case 384: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<24, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+        case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
         default: return CROSSCLR_E_ARG;
     }
     return CROSSCLR_OK;

@@ -272,9 +272,15 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
 //   Two launches: rows in parallel (each block leaves its partial loss sum in loss_ws[1 + block]),
 //   then one wave adds the block partials in index order -> deterministic, no atomics, no memset.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nslots, Geo g, const float* diag_cos,
-                                                         float inv_tau, float neg_w, float* logz, float* rz,
-                                                         float* wrz, double* loss_ws) {
+// header[4*L .. 4*L+3] of launch L (written by the forward launch itself): {kind, NB, NT, per}.
+//   kind 0: dense -- all `slots_per_launch` slots of the launch are valid for every row
+//   kind 1/2: persistent fast forward (symmetric / rectangular): row block I = p >> 8 owns slots
+//             0 .. last_block(I) - first_block(I); kind 1 additionally has column sums colpart[I' < I][p]
+__device__ __forceinline__ int fin_prefix(int kind, int NT, int rb) { return kind == 1 ? rb * NT - 4 * rb * (rb - 1) : rb * NT; }
+__global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nlaunch, int slots_per_launch, Geo g,
+                                                         const float* diag_cos, float inv_tau, float neg_w, float* logz,
+                                                         float* rz, float* wrz, double* loss_ws, const float* colpart,
+                                                         const int* header) {
     CROSSCLR_SHARED double red[4];
     const int n = 2 * g.bpad;
     const double shift = (double)g.m2 * (double)kLn2;
@@ -283,7 +289,18 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         const int mod = p / g.bpad, i = p - mod * g.bpad;
         double s = self_term;
-        for (int k = 0; k < nslots; ++k) s += (double)part[(size_t)k * n + p];
+        for (int L = 0; L < nlaunch; ++L) {
+            const int kind = header[4 * L], NT = header[4 * L + 2], per = header[4 * L + 3];
+            const float* base = part + (size_t)L * slots_per_launch * n;
+            int count = slots_per_launch;
+            if (kind != 0) {
+                const int rb = p >> 8;
+                count = (fin_prefix(kind, NT, rb + 1) - 1) / per - fin_prefix(kind, NT, rb) / per + 1;
+                if (kind == 1)
+                    for (int k = 0; k < rb; ++k) s += (double)colpart[(size_t)k * n + p];
+            }
+            for (int k = 0; k < count; ++k) s += (double)base[(size_t)k * n + p];
+        }
         const bool valid = i < g.b;
         const double lz = shift + log(s);
         logz[p] = valid ? (float)lz : 0.f;
@@ -597,6 +614,7 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
 // which = 2: transpose read: LDS holds bf16 M[r][c] = in[r*64+c] for a [16][64] matrix; every lane
 //            issues lds_read_tr16_b64 at row 4*(lane>>5)... exactly like bwd_gemm2 (ks=0, dt=0, DC=64)
 //            out s16[64][8] = the B fragment each lane assembled.
+// which = 3: the cross-lane exchanges of the symmetric forward: out f32[5][64] = lane_xor<1,2,7,15,16>(in[lane])
 __global__ void __launch_bounds__(64) selftest_kernel(int which, const void* in, void* out) {
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[64 * 64 * 2];
     const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
@@ -622,6 +640,15 @@ __global__ void __launch_bounds__(64) selftest_kernel(int which, const void* in,
         c = mfma_32x32x2_f32(A[l31 * 2 + half], B[half * 32 + l31], c);
         float* C = reinterpret_cast<float*>(out);
         for (int r = 0; r < 16; ++r) C[frag_row(r, half) * 32 + l31] = c[r];
+    } else if (which == 3) {
+        // out f32[5][64]: lane_xor<1,2,7,15,16> of in[lane]
+        const float v = reinterpret_cast<const float*>(in)[lane];
+        float* O = reinterpret_cast<float*>(out);
+        O[0 * 64 + lane] = lane_xor<1>(v);
+        O[1 * 64 + lane] = lane_xor<2>(v);
+        O[2 * 64 + lane] = lane_xor<7>(v);
+        O[3 * 64 + lane] = lane_xor<15>(v);
+        O[4 * 64 + lane] = lane_xor<16>(v);
     } else {
         const bf16_t* M = reinterpret_cast<const bf16_t*>(in);
         for (int e = lane; e < 64 * 64; e += 64) {

@@ -86,7 +86,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.inv_norm = torch.empty(2 * plan.bpad, **f32)
     ws.diag = torch.empty(plan.bpad, **f32)
     nlaunch = 1 if world == 1 else 2
-    part = torch.empty(nlaunch * plan.fwd_slots * 2 * plan.bpad, **f32)
+    part = torch.empty(plan.fwd_ws_floats, **f32)
     ws.logz = torch.empty(2 * plan.bpad, **f32)
     ws.rz = torch.empty(2 * plan.bpad, **f32)
     ws.wrz = torch.empty(2 * plan.bpad, **f32)

@@ -61,7 +61,9 @@ typedef struct crossclr_plan {
     int bpad;       /* b rounded up to 128                                  */
     int Dpad;       /* D rounded up to what the selected kernels need       */
     int fast_path;  /* 1: register-resident bf16 kernels, 0: generic tiled  */
-    int fwd_slots;  /* partial-sum slots one crossclr_forward launch writes */
+    int fwd_blocks; /* persistent thread blocks of the fast forward (0: generic grid) */
+    int fwd_slots;  /* partial-sum slots one crossclr_forward launch owns */
+    size_t fwd_ws_floats; /* floats in the forward workspace `part` (slots of two launches + column sums + flag) */
     int bwd_slices; /* gradient slices crossclr_backward writes (summed by _finish) */
     int loss_ws_doubles; /* doubles in the loss_sum buffer of crossclr_forward_finish: [0] = result */
     size_t operand_bytes;   /* one packed operand X[2][bpad][Dpad]          */
@@ -81,12 +83,17 @@ int crossclr_normalize(const crossclr_plan* plan, const void* video, const void*
                        long ld_video, long ld_text, int in_dtype,
                        void* xhat, float* inv_norm, float* diag_cos, void* stream);
 
-/* Shifted soft-max denominators of the plan's rows against the given columns:
- *   part[slot][2*bpad] += sum_q exp(s(p,q) * xhat_p . xhat_q / tau - shift)
+/* Shifted soft-max denominators of the plan's rows against the given columns, into the forward
+ * workspace `part` (plan->fwd_ws_floats floats; at most two launches per step: slot0 = 0 and
+ * slot0 = fwd_slots):
+ *   part[slot][2*bpad] = sum over the slot's columns q of exp(s(p,q) * xhat_p . xhat_q / tau - shift)
  * with s = 1 across modalities, negative_weight inside a modality, the intra-modal self pair
  * skipped (its exp(0) = 1 is added by crossclr_forward_finish).  Writes `plan->fwd_slots` slots
  * starting at slot0.  col_ranks/col_rank0 describe the column operand; skip_rank (or -1) lets a
- * second launch over the all-gathered operand skip the rank already covered by a local launch. */
+ * second launch over the all-gathered operand skip the rank already covered by a local launch.
+ * When xhat_rows == xhat_cols (local block, slot0 = 0) the bf16 fast path exploits the symmetry of
+ * the stacked matrix (upper triangle only; the mirrored contributions arrive as column sums in the
+ * workspace) -- transparent to the caller, crossclr_forward_finish reads a flag from the workspace. */
 int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
                      int col_ranks, int col_rank0, int skip_rank,
                      float temperature, float negative_weight,

@@ -119,6 +119,7 @@ template <typename T> inline T wave_read_lane(T v, int src) {
 inline float wave_xor_f32(float v, int mask) { return wave_read_lane(v, emu::my_lane() ^ mask); }
 inline double wave_xor_f64(double v, int mask) { return wave_read_lane(v, emu::my_lane() ^ mask); }
 inline float fast_exp2(float x) { return exp2f(x); }
+template <int MASK> inline float lane_xor(float v) { return wave_read_lane(v, emu::my_lane() ^ MASK); }
 
 // v_mfma_f32_32x32x16_bf16: A[i][k] in lane i + 32*(k/8), element k%8; B[k][j] in lane j + 32*(k/8),
 // element k%8; C[i][j] in lane j + 32*((i/4)%2), register (i%4) + 4*(i/8).

@@ -186,7 +186,7 @@ def _shard_via_cabi(v, t, world, mode):
     for r in range(world):
         pp = ctypes.byref(plans[r])
         xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
-        part = torch.empty(2 * pl.fwd_slots * 2 * pl.bpad, **f32)
+        part = torch.empty(pl.fwd_ws_floats, **f32)
         # local block first, then every other rank's columns (skip_rank = r): the overlap schedule
         nat.check(lib.crossclr_forward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(part), 0, stream))
         nat.check(lib.crossclr_forward(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(part), pl.fwd_slots, stream))

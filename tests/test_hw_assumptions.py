@@ -46,6 +46,11 @@ def _check_all(device):
     for lane in range(64):
         half, n = lane >> 5, lane & 31
         assert list(o[lane]) == [(8 * half + e) * 64 + n for e in range(8)], f"transpose read, lane {lane}"
+    # (3) DPP / swizzle lane exchanges used by the symmetric forward's column-sum butterfly
+    v = np.arange(64, dtype=np.float32) + 0.5
+    o = _run(3, v, 5 * 64, np.float32, device).reshape(5, 64)
+    for k, mask in enumerate((1, 2, 7, 15, 16)):
+        assert list(o[k]) == [v[lane ^ mask] for lane in range(64)], f"lane_xor<{mask}>"
 
 
 @pytest.mark.gpu

@@ -93,6 +93,20 @@ def test_zero_negative_and_large_negative_weight(w):
         assert (gt.double() - ref["grad_t"]).abs().max().item() <= gtol * scale
 
 
+@pytest.mark.parametrize("B,D", [(150, 32), (300, 40)])
+def test_symmetric_forward_upper_triangle(B, D, monkeypatch):
+    """bpad >= 256 -> several 256-row blocks: the fast forward evaluates only column tiles at/right of
+    the diagonal block and recovers the mirrored tiles from column sums.  (300: bpad = 384, so one row
+    block straddles the video/text boundary.)  Must agree with the full evaluation bit-for-bit-ish."""
+    v, t = orc.make_inputs("randn", B, D, 5)
+    sym = crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="bf16").item()
+    model = float(orc.bf16_operand_model_loss(v, t, 0.05, 0.8))
+    assert abs(sym - model) <= 2e-6 * max(1.0, abs(model))
+    monkeypatch.setenv("CROSSCLR_DISABLE_SYMMETRIC", "1")
+    full = crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="bf16").item()
+    assert abs(sym - full) <= 1e-6 * max(1.0, abs(full))
+
+
 def test_ragged_batch_crossing_a_tile_boundary():
     # B = 70: one full 64-column tile + a ragged one in the fast path; a ragged 128 tile in the generic path
     v, t = orc.make_inputs("randn", 70, 24, 17)
