@@ -192,8 +192,9 @@ inline void lds_dma16(const void* gsrc, void* lds_wave_base) {
 inline void lds_dma4(const void* gsrc, void* lds_wave_base) {
     memcpy(static_cast<unsigned char*>(lds_wave_base) + 4 * emu::my_lane(), gsrc, 4);
 }
-inline void wait_dma() {}
-template <int N> inline void wait_dma_keep() {}
+// a wave's DMA is complete for the whole wave once every lane has passed this point
+inline void wait_dma() { emu::wave_sync(); }
+template <int N> inline void wait_dma_keep() { emu::wave_sync(); }
 inline int uniform(int x) { return x; }
 
 }  // namespace crossclr
