@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Merge rocprofv3 --pmc passes (gpurun_out/<prefix>_<COUNTER>/.../*_counter_collection.csv) into one
+JSON summary for profiles/.  usage: make_pmc_json.py <prefix> <out.json> B D mode"""
+import collections, csv, glob, json, re, sys
+prefix, out, B, D, mode = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+agg = collections.defaultdict(dict)
+for path in glob.glob(f"gpurun_out/{prefix}_*/*/*_counter_collection.csv"):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void crossclr::", "").replace("crossclr::", "")
+        if "at::" in k or "kernel" not in k: continue
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in per.items():
+        for c, v in cs.items(): agg[k][c] = sum(v) / len(v)
+res = {"config": {"B": B, "D": D, "mode": mode, "command": "rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python tools/kbench.py"},
+       "note": "means per dispatch. FETCH_SIZE/WRITE_SIZE in KiB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half the bytes of a wide (16 B/lane) coalesced read stream, so hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE and WRITE_SIZE need separate passes. SQ_WAVE_CYCLES counts quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles.",
+       "kernels": {}}
+for k, e in agg.items():
+    e = dict(e)
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["hbm_bytes_raw"] = (e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024
+        e["hbm_bytes_corrected"] = (2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024
+    if "TCC_HIT_sum" in e: e["l2_hit_rate"] = e["TCC_HIT_sum"] / max(1.0, e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
+    if e.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+        e["mfma_busy_over_wave_cycles"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * e["SQ_WAVE_CYCLES"])
+    res["kernels"][k] = e
+json.dump(res, open(out, "w"), indent=1)
+for k, e in res["kernels"].items():
+    print(f"{k[:44]:44s} hbm {e.get('hbm_bytes_corrected',0)/1e6:7.1f} MB  L2hit {e.get('l2_hit_rate',0):.2f}  mfma/wave {e.get('mfma_busy_over_wave_cycles',0):.3f}  ldsconf {e.get('SQ_LDS_BANK_CONFLICT')}")
