@@ -95,6 +95,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on the C-level stdout of every rank.  Keep this process's stdout to
+    # exactly ONE JSON line: everything else that lands on fd 1 is sent to stderr; the result goes to
+    # the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     import crossclr_amd
     from crossclr_amd import _native as nat
@@ -199,7 +206,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(b, d)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

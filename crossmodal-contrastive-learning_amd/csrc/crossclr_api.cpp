@@ -56,6 +56,17 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static size_t ws_colpart_off(const crossclr_plan* p) { return (size_t)2 * p->fwd_slots * 2 * p->bpad; }
 static size_t ws_flag_off(const crossclr_plan* p) { return ws_colpart_off(p) + (size_t)(2 * p->bpad / 256 + 1) * 2 * p->bpad; }
 
+static int device_zero(void* where, size_t bytes, void* stream) {
+#ifdef CROSSCLR_EMU
+    (void)stream;
+    memset(where, 0, bytes);
+    return CROSSCLR_OK;
+#else
+    hipError_t e = hipMemsetAsync(where, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CROSSCLR_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return CROSSCLR_OK;
+#endif
+}
 static int device_zero_header(int* where, void* stream) {  // kind 0 = dense slots (generic kernels)
 #ifdef CROSSCLR_EMU
     (void)stream;
@@ -208,6 +219,13 @@ extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows
         // sharded run): evaluate only the upper triangle of the symmetric matrix
         const bool symmetric = xhat_rows == xhat_cols && col_ranks == 1 && col_rank0 == plan->rank && skip_rank < 0 &&
                                !getenv("CROSSCLR_DISABLE_SYMMETRIC");
+        const bool skipping = skip_rank >= col_rank0 && skip_rank < col_rank0 + col_ranks;
+        if (col_ranks - (skipping ? 1 : 0) <= 0) {
+            // nothing to do (every column rank is skipped): leave a dense, all-zero launch behind
+            rc = device_zero_header(header, stream);
+            if (rc) return rc;
+            return device_zero(out, (size_t)plan->fwd_slots * 2 * plan->bpad * sizeof(float), stream);
+        }
         rc = fast_forward(plan, g, xhat_rows, xhat_cols, out, part + ws_colpart_off(plan), header, symmetric, stream);
         return rc ? fail(rc, "fast_forward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_fwd_kernel");
     }

@@ -23,6 +23,7 @@ Keyword-only additions (defaults reproduce the reference's single-process behavi
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -62,7 +63,7 @@ def _resolve_mode(compute_mode: str, global_batch: int) -> int:
 class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
-                 "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype")
+                 "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded")
 
 
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
@@ -73,19 +74,23 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     b, D = video.shape
     world = dist.get_world_size(group) if group is not None else 1
     rank = dist.get_rank(group) if group is not None else 0
+    # CROSSCLR_FORCE_SHARDED_PATH=1 (test knob): take the multi-rank code path (all-gather, second launch
+    # with skip_rank, statistics gather, loss all-reduce) even for a 1-rank group, so the collectives and the
+    # skip logic can be exercised on a single GPU
+    sharded = world > 1 or (group is not None and os.environ.get("CROSSCLR_FORCE_SHARDED_PATH") == "1")
     mode = _resolve_mode(compute_mode, b * world)
     plan = nat.make_plan(b, D, world, rank, mode)
     stream = _stream_for(video)
     f32 = dict(dtype=torch.float32, device=dev)
 
     ws = _Workspace()
-    ws.plan, ws.world, ws.rank = plan, world, rank
+    ws.plan, ws.world, ws.rank, ws.sharded = plan, world, rank, sharded
     ws.temperature, ws.negative_w = float(temperature), float(negative_w)
     ws.in_dtype = _IN_DTYPE[video.dtype]
     ws.xhat = torch.empty(plan.operand_bytes, dtype=torch.uint8, device=dev)
     ws.inv_norm = torch.empty(2 * plan.bpad, **f32)
     ws.diag = torch.empty(plan.bpad, **f32)
-    nlaunch = 1 if world == 1 else 2
+    nlaunch = 2 if sharded else 1
     part = torch.empty(plan.fwd_ws_floats, **f32)
     ws.logz = torch.empty(2 * plan.bpad, **f32)
     ws.rz = torch.empty(2 * plan.bpad, **f32)
@@ -96,7 +101,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     nat.check(lib.crossclr_normalize(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
                                      _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
     gather = None
-    if world > 1:
+    if sharded:
         # all-gather of the packed operands runs on the collective's own stream (RCCL over xGMI)
         # while the local column block is processed on the compute stream
         ws.xcols = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device=dev)
@@ -105,14 +110,14 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         ws.xcols = ws.xhat
     nat.check(lib.crossclr_forward(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                    _ptr(part), 0, stream))
-    if world > 1:
+    if sharded:
         gather.wait()
         nat.check(lib.crossclr_forward(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                        ws.negative_w, _ptr(part), plan.fwd_slots, stream))
     nat.check(lib.crossclr_forward_finish(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), ws.temperature,
                                           ws.negative_w, _ptr(ws.logz), _ptr(ws.rz), _ptr(ws.wrz),
                                           _ptr(ws.loss_sum), stream))
-    if world > 1:
+    if sharded:
         stats = torch.cat([ws.rz, ws.wrz])
         allstats = torch.empty(world * stats.numel(), **f32)
         dist.all_gather_into_tensor(allstats, stats, group=group)
@@ -136,11 +141,10 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     stream = _stream_for(video)
     gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
     rank, world = ws.rank, ws.world
-    rz_loc = ws.rz_cols[rank] if world > 1 else ws.rz
-    wrz_loc = ws.wrz_cols[rank] if world > 1 else ws.wrz
+    rz_loc, wrz_loc = ws.rz, ws.wrz   # column statistics of the local block = this rank's row statistics
     nat.check(lib.crossclr_backward(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                     _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc), _ptr(gbuf), 0, stream))
-    if world > 1:
+    if ws.sharded:
         nat.check(lib.crossclr_backward(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                         ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols),
                                         _ptr(ws.wrz_cols), _ptr(gbuf), 1, stream))

@@ -263,3 +263,33 @@ def test_module_device_behaviour():
         crit(v, t)  # CPU tensors: no CPU fallback
     with pytest.raises(nat.CrossCLRNativeError):
         crossclr_amd.crossclr_loss(vd, td, temperature=0.001)  # outside the fixed-shift range: loud, not inf
+
+
+def test_sharded_host_path_with_real_collectives_on_one_gpu(monkeypatch):
+    """The multi-rank code path end to end on the device: RCCL all_gather_into_tensor of the packed operand
+    (async, overlapped with the local launch), the skip_rank launch, the statistics all-gather and the loss
+    all-reduce -- with a 1-rank NCCL group (CROSSCLR_FORCE_SHARDED_PATH), which is all a 1-GPU box allows.
+    Must reproduce the plain single-GPU result."""
+    import os
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for mode, B, D in (("bf16", 1024, 512), ("fp32", 200, 96)):
+            v, t = orc.make_inputs("randn", B, D, 41)
+            m = dict(temperature=0.03, negative_weight=0.8)
+            loss1, gv1, gt1 = run_module(v, t, m, mode)
+            monkeypatch.setenv("CROSSCLR_FORCE_SHARDED_PATH", "1")
+            crit = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode=mode, process_group=dist.group.WORLD).cuda()
+            vd = v.cuda().requires_grad_(True)
+            td = t.cuda().requires_grad_(True)
+            loss = crit(vd, td)
+            loss.backward()
+            torch.cuda.synchronize()
+            monkeypatch.delenv("CROSSCLR_FORCE_SHARDED_PATH")
+            assert abs(loss.item() - loss1.item()) <= 1e-9 * max(1.0, abs(loss1.item()))
+            assert torch.equal(vd.grad, gv1) and torch.equal(td.grad, gt1)
+    finally:
+        dist.destroy_process_group()
