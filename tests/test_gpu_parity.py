@@ -293,3 +293,41 @@ def test_sharded_host_path_with_real_collectives_on_one_gpu(monkeypatch):
             assert torch.equal(vd.grad, gv1) and torch.equal(td.grad, gt1)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,D,mode", [
+    (1000, 100, "bf16"),    # D padded 100 -> 128 (DK=8), ragged batch
+    (1536, 256, "bf16"),    # DK=16; bpad = 1536 (6 row blocks of 256)
+    (1300, 384, "bf16"),    # DK=24 (48 KiB tiles), ragged, row block straddling the modality boundary
+    (2048, 512, "bf16"),    # DK=32
+    (640, 600, "bf16"),     # D > 512: generic tiled bf16 kernels, Dpad = 768 (3 slices of 256)
+    (512, 1024, "bf16"),    # BASELINE config 5's embedding width through the generic bf16 kernels
+    (777, 200, "fp32"),     # generic fp32, Dpad = 256
+    (1024, 768, "fp32"),    # generic fp32, three backward slices
+    (3000, 512, "auto"),    # auto -> bf16 (global batch >= 1024)
+    (500, 512, "auto"),     # auto -> fp32
+])
+def test_shape_sweep_against_streaming_oracle(B, D, mode):
+    v, t = orc.make_inputs("randn", B, D, 1000 + B + D)
+    ref = orc.streaming_loss_and_grads(v, t, 0.03, 0.8, block=512)
+    loss, gv, gt = run_module(v, t, dict(temperature=0.03, negative_weight=0.8), mode)
+    exact = mode == "fp32" or (mode == "auto" and B < crossclr_amd.AUTO_BF16_MIN_GLOBAL_BATCH)
+    assert abs(loss.item() - float(ref["loss"])) <= (2e-5 if exact else 1e-3)
+    scale = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+    tol = (2e-4 if exact else 1e-2) * scale
+    assert (gv.double().cpu() - ref["grad_v"]).abs().max().item() <= tol
+    assert (gt.double().cpu() - ref["grad_t"]).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64])
+def test_input_dtypes_on_the_fast_path(dtype):
+    # inputs in any float dtype; gradients come back in that dtype; loss stays float64
+    v, t = orc.make_inputs("randn", 1280, 256, 9)
+    v, t = v.to(dtype), t.to(dtype)
+    ref = orc.streaming_loss_and_grads(v.double(), t.double(), 0.03, 0.8, block=512)
+    loss, gv, gt = run_module(v, t, dict(temperature=0.03, negative_weight=0.8), "bf16")
+    assert loss.dtype == torch.float64 and gv.dtype == dtype and gt.dtype == dtype
+    assert abs(loss.item() - float(ref["loss"])) <= 1e-3
+    scale = ref["grad_v"].abs().max().item()
+    out_eps = {torch.float16: 1e-3, torch.bfloat16: 8e-3, torch.float64: 0.0}[dtype]  # rounding of the stored gradient
+    assert (gv.double().cpu() - ref["grad_v"]).abs().max().item() <= (1e-2 + out_eps) * scale
