@@ -126,13 +126,17 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
 #endif
     plan->fwd_slots = nsplit;
     plan->fwd_ws_floats = 0;  // set below
-    // backward column slices (fast path only): one block per CU needs >= 256 blocks of 128 rows
-    plan->bwd_slices = 1;
-    if (plan->fast_path) {
-        const int rb = 2 * plan->bpad / 128;
-        int sl = (256 + rb - 1) / rb;
-        const int tiles = 2 * plan->bpad / 32;
-        if (sl > tiles / 8) sl = tiles / 8;   // keep >= 8 column tiles per slice
+    // backward column slices: each slice walks its share of the column tiles and writes its own gradient
+    // slice (summed by crossclr_backward_finish): enough thread blocks to occupy 256 CUs, >= 2 tiles each
+    {
+        const int tile = plan->fast_path ? 32 : 64;
+        const int row_blk = plan->fast_path ? 128 : 64;
+        int dsl = 1;
+        if (!plan->fast_path) dsl = plan->Dpad % 256 == 0 ? plan->Dpad / 256 : (plan->Dpad % 128 == 0 ? plan->Dpad / 128 : plan->Dpad / 64);
+        const int blocks = (2 * plan->bpad / row_blk) * dsl;
+        int sl = (256 + blocks - 1) / blocks;
+        const int tiles = 2 * plan->bpad / tile;
+        if (sl > tiles / 2) sl = tiles / 2;
         if (sl > 16) sl = 16;
         if (sl < 1) sl = 1;
         plan->bwd_slices = sl;
@@ -268,15 +272,18 @@ static int backward_generic(const crossclr_plan* p, const Geo& g, const void* ro
                             const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
     dim3 block(256);
     const int rb = 2 * p->bpad / 64;
+    const int ntiles = g.col_ranks * 2 * p->bpad / 64;
+    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+    const unsigned nz = (unsigned)p->bwd_slices;
     if (p->Dpad % 256 == 0) {
-        LAUNCH((bwd_kernel<T, 256>), dim3(rb, p->Dpad / 256), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
-               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate);
+        LAUNCH((bwd_kernel<T, 256>), dim3(rb, p->Dpad / 256, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
+               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps);
     } else if (p->Dpad % 128 == 0) {
-        LAUNCH((bwd_kernel<T, 128>), dim3(rb, p->Dpad / 128), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
-               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate);
+        LAUNCH((bwd_kernel<T, 128>), dim3(rb, p->Dpad / 128, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
+               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps);
     } else {
-        LAUNCH((bwd_kernel<T, 64>), dim3(rb, p->Dpad / 64), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
-               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate);
+        LAUNCH((bwd_kernel<T, 64>), dim3(rb, p->Dpad / 64, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
+               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps);
     }
     return launch_status("bwd_kernel");
 }

@@ -187,7 +187,7 @@ static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, in
     w.NB = 2 * bpad / 256;
     w.NT = kind == 1 ? 2 * bpad / 32 : usable_col_tiles;
     w.total = fwd_prefix(w, w.NB);
-    int nb = w.total / 8;                     // at least ~8 tiles per block
+    int nb = w.total / 2;                     // at least ~2 tiles per block
     if (nb > max_blocks) nb = max_blocks;
     if (nb < 1) nb = 1;
     w.per = (w.total + nb - 1) / nb;

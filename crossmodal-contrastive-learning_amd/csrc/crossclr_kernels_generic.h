@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(64) fwd_finish_reduce_kernel(double* loss_ws, 
 //   phase B  W[p][q]   = s * exp2(c S - m2) * (rz_p + rz_q), self pair -> 0, to LDS in operand type
 //   phase C  G[p][d]  += W[p][:] . xhat_Q[:, d]   (MFMA, contraction over the 64 columns q;
 //            the q-contiguous operand comes from ds_read_b64_tr_b16 for bf16, plain ds_read_b32 for fp32)
-// grid = (2*bpad/64, Dpad/DC).  Accumulators: 64 x DC fp32 per block (64 VGPRs per lane at DC=256).
+// grid = (2*bpad/64, Dpad/DC, column slices).  Accumulators: 64 x DC fp32 per block (64 VGPRs per lane at DC=256).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DC> struct BwdLds {
     static constexpr int kTileP = 0;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void bwd_gemm2(const unsigned char* wt, const unsigne
 template <typename T, int DC>
 __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, Geo g, const float* rz_rows,
                                                   const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
-                                                  float* gbuf, int accumulate) {
+                                                  float* gbuf, int accumulate, int tiles_per_slice) {
     typedef Operand<T> Op;
     typedef BwdLds<T, DC> L;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[L::kTotal];
@@ -453,8 +453,11 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
     const float rzp_intra = wrz_rows[row0 + p_t];
 
     const int ntiles = g.col_ranks * 2 * g.bpad / 64;
+    const int t_begin = blockIdx.z * tiles_per_slice;   // column slice z walks its share of the tiles ...
+    int t_stop = t_begin + tiles_per_slice;
+    if (t_stop > ntiles) t_stop = ntiles;
     KTileStage<64, 256> sp, sq;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_begin; t < t_stop; ++t) {
         const ColTile ct = col_tile(g, t, 64);
         if (ct.rank == g.skip_rank) continue;
         const unsigned char* cbase = reinterpret_cast<const unsigned char*>(cols) + ct.row0 * pitch;
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + 32 * wr + frag_row(r, half);
             const int d = d0 + wc * (DC / 2) + 32 * dt + l31;
-            float* dst = gbuf + (size_t)row * g.Dpad + d;
+            float* dst = gbuf + (size_t)blockIdx.z * 2 * g.bpad * g.Dpad + (size_t)row * g.Dpad + d;  // ... into its own slice
             *dst = accumulate ? (*dst + acc2[dt][r]) : acc2[dt][r];
         }
 }

@@ -149,7 +149,7 @@ def test_temperature_outside_fixed_shift_range_fails_loudly():
 def test_plan_geometry():
     p = nat.make_plan(8192, 512, 1, 0, nat.MODE_BF16)
     assert (p.bpad, p.Dpad, p.fast_path) == (8192, 512, 1)
-    assert p.operand_bytes == 2 * 8192 * 512 * 2 and p.bwd_slices == 2 and p.gbuf_bytes == 2 * 2 * 8192 * 512 * 4
+    assert p.operand_bytes == 2 * 8192 * 512 * 2 and p.bwd_slices == 2 and p.gbuf_bytes == 2 * 2 * 8192 * 512 * 4 and p.fwd_blocks == 256
     p = nat.make_plan(100, 300, 8, 3, nat.MODE_FP32)
     assert (p.bpad, p.Dpad, p.fast_path, p.world, p.rank) == (128, 512, 0, 8, 3)
     p = nat.make_plan(100, 700, 1, 0, nat.MODE_BF16)
