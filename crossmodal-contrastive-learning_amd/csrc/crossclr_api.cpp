@@ -139,6 +139,10 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         if (sl > tiles / 2) sl = tiles / 2;
         if (sl > 16) sl = 16;
         if (sl < 1) sl = 1;
+        if (const char* e = getenv("CROSSCLR_BWD_SLICES")) {  // tuning knob
+            int v = atoi(e);
+            if (v >= 1 && v <= tiles / 2 && v <= 64) sl = v;
+        }
         plan->bwd_slices = sl;
     }
     {
