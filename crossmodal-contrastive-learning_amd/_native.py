@@ -24,7 +24,7 @@ E_RANGE = -2
 class Plan(ctypes.Structure):
     _fields_ = [("b", ctypes.c_int), ("D", ctypes.c_int), ("world", ctypes.c_int), ("rank", ctypes.c_int),
                 ("mode", ctypes.c_int), ("bpad", ctypes.c_int), ("Dpad", ctypes.c_int),
-                ("fast_path", ctypes.c_int), ("fwd_blocks", ctypes.c_int), ("fwd_slots", ctypes.c_int),
+                ("fast_path", ctypes.c_int), ("fast_bwd", ctypes.c_int), ("fwd_blocks", ctypes.c_int), ("fwd_slots", ctypes.c_int),
                 ("fwd_ws_floats", ctypes.c_size_t),
                 ("bwd_slices", ctypes.c_int),
                 ("loss_ws_doubles", ctypes.c_int),

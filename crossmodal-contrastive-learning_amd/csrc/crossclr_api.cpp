@@ -14,6 +14,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef CROSSCLR_DEFAULT_BWD_KERNEL
+#define CROSSCLR_DEFAULT_BWD_KERNEL 1   // 1: 32-row waves, 2: 16-row waves (for Dpad <= 512, where both exist)
+#endif
+
 using namespace crossclr;
 
 static thread_local char g_err[512] = "";
@@ -98,6 +102,18 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
 #endif
     if (!plan->fast_path && dpad > 256) dpad = round_up(D, 256);  // generic backward slices D by 256
     plan->Dpad = dpad;
+    // backward kernel: 0 generic tiled, 1 register-resident 32-row waves (Dpad <= 512), 2 16-row waves (Dpad <= 1024)
+    plan->fast_bwd = 0;
+#ifndef CROSSCLR_NO_FAST
+    if (mode == CROSSCLR_MODE_BF16 && !getenv("CROSSCLR_DISABLE_FAST")) {
+        if (plan->fast_path) plan->fast_bwd = CROSSCLR_DEFAULT_BWD_KERNEL;
+        else if (dpad == 768 || dpad == 1024) plan->fast_bwd = 2;
+        if (const char* e = getenv("CROSSCLR_BWD_KERNEL")) {  // tuning knob: 16 or 32
+            if (atoi(e) == 16 && (plan->fast_path || dpad == 768 || dpad == 1024)) plan->fast_bwd = 2;
+            if (atoi(e) == 32 && plan->fast_path) plan->fast_bwd = 1;
+        }
+    }
+#endif
     // forward partial-sum slots.  generic kernels: (row block x column split) grid, enough work items to
     // fill 256 CUs a few times over.  fast path: persistent blocks over a flat work list (see FwdWork);
     // a row block's slots = the thread blocks whose range touches it.
@@ -129,10 +145,13 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     // backward column slices: each slice walks its share of the column tiles and writes its own gradient
     // slice (summed by crossclr_backward_finish): enough thread blocks to occupy 256 CUs, >= 2 tiles each
     {
-        const int tile = plan->fast_path ? 32 : 64;
-        const int row_blk = plan->fast_path ? 128 : 64;
+        const int tile = plan->fast_bwd ? 32 : 64;
+        int row_blk = 64;
+#ifndef CROSSCLR_NO_FAST
+        if (plan->fast_bwd) row_blk = fast_bwd_rows_per_block(plan->Dpad, plan->fast_bwd == 2);
+#endif
         int dsl = 1;
-        if (!plan->fast_path) dsl = plan->Dpad % 256 == 0 ? plan->Dpad / 256 : (plan->Dpad % 128 == 0 ? plan->Dpad / 128 : plan->Dpad / 64);
+        if (!plan->fast_bwd) dsl = plan->Dpad % 256 == 0 ? plan->Dpad / 256 : (plan->Dpad % 128 == 0 ? plan->Dpad / 128 : plan->Dpad / 64);
         const int blocks = (2 * plan->bpad / row_blk) * dsl;
         int sl = (256 + blocks - 1) / blocks;
         const int tiles = 2 * plan->bpad / tile;
@@ -303,8 +322,12 @@ extern "C" int crossclr_backward(const crossclr_plan* plan, const void* xhat_row
     int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
     if (rc) return rc;
 #ifndef CROSSCLR_NO_FAST
-    if (plan->fast_path)
-        return fast_backward(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+    if (plan->fast_bwd) {
+        rc = plan->fast_bwd == 2
+                 ? fast_backward16(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream)
+                 : fast_backward(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+        return rc ? fail(rc, "fast backward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_kernel");
+    }
 #endif
     if (plan->mode == CROSSCLR_MODE_FP32)
         return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
@@ -341,7 +364,7 @@ extern "C" int crossclr_backward_finish(const crossclr_plan* plan, const float* 
 }
 
 extern "C" int crossclr_selftest(int which, const void* in, void* out, void* stream) {
-    if (which < 0 || which > 3 || !in || !out) return fail(CROSSCLR_E_ARG, "bad selftest arguments");
+    if (which < 0 || which > 4 || !in || !out) return fail(CROSSCLR_E_ARG, "bad selftest arguments");
     LAUNCH(selftest_kernel, dim3(1), dim3(64), stream, which, in, out);
     return launch_status("selftest_kernel");
 }

@@ -53,6 +53,10 @@ struct Geo {
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// 16x16x32: A[i][k] in lane i + 16*(k/8), element k%8; B[k][j] in lane j + 16*(k/8); C[i][j] in lane j + 16*(i/4), reg i%4
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

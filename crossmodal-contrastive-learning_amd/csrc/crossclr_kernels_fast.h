@@ -109,7 +109,10 @@ __device__ __forceinline__ int swz_slot(int chunk, int q) { return (chunk & ~15)
 
 // Issue this wave's share of the LDS-DMA for one 64-row column tile (+ optionally its 64 per-column
 // statistics).  NW waves cooperate; wave-instruction ii fills LDS bytes [ii*1024, ii*1024+1024).
-template <int RB, int NW, int QT>
+// tile image of the 16-row backward: sigma(q) = (q & 7) << 1
+__device__ __forceinline__ int swz_slot16r(int chunk, int q) { return (chunk & ~15) | ((chunk ^ ((q & 7) << 1)) & 15); }
+
+template <int RB, int NW, int QT, int SWZ = 0>
 __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, unsigned char* buf, int wave, int lane,
                                                const float* stat_src, unsigned char* stat_dst) {
     constexpr int kInstr = QT * RB / 1024;  // wave-instructions per tile
@@ -119,7 +122,7 @@ __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, un
         if (kInstr % NW == 0 || ii < kInstr) {
             const int L = ii * 1024 + lane * 16;
             const int row = L / RB, slot = (L - row * RB) >> 4;
-            lds_dma16(tile_src + (size_t)row * RB + (swz_slot(slot, row) << 4), buf + ii * 1024);
+            lds_dma16(tile_src + (size_t)row * RB + ((SWZ ? swz_slot16r(slot, row) : swz_slot(slot, row)) << 4), buf + ii * 1024);
         }
     }
     // every wave issues the (identical) statistics DMA so that all waves have the same VMEM count per tile:
@@ -605,6 +608,190 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, 16-row wavefronts (v_mfma_f32_16x16x32_bf16).  A wave owns 16 rows: 16 x Dpad fp32 gradient
+// accumulators (Dpad/4 registers) + Dpad/8 registers of row fragments -- half of what the 32-row kernel
+// needs, so at Dpad <= 512 TWO waves fit per SIMD (8 waves x 16 rows = 128 rows per block) and hide each
+// other's LDS latency, barriers and exp/weight VALU; and Dpad up to 1024 fits at all (4 waves, 64 rows).
+// The price is twice the LDS read traffic per MFMA flop (a 16-row wave re-reads the whole column tile for
+// half the rows).  Same dataflow as fast_bwd_kernel: S^T = Xq.Xp^T with swapped operands (lane owns row
+// p = lane&15 and four columns of each 16x16 fragment) -> W in registers; the lane's eight weights of a
+// 32-column tile are exactly ONE A fragment of the second product (k-slot (g,j) <-> column 4g+j / 16+4g+j-4),
+// whose B fragments are two ds_read_b64_tr_b16 of the same tile.
+// Tile image: row q at q*RB, 16-byte chunk c at slot (c & ~15) | ((c ^ ((q&7)<<1)) & 15): conflict-free for
+// the ds_read_b128 of the first product (a 16-lane group mixes two k-groups: even/odd slots) and for the
+// transpose reads of the second (8 rows x 2 chunks -> 16 distinct slots per 32 lanes).
+// ---------------------------------------------------------------------------------------------
+template <int DKK, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
+                                                                    const float* rz_rows, const float* wrz_rows,
+                                                                    const float* rz_cols, const float* wrz_cols,
+                                                                    float* gbuf, int accumulate, int tiles_per_slice) {
+    constexpr int DP = DKK * 32;           // padded embedding width
+    constexpr int RB = DP * 2;             // bytes per operand row
+    constexpr int QT = 32;
+    constexpr int TILE = QT * RB;
+    constexpr int NST = (4 * TILE + 512 <= 160 * 1024) ? 4 : 2;   // ring depth
+    constexpr int DS = DP / 16;            // 16-wide output fragments
+    constexpr int PF = (CROSSCLR_PF < DKK / 2) ? CROSSCLR_PF : (DKK / 2 > 0 ? DKK / 2 : 1);
+    constexpr int NOPS = QT * RB / 1024 / NW + 1;
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128];
+    unsigned char* stat = lds + NST * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int row0w = blockIdx.x * (16 * NW) + 16 * wave;
+    const int rmod = row0w / g.bpad;
+    const int r0_in_mod = row0w - rmod * g.bpad;         // first row of the wave inside its modality (multiple of 16)
+
+    bf16x8 pf[DKK];
+    {
+        const bf16_t* src = rows + (size_t)(row0w + i16) * DP + 8 * g4;
+#pragma unroll
+        for (int ks = 0; ks < DKK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 32 * ks);
+    }
+    const float rzp_inter = rz_rows[row0w + i16];
+    const float rzp_intra = wrz_rows[row0w + i16];
+
+    // first product: row q = i16 (+16) of the tile, chunk 4ks + g4
+    int offA[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offA[j] = i16 * RB + ((((4 * j + g4) ^ ((i16 & 7) << 1)) & 15) << 4);
+    // second product: in a 16-lane group (= k-group g4) lane 4j+c addresses row 4g4 + j (+16), 8-byte piece c
+    const int jrow = i16 >> 2, piece = i16 & 3;
+    int comb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        comb[k] = (4 * g4 + jrow) * RB + 32 * (k ^ (4 * (g4 & 1) + jrow)) + 16 * (piece >> 1) + 8 * (piece & 1);
+
+    f32x4 acc2[DS];
+#pragma unroll
+    for (int d = 0; d < DS; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[d][r] = 0.f;
+
+    const int ntiles = g.col_ranks * 2 * g.bpad / QT;
+    const int per_rank = 2 * g.bpad / QT;
+    int t0 = blockIdx.y * tiles_per_slice;
+    int t_end = t0 + tiles_per_slice;
+    if (t_end > ntiles) t_end = ntiles;
+    auto next = [&](int x) {
+        if (x >= t_end) return t_end;
+        if (g.skip_rank >= 0 && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
+        return x < t_end ? x : t_end;
+    };
+    const size_t pitch = RB;
+    auto issue = [&](int tile, int stage) {
+        const ColTile c = col_tile(g, tile, QT);
+        issue_tile_dma<RB, NW, QT, 1>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE,
+                                      wave, lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128);
+    };
+    auto wait_keep = [&](int tiles_in_flight) {
+        if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
+        else if (tiles_in_flight == 1) wait_dma_keep<NOPS>();
+        else wait_dma();
+    };
+    struct Pair { s16x4 lo, hi; };
+    int tl[NST];  // tl[0]: tile being consumed; tl[1..NST-2]: in flight; tl[NST-1]: issued after the barrier
+    tl[0] = next(t0);
+#pragma unroll
+    for (int k = 1; k < NST; ++k) tl[k] = next(tl[k - 1] + 1);
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k)
+        if (tl[k] < t_end) issue(tl[k], k);
+    int stage = 0;
+    while (tl[0] < t_end) {
+        int inflight = 0;
+#pragma unroll
+        for (int k = 1; k < NST - 1; ++k) inflight += (tl[k] < t_end);
+        wait_keep(inflight);
+        __syncthreads();
+        if (tl[NST - 1] < t_end) issue(tl[NST - 1], (stage + NST - 1) % NST);
+        const unsigned char* bt = lds + stage * TILE;
+        const ColTile ct = col_tile(g, tl[0], QT);
+        // ---- S^T = Xq . Xp^T: two 16x16 fragments (columns 0-15 and 16-31 of the tile), independent chains ----
+        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            bf16x8 r0[PF], r1[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const unsigned char* a = bt + offA[i & 3] + (i >> 2) * 256;
+                r0[i] = *reinterpret_cast<const bf16x8*>(a);
+                r1[i] = *reinterpret_cast<const bf16x8*>(a + 16 * RB);
+            }
+#pragma unroll
+            for (int ks = 0; ks < DKK; ++ks) {
+                const bf16x8 a0 = r0[ks % PF], a1 = r1[ks % PF];
+                if (ks + PF < DKK) {
+                    const unsigned char* a = bt + offA[(ks + PF) & 3] + ((ks + PF) >> 2) * 256;
+                    r0[ks % PF] = *reinterpret_cast<const bf16x8*>(a);
+                    r1[ks % PF] = *reinterpret_cast<const bf16x8*>(a + 16 * RB);
+                }
+                x0 = mfma_16x16x32_bf16(a0, pf[ks], x0);
+                x1 = mfma_16x16x32_bf16(a1, pf[ks], x1);
+            }
+            SCHED_PIPELINE_FWD(DKK, PF);
+        }
+        // ---- W = s E (1/Z_p + 1/Z_q) -> ONE bf16 A fragment for the whole tile ----
+        const bool same_mod = (ct.mod == rmod);
+        const float c2 = same_mod ? g.c_intra : g.c_inter;
+        const float rzp = same_mod ? rzp_intra : rzp_inter;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { x0[r] = x0[r] * c2 - g.m2; x1[r] = x1[r] * c2 - g.m2; }
+        if (same_mod && ct.rank == g.row_rank && ct.in_mod0 == (r0_in_mod & ~31)) {  // tile holds the wave's diagonal
+            const int pt = (r0_in_mod & 31) + i16;   // this lane's row as a column index of the tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * g4 + r == pt) x0[r] = -__builtin_inff();
+                if (16 + 4 * g4 + r == pt) x1[r] = -__builtin_inff();
+            }
+        }
+        const float* rzq = reinterpret_cast<const float*>(stat + stage * 128);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(rzq + 4 * g4);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(rzq + 16 + 4 * g4);
+        struct { bf16_t e[8]; } pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pk.e[r] = f32_to_bf16_bits(fast_exp2(x0[r]) * (rzp + q0[r]));
+            pk.e[4 + r] = f32_to_bf16_bits(fast_exp2(x1[r]) * (rzp + q1[r]));
+        }
+        const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+        // ---- G[p][:] += W[p][q] . Xq[q][:] : one k-step (32 columns) per 16-wide output fragment ----
+        {
+            auto trpair = [&](int ds) {
+                Pair p;
+                const unsigned char* a = bt + comb[ds & 7] + 256 * (ds >> 3);
+                p.lo = lds_read_tr16_b64(a);
+                p.hi = lds_read_tr16_b64(a + 16 * RB);
+                return p;
+            };
+            constexpr int PF2 = CROSSCLR_PF < DS / 2 ? CROSSCLR_PF : DS / 2;
+            Pair ring[PF2];
+#pragma unroll
+            for (int i = 0; i < PF2; ++i) ring[i] = trpair(i);
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                const Pair curp = ring[ds % PF2];
+                if (ds + PF2 < DS) ring[ds % PF2] = trpair(ds + PF2);
+                acc2[ds] = mfma_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, curp), acc2[ds]);
+            }
+            SCHED_PIPELINE(DS, 2, PF2);
+        }
+#pragma unroll
+        for (int k = 0; k < NST - 1; ++k) tl[k] = tl[k + 1];
+        tl[NST - 1] = next(tl[NST - 2] + 1);
+        stage = (stage + 1) % NST;
+    }
+    float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * DP;
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* dst = gslice + (size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16;
+            *dst = accumulate ? (*dst + acc2[ds][r]) : acc2[ds][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers (called from crossclr_api.cpp)
 // ---------------------------------------------------------------------------------------------
 #ifdef CROSSCLR_EMU
@@ -644,6 +831,33 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
         case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
         default: return CROSSCLR_E_ARG;
     }
+    return CROSSCLR_OK;
+}
+
+// which backward the fast path uses: 16-row wavefronts (rows per block 128 at Dpad <= 512, 64 above) or the
+// 32-row kernel (Dpad <= 512 only)
+static inline int fast_bwd_rows_per_block(int Dpad, int use16) { return use16 ? (Dpad <= 512 ? 128 : 64) : 128; }
+
+static inline int fast_backward16(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
+                                  const float* rz_rows, const float* wrz_rows, const float* rz_cols,
+                                  const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
+    const int ntiles = g.col_ranks * 2 * p->bpad / 32;
+    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+    const bf16_t* r = (const bf16_t*)rows;
+    const bf16_t* c = (const bf16_t*)cols;
+#define CROSSCLR_L16(DKK, NW)                                                                                      \
+    CROSSCLR_FAST_LAUNCH((fast_bwd16_kernel<DKK, NW>), dim3(2 * p->bpad / (16 * NW), p->bwd_slices), dim3(64 * NW), stream, r, c, g, \
+                         rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps)
+    switch (p->Dpad) {
+        case 128: CROSSCLR_L16(4, 8); break;
+        case 256: CROSSCLR_L16(8, 8); break;
+        case 384: CROSSCLR_L16(12, 8); break;
+        case 512: CROSSCLR_L16(16, 8); break;
+        case 768: CROSSCLR_L16(24, 4); break;
+        case 1024: CROSSCLR_L16(32, 4); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_L16
     return CROSSCLR_OK;
 }
 

@@ -617,6 +617,7 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
 // which = 2: transpose read: LDS holds bf16 M[r][c] = in[r*64+c] for a [16][64] matrix; every lane
 //            issues lds_read_tr16_b64 at row 4*(lane>>5)... exactly like bwd_gemm2 (ks=0, dt=0, DC=64)
 //            out s16[64][8] = the B fragment each lane assembled.
+// which = 4: C = A(16x32 bf16) * B(32x16 bf16) with v_mfma_f32_16x16x32_bf16 -> out f32[16][16]
 // which = 3: the cross-lane exchanges of the symmetric forward: out f32[5][64] = lane_xor<1,2,7,15,16>(in[lane])
 __global__ void __launch_bounds__(64) selftest_kernel(int which, const void* in, void* out) {
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[64 * 64 * 2];
@@ -643,6 +644,20 @@ __global__ void __launch_bounds__(64) selftest_kernel(int which, const void* in,
         c = mfma_32x32x2_f32(A[l31 * 2 + half], B[half * 32 + l31], c);
         float* C = reinterpret_cast<float*>(out);
         for (int r = 0; r < 16; ++r) C[frag_row(r, half) * 32 + l31] = c[r];
+    } else if (which == 4) {
+        // C = A(16x32 bf16) * B(32x16 bf16) through the 16x16x32 fragment maps -> out f32[16][16]
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(in);
+        const bf16_t* B = A + 16 * 32;
+        const int i16 = lane & 15, g4 = lane >> 4;
+        struct { bf16_t e[8]; } ta, tb;
+        for (int j = 0; j < 8; ++j) {
+            ta.e[j] = A[i16 * 32 + 8 * g4 + j];
+            tb.e[j] = B[(8 * g4 + j) * 16 + i16];
+        }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = mfma_16x16x32_bf16(__builtin_bit_cast(bf16x8, ta), __builtin_bit_cast(bf16x8, tb), c);
+        float* C = reinterpret_cast<float*>(out);
+        for (int r = 0; r < 4; ++r) C[(4 * g4 + r) * 16 + i16] = c[r];
     } else if (which == 3) {
         // out f32[5][64]: lane_xor<1,2,7,15,16> of in[lane]
         const float v = reinterpret_cast<const float*>(in)[lane];

@@ -60,7 +60,8 @@ typedef struct crossclr_plan {
     /* derived by crossclr_make_plan */
     int bpad;       /* b rounded up to 128                                  */
     int Dpad;       /* D rounded up to what the selected kernels need       */
-    int fast_path;  /* 1: register-resident bf16 kernels, 0: generic tiled  */
+    int fast_path;  /* forward: 1 register-resident bf16 kernel, 0 generic tiled */
+    int fast_bwd;   /* backward: 0 generic tiled, 1 32-row-wave kernel, 2 16-row-wave kernel */
     int fwd_blocks; /* persistent thread blocks of the fast forward (0: generic grid) */
     int fwd_slots;  /* partial-sum slots one crossclr_forward launch owns */
     size_t fwd_ws_floats; /* floats in the forward workspace `part` (slots of two launches + column sums + flag) */

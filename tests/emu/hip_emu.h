@@ -145,6 +145,31 @@ inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     emu::wave_sync();
     return c;
 }
+// v_mfma_f32_16x16x32_bf16: A[i][k] in lane i + 16*(k/8), element k%8; B[k][j] in lane j + 16*(k/8), element k%8;
+// C[i][j] in lane j + 16*(i/4), register i%4.
+typedef __attribute__((ext_vector_type(4))) float f32x4_emu;
+inline f32x4_emu mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4_emu c) {
+    emu::WaveCtx& w = emu::my_wave();
+    const int lane = emu::my_lane();
+    struct AB { bf16x8 a, b; };
+    AB mine{a, b};
+    memcpy(w.slot[lane], &mine, sizeof(mine));
+    emu::wave_sync();
+    const int j = lane & 15, g4 = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g4 + r;
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) {
+            AB la, lb;
+            memcpy(&la, w.slot[i + 16 * (k >> 3)], sizeof(AB));
+            memcpy(&lb, w.slot[j + 16 * (k >> 3)], sizeof(AB));
+            s += (float)la.a[k & 7] * (float)lb.b[k & 7];
+        }
+        c[r] = s;
+    }
+    emu::wave_sync();
+    return c;
+}
 // v_mfma_f32_32x32x2_f32: A[i][k] in lane i + 32k, B[k][j] in lane j + 32k (k = 0, 1)
 inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     emu::WaveCtx& w = emu::my_wave();

@@ -46,6 +46,12 @@ def _check_all(device):
     for lane in range(64):
         half, n = lane >> 5, lane & 31
         assert list(o[lane]) == [(8 * half + e) * 64 + n for e in range(8)], f"transpose read, lane {lane}"
+    # (4) v_mfma_f32_16x16x32_bf16 (the 16-row backward)
+    a = torch.from_numpy(rng.standard_normal((16, 32)).astype(np.float32)).bfloat16()
+    b = torch.from_numpy(rng.standard_normal((32, 16)).astype(np.float32)).bfloat16()
+    inp = torch.cat([a.flatten(), b.flatten()]).view(torch.int16).numpy().copy()
+    c = _run(4, inp, 256, np.float32, device).reshape(16, 16)
+    assert np.abs(c - (a.float() @ b.float()).numpy()).max() <= 1e-5, "bf16 16x16x32 fragment layout differs"
     # (3) DPP / swizzle lane exchanges used by the symmetric forward's column-sum butterfly
     v = np.arange(64, dtype=np.float32) + 0.5
     o = _run(3, v, 5 * 64, np.float32, device).reshape(5, 64)

@@ -107,6 +107,20 @@ def test_symmetric_forward_upper_triangle(B, D, monkeypatch):
     assert abs(sym - full) <= 1e-6 * max(1.0, abs(full))
 
 
+@pytest.mark.parametrize("B,D", [(8, 16), (70, 48), (150, 100)])
+def test_bf16_16row_backward_matches_reference(B, D, monkeypatch):
+    """The 16-row-wavefront backward (v_mfma_f32_16x16x32_bf16; the default for 512 < D <= 1024) forced onto
+    small widths so the emulator can run it."""
+    monkeypatch.setenv("CROSSCLR_BWD_KERNEL", "16")
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).fast_bwd == 2
+    v, t = orc.make_inputs("randn", B, D, 3)
+    ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.8)
+    loss, gv, gt = run(v, t, 0.05, 0.8, "bf16")
+    scale = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+    assert (gv.double() - ref["grad_v"]).abs().max().item() <= 2e-2 * scale
+    assert (gt.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
+
+
 def test_ragged_batch_crossing_a_tile_boundary():
     # B = 70: one full 64-column tile + a ragged one in the fast path; a ragged 128 tile in the generic path
     v, t = orc.make_inputs("randn", 70, 24, 17)
@@ -153,7 +167,10 @@ def test_plan_geometry():
     p = nat.make_plan(100, 300, 8, 3, nat.MODE_FP32)
     assert (p.bpad, p.Dpad, p.fast_path, p.world, p.rank) == (128, 512, 0, 8, 3)
     p = nat.make_plan(100, 700, 1, 0, nat.MODE_BF16)
-    assert (p.Dpad, p.fast_path) == (768, 0)      # D > 512: bf16 falls back to the generic tiled kernels
+    assert (p.Dpad, p.fast_path, p.fast_bwd) == (768, 0, 2)   # 512 < D <= 1024: generic forward, 16-row-wave backward
+    p = nat.make_plan(100, 1500, 1, 0, nat.MODE_BF16)
+    assert (p.Dpad, p.fast_path, p.fast_bwd) == (1536, 0, 0)  # wider: generic tiled kernels
+    assert nat.make_plan(100, 512, 1, 0, nat.MODE_BF16).fast_bwd == 1 and nat.make_plan(100, 512, 1, 0, nat.MODE_FP32).fast_bwd == 0
     with pytest.raises(nat.CrossCLRNativeError):
         nat.make_plan(0, 16, 1, 0, nat.MODE_FP32)
     with pytest.raises(nat.CrossCLRNativeError):
