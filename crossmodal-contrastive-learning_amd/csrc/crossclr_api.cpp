@@ -56,9 +56,9 @@ extern "C" const char* crossclr_backend(void) {
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// forward workspace ("part") layout, in floats:  [2*fwd_slots slots][2*bpad] | colpart [2*bpad/256][2*bpad] | flag
+// forward workspace ("part") layout, in floats:  [2*fwd_slots slots][2*bpad] | colpart [<= 2*bpad/128 row blocks][2*bpad] | header
 static size_t ws_colpart_off(const crossclr_plan* p) { return (size_t)2 * p->fwd_slots * 2 * p->bpad; }
-static size_t ws_flag_off(const crossclr_plan* p) { return ws_colpart_off(p) + (size_t)(2 * p->bpad / 256 + 1) * 2 * p->bpad; }
+static size_t ws_flag_off(const crossclr_plan* p) { return ws_colpart_off(p) + (size_t)(2 * p->bpad / 128 + 1) * 2 * p->bpad; }
 
 static int device_zero(void* where, size_t bytes, void* stream) {
 #ifdef CROSSCLR_EMU
@@ -106,11 +106,10 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     plan->fast_bwd = 0;
 #ifndef CROSSCLR_NO_FAST
     if (mode == CROSSCLR_MODE_BF16 && !getenv("CROSSCLR_DISABLE_FAST")) {
-        if (plan->fast_path) plan->fast_bwd = CROSSCLR_DEFAULT_BWD_KERNEL;
-        else if (dpad == 768 || dpad == 1024) plan->fast_bwd = 2;
+        if (plan->fast_path) plan->fast_bwd = dpad <= 512 ? CROSSCLR_DEFAULT_BWD_KERNEL : 2;
         if (const char* e = getenv("CROSSCLR_BWD_KERNEL")) {  // tuning knob: 16 or 32
-            if (atoi(e) == 16 && (plan->fast_path || dpad == 768 || dpad == 1024)) plan->fast_bwd = 2;
-            if (atoi(e) == 32 && plan->fast_path) plan->fast_bwd = 1;
+            if (atoi(e) == 16 && plan->fast_path) plan->fast_bwd = 2;
+            if (atoi(e) == 32 && plan->fast_path && dpad <= 512) plan->fast_bwd = 1;
         }
     }
 #endif

@@ -101,6 +101,8 @@ static inline int fast_dpad(int D) {
     if (D <= 256) return 256;
     if (D <= 384) return 384;
     if (D <= 512) return 512;
+    if (D <= 768) return 768;
+    if (D <= 1024) return 1024;
     return 0;
 }
 
@@ -164,15 +166,16 @@ __device__ __forceinline__ int halving_elem16(int l31) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Work list of the persistent forward.  Row block I = 256 rows of the stacked operand; column tile
-// t = 32 columns.  kind 1 (symmetric: rows and columns are the same operand): row block I owns tiles
-// 8I .. NT-1;  kind 2 (rectangular): every row block owns all NC column tiles that are not in the
+// Work list of the persistent forward.  Row block I = 32*tpr rows of the stacked operand (tpr = 8: eight
+// waves per block, Dpad <= 512; tpr = 4: four waves, Dpad <= 1024); column tile t = 32 columns.
+// kind 1 (symmetric: rows and columns are the same operand): row block I owns tiles tpr*I .. NT-1;  kind 2 (rectangular): every row block owns all NC column tiles that are not in the
 // skipped rank.  The (I, t) pairs, row-block major, form a flat list of `total` items that is cut
 // into `nblk` equal contiguous ranges of `per` items -- one persistent thread block each.
 // A row block's partial row sums land in slot (block - first block touching that row block).
 // ---------------------------------------------------------------------------------------------
 struct FwdWork {
     int kind;   // 1 symmetric, 2 rectangular (0 in the workspace header = dense slots of the generic kernel)
+    int tpr;    // 32-column tiles per row block (= waves per thread block)
     int NB;     // row blocks
     int NT;     // symmetric: column tiles of the operand; rectangular: usable column tiles
     int per;    // items per thread block
@@ -180,14 +183,15 @@ struct FwdWork {
     int total;
 };
 __host__ __device__ __forceinline__ int fwd_prefix(const FwdWork& w, int rb) {  // items before row block rb
-    return w.kind == 1 ? rb * w.NT - 4 * rb * (rb - 1) : rb * w.NT;
+    return w.kind == 1 ? rb * w.NT - (w.tpr / 2) * rb * (rb - 1) : rb * w.NT;
 }
 __host__ __device__ __forceinline__ int fwd_first_block(const FwdWork& w, int rb) { return fwd_prefix(w, rb) / w.per; }
 __host__ __device__ __forceinline__ int fwd_last_block(const FwdWork& w, int rb) { return (fwd_prefix(w, rb + 1) - 1) / w.per; }
-static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, int max_blocks) {
+static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, int max_blocks, int tpr) {
     FwdWork w;
     w.kind = kind;
-    w.NB = 2 * bpad / 256;
+    w.tpr = tpr;
+    w.NB = 2 * bpad / (32 * tpr);
     w.NT = kind == 1 ? 2 * bpad / 32 : usable_col_tiles;
     w.total = fwd_prefix(w, w.NB);
     int nb = w.total / 2;                     // at least ~2 tiles per block
@@ -207,33 +211,35 @@ static inline int fwd_max_slots(const FwdWork& w) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward denominators, persistent: 8 waves x 32 rows per block (two waves per SIMD), 32-column tiles
-// in a 4-deep LDS-DMA ring that keeps running across row-block boundaries, counted s_waitcnt vmcnt(N),
-// one barrier per tile.  A block re-reads its row fragments only when its range of the work list
+// forward denominators, persistent: NW waves x 32 rows per block (NW = 8, two waves per SIMD, for Dpad <= 512;
+// NW = 4, one wave per SIMD with the 512-register budget, for Dpad <= 1024), 32-column tiles in a 4-deep
+// (2-deep when the tile is 48/64 KiB) LDS-DMA ring that keeps running across row-block boundaries, counted
+// s_waitcnt vmcnt(N), one barrier per tile.  A block re-reads its row fragments only when its range of the work list
 // crosses into the next row block.
 //  SYM: the stacked 2B x 2B matrix of exponentiated logits is symmetric, so only tiles at or right of
-//    a row block's own 256 columns are evaluated; a tile strictly right of the diagonal block also
-//    yields the COLUMN sums of its 32 columns over the block's 256 rows -- the row sums of the
+//    a row block's own columns are evaluated; a tile strictly right of the diagonal block also
+//    yields the COLUMN sums of its 32 columns over the block's rows -- the row sums of the
 //    mirrored tile that is never computed.  Column sums: per-wave halving_sum16 in registers, then
-//    the 8 waves' values meet in a 1 KiB LDS slot and are written by 32 threads one barrier later
+//    the waves' values meet in an LDS slot and are written by 32 threads one barrier later
 //    (the ring barrier of the next tile) to colpart[row block][column]: fixed order, no atomics,
 //    nothing to zero.
 // ---------------------------------------------------------------------------------------------
-template <int DK, bool SYM>
-__global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
+template <int DK, bool SYM, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
                                                           float* part, float* colpart, int* header) {
     constexpr int RB = DK * 32;            // bytes per operand row
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
-    constexpr int NST = 4;
-    constexpr int NOPS = DK / 8;           // DMA wave-instructions per tile per wave (8 waves)
-    constexpr int CS = 8 * QT * 4;         // one column-sum slot: [8 waves][32 columns] floats
+    constexpr int RPB = 32 * NW;           // rows per thread block
+    constexpr int NST = (4 * TILE + 4096 <= 160 * 1024) ? 4 : 2;
+    constexpr int NOPS = QT * RB / 1024 / NW;  // DMA wave-instructions per tile per wave
+    constexpr int CS = NW * QT * 4;        // one column-sum slot: [NW waves][32 columns] floats
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + (SYM ? 2 * CS : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     if (blockIdx.x == 0 && tid == 0) {  // tell crossclr_forward_finish how this launch laid out its slots
-        header[0] = wk.kind; header[1] = wk.NB; header[2] = wk.NT; header[3] = wk.per;
+        header[0] = wk.kind; header[1] = wk.tpr; header[2] = wk.NT; header[3] = wk.per;
     }
     const int per_rank = 2 * g.bpad / QT;
     const int skip_seg = (!SYM && g.skip_rank >= 0) ? g.skip_rank - g.col_rank0 : -1;
@@ -243,11 +249,11 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
     if (w_end > wk.total) w_end = wk.total;
     struct Cursor { int rb, j; };  // j = index inside the row block's tile list
     auto tile_of = [&](const Cursor& c) {
-        if (SYM) return 8 * c.rb + c.j;
+        if (SYM) return NW * c.rb + c.j;
         return (skip_seg >= 0 && c.j >= skip_seg * per_rank) ? c.j + per_rank : c.j;
     };
     auto advance = [&](Cursor& c) {
-        const int n = SYM ? wk.NT - 8 * c.rb : wk.NT;
+        const int n = SYM ? wk.NT - NW * c.rb : wk.NT;
         if (++c.j == n) { c.j = 0; ++c.rb; }
     };
     Cursor cur;
@@ -259,7 +265,7 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
     }
     const size_t pitch = RB;
     auto issue = [&](const Cursor& c, int stage) {
-        issue_tile_dma<RB, 8, QT>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tile_of(c), QT).row0 * pitch,
+        issue_tile_dma<RB, NW, QT>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tile_of(c), QT).row0 * pitch,
                                   lds + stage * TILE, wave, lane, nullptr, nullptr);
     };
     auto wait_keep = [&](int tiles_in_flight) {
@@ -277,21 +283,21 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
     int ptile = 0, pbuf = 0, prb = 0;
     auto flush = [&]() {
         if (tid < QT) {
-            const float* c = cs + pbuf * (8 * QT);
+            const float* c = cs + pbuf * (NW * QT);
             float sum = c[tid];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) sum += c[k * QT + tid];
+            for (int k = 1; k < NW; ++k) sum += c[k * QT + tid];
             colpart[(size_t)prb * 2 * g.bpad + QT * ptile + tid] = sum;
         }
     };
-    // ring: item w being consumed, w+1 and w+2 in flight
-    Cursor c1 = cur, c2, c3;
-    advance(c1);
-    c2 = c1; advance(c2);
-    c3 = c2; advance(c3);
-    if (w < w_end) issue(cur, 0);
-    if (w + 1 < w_end) issue(c1, 1);
-    if (w + 2 < w_end) issue(c2, 2);
+    // ring: cq[0] = item w being consumed, cq[1..NST-2] in flight, cq[NST-1] issued after the next barrier
+    Cursor cq[NST];
+    cq[0] = cur;
+#pragma unroll
+    for (int k = 1; k < NST; ++k) { cq[k] = cq[k - 1]; advance(cq[k]); }
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k)
+        if (w + k < w_end) issue(cq[k], k);
     int stage = 0;
     int my_rb = -1, row0w = 0, rmod = 0, r_in_mod = 0;
     float rowacc = 0.f;
@@ -301,11 +307,11 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
         if (half == 0) part[(size_t)(blockIdx.x - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + l31] = v;
     };
     while (w < w_end) {
-        if (cur.rb != my_rb) {  // (re)load this wave's 32 rows as MFMA B fragments
+        if (cq[0].rb != my_rb) {  // (re)load this wave's 32 rows as MFMA B fragments
             if (my_rb >= 0) store_rows();
-            my_rb = cur.rb;
+            my_rb = cq[0].rb;
             rowacc = 0.f;
-            row0w = my_rb * 256 + 32 * wave;
+            row0w = my_rb * RPB + 32 * wave;
             rmod = row0w / g.bpad;
             r_in_mod = row0w - rmod * g.bpad + l31;
             if (CROSSCLR_FABL & 16) {
@@ -320,11 +326,14 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
                 for (int ks = 0; ks < DK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
             }
         }
-        const int t = tile_of(cur);
+        const int t = tile_of(cq[0]);
         if (!(CROSSCLR_FABL & 4)) {
-            wait_keep((w + 1 < w_end) + (w + 2 < w_end));
+            int inflight = 0;
+#pragma unroll
+            for (int k = 1; k < NST - 1; ++k) inflight += (w + k < w_end);
+            wait_keep(inflight);
             __syncthreads();  // item w landed everywhere; every wave is done with item w-1's stage
-            if (w + 3 < w_end) issue(c3, (stage + 3) & (NST - 1));
+            if (w + NST - 1 < w_end) issue(cq[NST - 1], (stage + NST - 1) % NST);
         }
         if (SYM && pending) { flush(); pending = false; }
         const ColTile ct = col_tile(g, t, QT);
@@ -371,7 +380,7 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
             for (int r = 0; r < 16; ++r)
                 if (frag_row(r, half) == l31) acc[r] = ninf;
         }
-        const bool upper = SYM && t >= 8 * (my_rb + 1);  // strictly right of the diagonal block
+        const bool upper = SYM && t >= NW * (my_rb + 1);  // strictly right of the diagonal block
         if (upper && (r_in_mod - l31) + 32 > g.b) {      // padding ROWS must not reach the column sums
             if (r_in_mod >= g.b) {
 #pragma unroll
@@ -387,15 +396,16 @@ __global__ void __launch_bounds__(512, 2) fast_fwd_kernel(const bf16_t* rows, co
         if (upper) {
             const float colsum = (CROSSCLR_FABL & 8) ? e[l31 & 15] : halving_sum16(e, l31);
             pbuf ^= 1;
-            if (l31 < 16) cs[pbuf * (8 * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
+            if (l31 < 16) cs[pbuf * (NW * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
             pending = true;
             ptile = t;
             prb = my_rb;
         }
-        stage = (stage + 1) & (NST - 1);
+        stage = (stage + 1) % NST;
         ++w;
-        cur = c1; c1 = c2; c2 = c3;
-        advance(c3);
+#pragma unroll
+        for (int k = 0; k < NST - 1; ++k) cq[k] = cq[k + 1];
+        advance(cq[NST - 1]);
     }
     if (SYM) {
         __syncthreads();
@@ -801,9 +811,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
     hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 #endif
 
+static inline int fast_fwd_tpr(int Dpad) { return Dpad <= 512 ? 8 : 4; }   // waves per block = 32-column tiles per row block
+
 static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, int skip_rank, bool symmetric) {
     const int usable = (col_ranks - (skip_rank >= 0 ? 1 : 0)) * (2 * p->bpad / 32);
-    return fwd_make_work(symmetric ? 1 : 2, p->bpad, usable, p->fwd_blocks);
+    return fwd_make_work(symmetric ? 1 : 2, p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
 }
 
 static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
@@ -813,24 +825,22 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     if (wk.total <= 0) return CROSSCLR_OK;
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
-    dim3 block(512), grid(wk.nblk);
-    if (symmetric) {
-        switch (p->Dpad) {
-            case 128: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<8, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-            case 256: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<16, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-            case 384: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<24, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-            case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32, true>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-            default: return CROSSCLR_E_ARG;
-        }
-        return CROSSCLR_OK;
-    }
+    dim3 grid(wk.nblk);
+#define CROSSCLR_LF(DK, NW)                                                                                                   \
+    do {                                                                                                                       \
+        if (symmetric) CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, true, NW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, false, NW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header);         \
+    } while (0)
     switch (p->Dpad) {
-        case 128: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<8, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-        case 256: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<16, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-        case 384: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<24, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
-        case 512: CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<32, false>), grid, block, stream, r, c, g, wk, part, colpart, header); break;
+        case 128: CROSSCLR_LF(8, 8); break;
+        case 256: CROSSCLR_LF(16, 8); break;
+        case 384: CROSSCLR_LF(24, 8); break;
+        case 512: CROSSCLR_LF(32, 8); break;
+        case 768: CROSSCLR_LF(48, 4); break;
+        case 1024: CROSSCLR_LF(64, 4); break;
         default: return CROSSCLR_E_ARG;
     }
+#undef CROSSCLR_LF
     return CROSSCLR_OK;
 }
 

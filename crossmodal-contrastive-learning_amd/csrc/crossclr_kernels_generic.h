@@ -272,11 +272,14 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
 //   Two launches: rows in parallel (each block leaves its partial loss sum in loss_ws[1 + block]),
 //   then one wave adds the block partials in index order -> deterministic, no atomics, no memset.
 // ---------------------------------------------------------------------------------------------
-// header[4*L .. 4*L+3] of launch L (written by the forward launch itself): {kind, NB, NT, per}.
+// header[4*L .. 4*L+3] of launch L (written by the forward launch itself): {kind, tpr, NT, per}
+// (tpr = 32-column tiles = 32-row groups per row block: row block I = p / (32*tpr)).
 //   kind 0: dense -- all `slots_per_launch` slots of the launch are valid for every row
-//   kind 1/2: persistent fast forward (symmetric / rectangular): row block I = p >> 8 owns slots
+//   kind 1/2: persistent fast forward (symmetric / rectangular): row block I owns slots
 //             0 .. last_block(I) - first_block(I); kind 1 additionally has column sums colpart[I' < I][p]
-__device__ __forceinline__ int fin_prefix(int kind, int NT, int rb) { return kind == 1 ? rb * NT - 4 * rb * (rb - 1) : rb * NT; }
+__device__ __forceinline__ int fin_prefix(int kind, int tpr, int NT, int rb) {
+    return kind == 1 ? rb * NT - (tpr / 2) * rb * (rb - 1) : rb * NT;
+}
 __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nlaunch, int slots_per_launch, Geo g,
                                                          const float* diag_cos, float inv_tau, float neg_w, float* logz,
                                                          float* rz, float* wrz, double* loss_ws, const float* colpart,
@@ -290,12 +293,12 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
         const int mod = p / g.bpad, i = p - mod * g.bpad;
         double s = self_term;
         for (int L = 0; L < nlaunch; ++L) {
-            const int kind = header[4 * L], NT = header[4 * L + 2], per = header[4 * L + 3];
+            const int kind = header[4 * L], tpr = header[4 * L + 1], NT = header[4 * L + 2], per = header[4 * L + 3];
             const float* base = part + (size_t)L * slots_per_launch * n;
             int count = slots_per_launch;
             if (kind != 0) {
-                const int rb = p >> 8;
-                count = (fin_prefix(kind, NT, rb + 1) - 1) / per - fin_prefix(kind, NT, rb) / per + 1;
+                const int rb = p / (32 * tpr);
+                count = (fin_prefix(kind, tpr, NT, rb + 1) - 1) / per - fin_prefix(kind, tpr, NT, rb) / per + 1;
                 if (kind == 1)
                     for (int k = 0; k < rb; ++k) s += (double)colpart[(size_t)k * n + p];
             }

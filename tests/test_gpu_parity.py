@@ -300,8 +300,8 @@ def test_sharded_host_path_with_real_collectives_on_one_gpu(monkeypatch):
     (1536, 256, "bf16"),    # DK=16; bpad = 1536 (6 row blocks of 256)
     (1300, 384, "bf16"),    # DK=24 (48 KiB tiles), ragged, row block straddling the modality boundary
     (2048, 512, "bf16"),    # DK=32
-    (640, 600, "bf16"),     # 512 < D <= 768: generic forward + 16-row-wave backward, Dpad = 768
-    (512, 1024, "bf16"),    # BASELINE config 5's embedding width: generic forward + 16-row-wave backward
+    (640, 600, "bf16"),     # 512 < D <= 768: 4-wave persistent forward + 16-row-wave backward, Dpad = 768
+    (512, 1024, "bf16"),    # BASELINE config 5's embedding width: 4-wave persistent forward + 16-row-wave backward
     (2048, 768, "bf16"),    # the common ViT-L / BERT width
     (300, 1100, "bf16"),    # D > 1024: generic tiled bf16 kernels end to end (Dpad = 1280)
     (777, 200, "fp32"),     # generic fp32, Dpad = 256

@@ -167,7 +167,7 @@ def test_plan_geometry():
     p = nat.make_plan(100, 300, 8, 3, nat.MODE_FP32)
     assert (p.bpad, p.Dpad, p.fast_path, p.world, p.rank) == (128, 512, 0, 8, 3)
     p = nat.make_plan(100, 700, 1, 0, nat.MODE_BF16)
-    assert (p.Dpad, p.fast_path, p.fast_bwd) == (768, 0, 2)   # 512 < D <= 1024: generic forward, 16-row-wave backward
+    assert (p.Dpad, p.fast_path, p.fast_bwd) == (768, 1, 2)   # 512 < D <= 1024: 4-wave forward, 16-row-wave backward
     p = nat.make_plan(100, 1500, 1, 0, nat.MODE_BF16)
     assert (p.Dpad, p.fast_path, p.fast_bwd) == (1536, 0, 0)  # wider: generic tiled kernels
     assert nat.make_plan(100, 512, 1, 0, nat.MODE_BF16).fast_bwd == 1 and nat.make_plan(100, 512, 1, 0, nat.MODE_FP32).fast_bwd == 0
