@@ -333,3 +333,35 @@ def test_input_dtypes_on_the_fast_path(dtype):
     scale = ref["grad_v"].abs().max().item()
     out_eps = {torch.float16: 1e-3, torch.bfloat16: 8e-3, torch.float64: 0.0}[dtype]  # rounding of the stored gradient
     assert (gv.double().cpu() - ref["grad_v"]).abs().max().item() <= (1e-2 + out_eps) * scale
+
+
+def test_global_batch_scale_on_one_gpu():
+    """B = 32768 (half of BASELINE's 8-GPU global batch) on one GPU: index arithmetic, workspace sizes and
+    finiteness at scale.  The CPU oracle would take minutes here, so the checker is an independent blocked
+    evaluation with stock torch ops on the device (fp32 GEMMs, fp64 logsumexp) -- the closed form of
+    SURVEY.md 3.4, not the kernels under test."""
+    B, D = 32768, 512
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    v = torch.randn(B, D, device="cuda", generator=gen).requires_grad_(True)
+    t = torch.randn(B, D, device="cuda", generator=gen).requires_grad_(True)
+    loss = crossclr_amd.crossclr_loss(v, t, 0.03, 0.8, compute_mode="bf16")
+    loss.backward()
+    assert torch.isfinite(v.grad).all() and torch.isfinite(t.grad).all()
+    with torch.no_grad():
+        vh = torch.nn.functional.normalize(v.detach(), dim=1)
+        th = torch.nn.functional.normalize(t.detach(), dim=1)
+        tot = torch.zeros((), dtype=torch.float64, device="cuda")
+        blk = 2048
+        rr = torch.arange(blk, device="cuda")
+        for r0 in range(0, B, blk):
+            idx = torch.arange(r0, r0 + blk, device="cuda")
+            for own, oth in ((vh, th), (th, vh)):
+                a = (own[r0:r0 + blk] @ oth.t()).double() / 0.03
+                c = (own[r0:r0 + blk] @ own.t()).double() * (0.8 / 0.03)
+                c[rr, idx] = 0.0
+                tot += torch.logsumexp(torch.cat([a, c], 1), 1).sum()
+        ref = (tot - 2 * (vh * th).sum(1).double().sum() / 0.03) / (2 * B)
+    assert abs(loss.item() - ref.item()) <= 1e-4
+    # the normalise-backward leaves every gradient row orthogonal to its input row
+    radial = (v.grad.double() * v.detach().double()).sum(1).abs().max().item()
+    assert radial <= 1e-3 * v.grad.double().norm(dim=1).max().item() * v.detach().double().norm(dim=1).max().item()
