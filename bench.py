@@ -77,7 +77,14 @@ def cpu_baseline(b, d):
         if time.perf_counter() - budget_t0 > 25 and i >= 1:
             break
     best = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": bb * bb / best, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model,
             "samples_per_s": bb / best, "seconds_per_step": best, "host_cpus": os.cpu_count(),
             "loss": float(loss),
             "sample": f"oracle.eager_loss_and_grads (op-for-op reference restatement) fwd+bwd, fp32 inputs, "
