@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--rows", type=int, default=B_PER_GPU, help="rows per GPU (default = BASELINE config)")
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--influential", action="store_true",
+                    help="BASELINE config 5: influential-sample pruning + loss weighting from synthetic input-space "
+                         "features (crossclr_amd.CrossCLR); not the default workload")
     args = ap.parse_args()
 
     # RCCL prints a version banner on the C-level stdout of every rank.  Keep this process's stdout to
@@ -134,12 +137,18 @@ def main():
     v, t = orc.make_inputs("randn", b, d, 1234 + rank)
     v = v.to(dev).requires_grad_(True)
     t = t.to(dev).requires_grad_(True)
-    crit = crossclr_amd.CrossCLR_onlyIntraModality(TAU, NEG_W, compute_mode=args.mode, process_group=group).to(dev)
+    if args.influential:
+        # input-space features: 16 clusters + noise (so that connectivities differ and the threshold prunes a part)
+        xv, xt = orc.make_inputs("cluster", b, 256, 4321 + rank)
+        xv, xt = xv.to(dev), xt.to(dev)
+        crit = crossclr_amd.CrossCLR(TAU, 0.0035, NEG_W, 0.9, compute_mode=args.mode, process_group=group).to(dev)
+    else:
+        crit = crossclr_amd.CrossCLR_onlyIntraModality(TAU, NEG_W, compute_mode=args.mode, process_group=group).to(dev)
 
     def step():
         v.grad = None
         t.grad = None
-        loss = crit(v, t)
+        loss = crit(v, t, xv, xt) if args.influential else crit(v, t)   # the O(B D) weight recipe is inside the step
         loss.backward()
         return loss
 
@@ -171,7 +180,9 @@ def main():
         return
 
     # ---- per-kernel HIP-event timing of the single-GPU stages (roofline of the dominant kernel) ----
-    st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, args.mode, iters=10, warmup=2)
+    sw = crossclr_amd.influential_sample_weights(xv, xt, 0.9, 0.0035) if args.influential else (None, None)
+    st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, args.mode, iters=10, warmup=2,
+                              negative_scale=sw[0], loss_weight=sw[1])
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
     # algorithmic flops per launch: forward 6*b*b*D, backward 8*b*b*D for the local block
     alg = {"forward": 6.0 * b * b * d, "backward": 8.0 * b * b * d}
@@ -183,7 +194,8 @@ def main():
             kernels[k].update(algorithmic_tflops=round(tf, 2), frac=round(tf / peak, 4))
     dom = "backward"
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
-    traffic = measured_traffic(b, d, args.mode, "fast_bwd_kernel" if st["fast_path"] else "bwd_kernel") if world == 1 else None
+    traffic = (measured_traffic(b, d, args.mode, "fast_bwd_kernel" if st["fast_path"] else "bwd_kernel")
+               if world == 1 and not args.influential else None)
     step_tf = 14.0 * b * B * d / t_step / 1e12  # per-GPU algorithmic fwd+bwd flops over the whole step
     out = {
         "metric": "contrastive-pairs/sec (fwd+bwd)", "value": B * B / t_step, "unit": "pairs/s",
@@ -191,7 +203,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
         "samples_per_s": B / t_step,
-        "config": {"workload": f"CrossCLR_onlyIntraModality fwd+bwd, b={b} rows/GPU, global B={B}, D={d}, "
+        "config": {"workload": ("CrossCLR (influential-sample pruning + weighting) " if args.influential else "CrossCLR_onlyIntraModality ") +
+                               f"fwd+bwd, b={b} rows/GPU, global B={B}, D={d}, "
                                f"tau={TAU}, negative_weight={NEG_W}, {args.mode} operands / fp32 accumulate, "
                                "randn features seed 1234+rank",
                    "global_batch": B, "rows_per_gpu": b, "dim": d,
@@ -208,7 +221,9 @@ def main():
                      "whole_step_frac": round(step_tf / peak, 4)},
         "kernels": kernels,
     }
-    if world == 1 and b == B_PER_GPU and d == DIM:
+    if args.influential:
+        out["config"]["pruned_fraction"] = [round(1.0 - float(k.mean()), 4) for k in sw[0]]
+    if world == 1 and b == B_PER_GPU and d == DIM and not args.influential:
         out["loss_delta_vs_reference"] = abs(loss_val - GOLDEN_LOSS_B8192_SEED1234)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(b, d)

@@ -9,5 +9,7 @@ through the `crossclr_amd` alias module at the repository root:
 """
 from . import _native
 from .loss import AUTO_BF16_MIN_GLOBAL_BATCH, CrossCLR_onlyIntraModality, crossclr_loss
+from .influence import CrossCLR, influential_sample_weights
 
-__all__ = ["CrossCLR_onlyIntraModality", "crossclr_loss", "AUTO_BF16_MIN_GLOBAL_BATCH", "_native"]
+__all__ = ["CrossCLR_onlyIntraModality", "CrossCLR", "crossclr_loss", "influential_sample_weights",
+           "AUTO_BF16_MIN_GLOBAL_BATCH", "_native"]

@@ -19,6 +19,7 @@ HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcro
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
+ABI_VERSION = 2
 
 
 class Plan(ctypes.Structure):
@@ -29,6 +30,11 @@ class Plan(ctypes.Structure):
                 ("bwd_slices", ctypes.c_int),
                 ("loss_ws_doubles", ctypes.c_int),
                 ("operand_bytes", ctypes.c_size_t), ("gbuf_bytes", ctypes.c_size_t)]
+
+
+class SampleWeights(ctypes.Structure):
+    """crossclr_sample_weights: device pointers (0 = all ones)."""
+    _fields_ = [("neg_scale_rows", ctypes.c_void_p), ("neg_scale_cols", ctypes.c_void_p), ("loss_weight", ctypes.c_void_p)]
 
 
 class CrossCLRNativeError(RuntimeError):
@@ -53,7 +59,24 @@ _SIGNATURES = {
                                                 ctypes.c_int, _P, ctypes.c_float, _P, _P, _P, ctypes.c_long,
                                                 ctypes.c_long, _P]),
     "crossclr_selftest": (ctypes.c_int, [ctypes.c_int, _P, _P, _P]),
+    # ABI version 2: the same four entry points with per-sample weights
+    "crossclr_forward_w": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_float, ctypes.c_float, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    "crossclr_forward_finish_w": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_int, _P, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.POINTER(SampleWeights), _P, _P, _P, _P, _P]),
+    "crossclr_backward_w": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights),
+                                           _P, ctypes.c_int, _P]),
+    "crossclr_backward_finish_w": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long,
+                                                  ctypes.c_int, _P, ctypes.c_float, ctypes.POINTER(SampleWeights), _P, _P, _P,
+                                                  ctypes.c_long, ctypes.c_long, _P]),
+    "crossclr_influence_colsum": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 _P, _P, _P, _P]),
+    "crossclr_influence_conn": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               _P, _P, ctypes.c_int, _P, _P]),
+    "crossclr_influence_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_float, ctypes.c_float, _P, _P, _P]),
 }
+INFL_BLOCKS = 256
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib: Optional[ctypes.CDLL] = None
@@ -66,8 +89,8 @@ def _bind(path: str) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI
         fn.restype = res
         fn.argtypes = args
-    if lib.crossclr_abi_version() != 1:
-        raise CrossCLRNativeError(f"{path}: ABI version {lib.crossclr_abi_version()} != 1")
+    if lib.crossclr_abi_version() != ABI_VERSION:
+        raise CrossCLRNativeError(f"{path}: ABI version {lib.crossclr_abi_version()} != {ABI_VERSION}")
     return lib
 
 

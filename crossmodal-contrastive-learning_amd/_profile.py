@@ -14,11 +14,13 @@ from . import loss as L
 
 
 def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
-                compute_mode: str, iters: int = 10, warmup: int = 2) -> Dict[str, float]:
+                compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None
+                ) -> Dict[str, float]:
     """Average milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
-    backward, backward_finish)."""
+    backward, backward_finish); with sample weights the `_w` entry points are the ones timed."""
     lib = nat.library()
-    _, ws = L._forward_impl(video, text, temperature, negative_w, compute_mode, None)
+    _, ws = L._forward_impl(video, text, temperature, negative_w, compute_mode, None, negative_scale, loss_weight)
+    sw_k, sw_all, sw_lw = L._sw(ws.k_rows, ws.k_rows, None), L._sw(ws.k_rows, ws.k_rows, ws.lw), L._sw(None, None, ws.lw)
     plan, pp = ws.plan, ctypes.byref(ws.plan)
     dev = video.device
     p = L._ptr
@@ -32,14 +34,14 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
     stages = {
         "normalize": lambda: lib.crossclr_normalize(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
                                                     p(ws.xhat), p(ws.inv_norm), p(ws.diag), stream),
-        "forward": lambda: lib.crossclr_forward(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(part), 0, stream),
-        "forward_finish": lambda: lib.crossclr_forward_finish(pp, p(part), plan.fwd_slots, p(ws.diag), t, w, p(ws.logz),
-                                                              p(ws.rz), p(ws.wrz), p(ws.loss_sum), stream),
-        "backward": lambda: lib.crossclr_backward(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(ws.rz), p(ws.wrz),
-                                                  p(ws.rz), p(ws.wrz), p(gbuf), 0, stream),
-        "backward_finish": lambda: lib.crossclr_backward_finish(pp, p(gbuf), p(video), p(text), video.stride(0),
-                                                                text.stride(0), ws.in_dtype, p(ws.inv_norm), t, p(go),
-                                                                p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
+        "forward": lambda: lib.crossclr_forward_w(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, sw_k, p(part), 0, stream),
+        "forward_finish": lambda: lib.crossclr_forward_finish_w(pp, p(part), plan.fwd_slots, p(ws.diag), t, w, sw_all,
+                                                                p(ws.logz), p(ws.rz), p(ws.wrz), p(ws.loss_sum), stream),
+        "backward": lambda: lib.crossclr_backward_w(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(ws.rz), p(ws.wrz),
+                                                    p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream),
+        "backward_finish": lambda: lib.crossclr_backward_finish_w(pp, p(gbuf), p(video), p(text), video.stride(0),
+                                                                  text.stride(0), ws.in_dtype, p(ws.inv_norm), t, sw_lw,
+                                                                  p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
     }
     out = {}
     for name, fn in stages.items():

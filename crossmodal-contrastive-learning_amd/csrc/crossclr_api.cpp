@@ -229,10 +229,29 @@ extern "C" int crossclr_normalize(const crossclr_plan* plan, const void* video, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// sample weights: both k arrays or neither (a missing struct / NULL arrays = all ones = the reference's loss)
+static int unpack_k(const crossclr_sample_weights* sw, const float** krows, const float** kcols) {
+    *krows = sw ? sw->neg_scale_rows : nullptr;
+    *kcols = sw ? sw->neg_scale_cols : nullptr;
+    if ((*krows == nullptr) != (*kcols == nullptr))
+        return fail(CROSSCLR_E_ARG, "neg_scale_rows and neg_scale_cols must be given together");
+    return CROSSCLR_OK;
+}
+
 extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
                                 int col_ranks, int col_rank0, int skip_rank, float temperature,
                                 float negative_weight, float* part, int slot0, void* stream) {
+    return crossclr_forward_w(plan, xhat_rows, xhat_cols, col_ranks, col_rank0, skip_rank, temperature, negative_weight,
+                              nullptr, part, slot0, stream);
+}
+
+extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                                  int col_ranks, int col_rank0, int skip_rank, float temperature,
+                                  float negative_weight, const crossclr_sample_weights* sw, float* part, int slot0,
+                                  void* stream) {
     if (!plan || !xhat_rows || !xhat_cols || !part || slot0 < 0) return fail(CROSSCLR_E_ARG, "NULL/negative argument");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
     Geo g;
     int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
     if (rc) return rc;
@@ -252,7 +271,7 @@ extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows
             if (rc) return rc;
             return device_zero(out, (size_t)plan->fwd_slots * 2 * plan->bpad * sizeof(float), stream);
         }
-        rc = fast_forward(plan, g, xhat_rows, xhat_cols, out, part + ws_colpart_off(plan), header, symmetric, stream);
+        rc = fast_forward(plan, g, xhat_rows, xhat_cols, out, part + ws_colpart_off(plan), header, symmetric, krows, kcols, stream);
         return rc ? fail(rc, "fast_forward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_fwd_kernel");
     }
 #endif
@@ -262,16 +281,27 @@ extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows
     const int nsplit = plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     dim3 grid(2 * plan->bpad / 128, nsplit), block(256);
-    if (plan->mode == CROSSCLR_MODE_FP32)
-        LAUNCH((fwd_sums_kernel<float>), grid, block, stream, (const float*)xhat_rows, (const float*)xhat_cols, g, tps, out);
-    else
-        LAUNCH((fwd_sums_kernel<bf16_t>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out);
+    if (plan->mode == CROSSCLR_MODE_FP32) {
+        if (kcols) LAUNCH((fwd_sums_kernel<float, true>), grid, block, stream, (const float*)xhat_rows, (const float*)xhat_cols, g, tps, out, kcols);
+        else LAUNCH((fwd_sums_kernel<float, false>), grid, block, stream, (const float*)xhat_rows, (const float*)xhat_cols, g, tps, out, kcols);
+    } else {
+        if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out, kcols);
+        else LAUNCH((fwd_sums_kernel<bf16_t, false>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out, kcols);
+    }
     return launch_status("fwd_sums_kernel");
 }
 
 extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int nslots,
                                        const float* diag_cos, float temperature, float negative_weight,
                                        float* logz, float* rz, float* wrz, double* loss_sum, void* stream) {
+    return crossclr_forward_finish_w(plan, part, nslots, diag_cos, temperature, negative_weight, nullptr, logz, rz, wrz,
+                                     loss_sum, stream);
+}
+
+extern "C" int crossclr_forward_finish_w(const crossclr_plan* plan, const float* part, int nslots,
+                                         const float* diag_cos, float temperature, float negative_weight,
+                                         const crossclr_sample_weights* sw, float* logz, float* rz, float* wrz,
+                                         double* loss_sum, void* stream) {
     if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum ||
         (nslots != plan->fwd_slots && nslots != 2 * plan->fwd_slots))
         return fail(CROSSCLR_E_ARG, "NULL argument / nslots must be fwd_slots (one launch) or 2*fwd_slots (two)");
@@ -282,7 +312,8 @@ extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* p
     const int nlaunch = nslots / plan->fwd_slots;
     LAUNCH(fwd_finish_kernel, dim3(nb), dim3(256), stream, part, nlaunch, plan->fwd_slots, g, diag_cos, 1.0f / temperature,
            negative_weight, logz, rz, wrz, loss_sum, part + ws_colpart_off(plan),
-           reinterpret_cast<const int*>(part + ws_flag_off(plan)));
+           reinterpret_cast<const int*>(part + ws_flag_off(plan)), sw ? sw->neg_scale_rows : nullptr,
+           sw ? sw->loss_weight : nullptr);
     LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb);
     return launch_status("fwd_finish_kernel");
 }
@@ -291,22 +322,24 @@ extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* p
 template <typename T>
 static int backward_generic(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                             const float* rz_rows, const float* wrz_rows, const float* rz_cols,
-                            const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
+                            const float* wrz_cols, float* gbuf, int accumulate, const float* krows, const float* kcols,
+                            void* stream) {
     dim3 block(256);
     const int rb = 2 * p->bpad / 64;
     const int ntiles = g.col_ranks * 2 * p->bpad / 64;
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     const unsigned nz = (unsigned)p->bwd_slices;
-    if (p->Dpad % 256 == 0) {
-        LAUNCH((bwd_kernel<T, 256>), dim3(rb, p->Dpad / 256, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
-               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps);
-    } else if (p->Dpad % 128 == 0) {
-        LAUNCH((bwd_kernel<T, 128>), dim3(rb, p->Dpad / 128, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
-               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps);
-    } else {
-        LAUNCH((bwd_kernel<T, 64>), dim3(rb, p->Dpad / 64, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,
-               wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps);
-    }
+#define CROSSCLR_LB(DC)                                                                                                       \
+    do {                                                                                                                       \
+        if (krows) LAUNCH((bwd_kernel<T, DC, true>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows, \
+                          wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols);                                  \
+        else LAUNCH((bwd_kernel<T, DC, false>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,     \
+                    wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols);                                        \
+    } while (0)
+    if (p->Dpad % 256 == 0) CROSSCLR_LB(256);
+    else if (p->Dpad % 128 == 0) CROSSCLR_LB(128);
+    else CROSSCLR_LB(64);
+#undef CROSSCLR_LB
     return launch_status("bwd_kernel");
 }
 
@@ -315,33 +348,44 @@ extern "C" int crossclr_backward(const crossclr_plan* plan, const void* xhat_row
                                  float negative_weight, const float* rz_rows, const float* wrz_rows,
                                  const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
                                  void* stream) {
+    return crossclr_backward_w(plan, xhat_rows, xhat_cols, col_ranks, col_rank0, skip_rank, temperature, negative_weight,
+                               rz_rows, wrz_rows, rz_cols, wrz_cols, nullptr, gbuf, accumulate, stream);
+}
+
+extern "C" int crossclr_backward_w(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                                   int col_ranks, int col_rank0, int skip_rank, float temperature,
+                                   float negative_weight, const float* rz_rows, const float* wrz_rows,
+                                   const float* rz_cols, const float* wrz_cols, const crossclr_sample_weights* sw,
+                                   float* gbuf, int accumulate, void* stream) {
     if (!plan || !xhat_rows || !xhat_cols || !rz_rows || !wrz_rows || !rz_cols || !wrz_cols || !gbuf)
         return fail(CROSSCLR_E_ARG, "NULL argument");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
     Geo g;
     int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
     if (rc) return rc;
 #ifndef CROSSCLR_NO_FAST
     if (plan->fast_bwd) {
         rc = plan->fast_bwd == 2
-                 ? fast_backward16(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream)
-                 : fast_backward(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+                 ? fast_backward16(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, stream)
+                 : fast_backward(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, stream);
         return rc ? fail(rc, "fast backward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_kernel");
     }
 #endif
     if (plan->mode == CROSSCLR_MODE_FP32)
-        return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
-    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, stream);
+        return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, stream);
+    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, stream);
 }
 
 template <typename TIN>
 static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const void* v, const void* t, long ldv, long ldt,
                              const float* inv_norm, float temperature, const double* grad_out, void* gv, void* gt,
-                             long ldgv, long ldgt, void* stream) {
+                             long ldgv, long ldgt, const float* lw, void* stream) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((2 * p->b + 3) / 4), block(256);
     LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,
-           1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt);
+           1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw);
     return launch_status("bwd_finish_kernel");
 }
 
@@ -350,16 +394,92 @@ extern "C" int crossclr_backward_finish(const crossclr_plan* plan, const float* 
                                         const float* inv_norm, float temperature, const double* grad_out,
                                         void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext,
                                         void* stream) {
+    return crossclr_backward_finish_w(plan, gbuf, video, text, ld_video, ld_text, in_dtype, inv_norm, temperature, nullptr,
+                                      grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
+}
+
+extern "C" int crossclr_backward_finish_w(const crossclr_plan* plan, const float* gbuf, const void* video,
+                                          const void* text, long ld_video, long ld_text, int in_dtype,
+                                          const float* inv_norm, float temperature, const crossclr_sample_weights* sw,
+                                          const double* grad_out, void* grad_video, void* grad_text, long ld_gvideo,
+                                          long ld_gtext, void* stream) {
+    const float* lw = sw ? sw->loss_weight : nullptr;
     if (!plan || !gbuf || !video || !text || !inv_norm || !grad_out || !grad_video || !grad_text)
         return fail(CROSSCLR_E_ARG, "NULL argument");
     if (!(temperature > 0.f)) return fail(CROSSCLR_E_ARG, "temperature must be > 0");
     switch (in_dtype) {
-        case CROSSCLR_IN_F32: return backward_finish_t<float>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
-        case CROSSCLR_IN_F64: return backward_finish_t<double>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
-        case CROSSCLR_IN_F16: return backward_finish_t<in_f16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
-        case CROSSCLR_IN_BF16: return backward_finish_t<in_bf16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, stream);
+        case CROSSCLR_IN_F32: return backward_finish_t<float>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
+        case CROSSCLR_IN_F64: return backward_finish_t<double>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
+        case CROSSCLR_IN_F16: return backward_finish_t<in_f16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
+        case CROSSCLR_IN_BF16: return backward_finish_t<in_bf16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
     }
     return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+// ------------------------------------------------------------------------------------------------
+// influential-sample statistics
+template <typename TIN>
+static int infl_colsum_t(const void* xv, const void* xt, long ldv, long ldt, int b, int Din, float* inv_norm, float* partial,
+                         double* colsum, void* stream) {
+#define CROSSCLR_LI(KC) LAUNCH((infl_colsum_kernel<TIN, KC>), dim3(kInflBlocks, 2), dim3(256), stream, (const TIN*)xv, (const TIN*)xt, ldv, ldt, b, Din, inv_norm, partial)
+    if (Din <= 256) CROSSCLR_LI(1);
+    else if (Din <= 512) CROSSCLR_LI(2);
+    else if (Din <= 1024) CROSSCLR_LI(4);
+    else if (Din <= 2048) CROSSCLR_LI(8);
+    else CROSSCLR_LI(16);
+#undef CROSSCLR_LI
+    LAUNCH(infl_colsum_finish_kernel, dim3((Din + 63) / 64, 2), dim3(256), stream, (const float*)partial, kInflBlocks, Din, colsum);
+    return launch_status("infl_colsum_kernel");
+}
+template <typename TIN>
+static int infl_conn_t(const void* xv, const void* xt, long ldv, long ldt, int b, int Din, const float* inv_norm,
+                       const double* colsum, int Bglobal, double* conn, void* stream) {
+    LAUNCH((infl_conn_kernel<TIN>), dim3((b + 3) / 4, 2), dim3(256), stream, (const TIN*)xv, (const TIN*)xt, ldv, ldt, b, Din,
+           inv_norm, colsum, Bglobal, conn);
+    return launch_status("infl_conn_kernel");
+}
+static int infl_args(const void* xv, const void* xt, long ldv, long ldt, int b, int Din) {
+    if (!xv || !xt) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (b < 1 || Din < 1 || Din > CROSSCLR_INFL_MAX_DIN) return fail(CROSSCLR_E_ARG, "need b >= 1 and 1 <= Din <= %d", CROSSCLR_INFL_MAX_DIN);
+    if (ldv < Din || ldt < Din) return fail(CROSSCLR_E_ARG, "row stride smaller than Din");
+    return CROSSCLR_OK;
+}
+
+extern "C" int crossclr_influence_colsum(const void* x_video, const void* x_text, long ld_video, long ld_text, int in_dtype,
+                                         int b, int Din, float* inv_norm, float* partial_ws, double* colsum, void* stream) {
+    static_assert(kInflBlocks == CROSSCLR_INFL_BLOCKS && 256 * kInflMaxCols == CROSSCLR_INFL_MAX_DIN, "header out of sync");
+    if (int rc = infl_args(x_video, x_text, ld_video, ld_text, b, Din)) return rc;
+    if (!inv_norm || !partial_ws || !colsum) return fail(CROSSCLR_E_ARG, "NULL argument");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return infl_colsum_t<float>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, partial_ws, colsum, stream);
+        case CROSSCLR_IN_F64: return infl_colsum_t<double>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, partial_ws, colsum, stream);
+        case CROSSCLR_IN_F16: return infl_colsum_t<in_f16>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, partial_ws, colsum, stream);
+        case CROSSCLR_IN_BF16: return infl_colsum_t<in_bf16>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, partial_ws, colsum, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+extern "C" int crossclr_influence_conn(const void* x_video, const void* x_text, long ld_video, long ld_text, int in_dtype,
+                                       int b, int Din, const float* inv_norm, const double* colsum_total, int B_global,
+                                       double* conn, void* stream) {
+    if (int rc = infl_args(x_video, x_text, ld_video, ld_text, b, Din)) return rc;
+    if (!inv_norm || !colsum_total || !conn || B_global < b) return fail(CROSSCLR_E_ARG, "NULL argument / B_global < b");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return infl_conn_t<float>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, colsum_total, B_global, conn, stream);
+        case CROSSCLR_IN_F64: return infl_conn_t<double>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, colsum_total, B_global, conn, stream);
+        case CROSSCLR_IN_F16: return infl_conn_t<in_f16>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, colsum_total, B_global, conn, stream);
+        case CROSSCLR_IN_BF16: return infl_conn_t<in_bf16>(x_video, x_text, ld_video, ld_text, b, Din, inv_norm, colsum_total, B_global, conn, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+extern "C" int crossclr_influence_finish(const crossclr_plan* plan, const double* conn_all, float score_threshold,
+                                         float temperature_weights, float* neg_scale, float* loss_weight, void* stream) {
+    if (!plan || !conn_all || !neg_scale || !loss_weight) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (!(temperature_weights > 0.f)) return fail(CROSSCLR_E_ARG, "temperature_weights must be > 0");
+    LAUNCH(infl_finish_kernel, dim3(2), dim3(1024), stream, conn_all, plan->world, plan->rank, plan->b, plan->bpad,
+           (double)score_threshold, (double)temperature_weights, neg_scale, loss_weight);
+    return launch_status("infl_finish_kernel");
 }
 
 extern "C" int crossclr_selftest(int which, const void* in, void* out, void* stream) {

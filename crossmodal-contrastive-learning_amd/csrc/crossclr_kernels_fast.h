@@ -116,7 +116,8 @@ __device__ __forceinline__ int swz_slot16r(int chunk, int q) { return (chunk & ~
 
 template <int RB, int NW, int QT, int SWZ = 0>
 __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, unsigned char* buf, int wave, int lane,
-                                               const float* stat_src, unsigned char* stat_dst) {
+                                               const float* stat_src, unsigned char* stat_dst,
+                                               const float* stat2_src = nullptr, unsigned char* stat2_dst = nullptr) {
     constexpr int kInstr = QT * RB / 1024;  // wave-instructions per tile
 #pragma unroll
     for (int k = 0; k < (kInstr + NW - 1) / NW; ++k) {
@@ -124,12 +125,16 @@ __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, un
         if (kInstr % NW == 0 || ii < kInstr) {
             const int L = ii * 1024 + lane * 16;
             const int row = L / RB, slot = (L - row * RB) >> 4;
-            lds_dma16(tile_src + (size_t)row * RB + ((SWZ ? swz_slot16r(slot, row) : swz_slot(slot, row)) << 4), buf + ii * 1024);
+            // wave-uniform 64-bit base + per-lane UNSIGNED 32-bit offset: selects the SGPR-base addressing form
+            // (one offset VGPR per DMA instead of 64-bit address pairs -- the backward has no registers to spare)
+            const unsigned off = (unsigned)(row * RB + ((SWZ ? swz_slot16r(slot, row) : swz_slot(slot, row)) << 4));
+            lds_dma16(tile_src + off, buf + ii * 1024);
         }
     }
     // every wave issues the (identical) statistics DMA so that all waves have the same VMEM count per tile:
     // the counted s_waitcnt vmcnt(N) in the backward relies on it
-    if (stat_src != nullptr && lane < QT) lds_dma4(stat_src + lane, stat_dst);
+    if (stat_src != nullptr && lane < QT) lds_dma4(stat_src + (unsigned)lane, stat_dst);
+    if (stat2_src != nullptr && lane < QT) lds_dma4(stat2_src + (unsigned)lane, stat2_dst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,17 +229,22 @@ static inline int fwd_max_slots(const FwdWork& w) {
 //    (the ring barrier of the next tile) to colpart[row block][column]: fixed order, no atomics,
 //    nothing to zero.
 // ---------------------------------------------------------------------------------------------
-template <int DK, bool SYM, int NW>
+//  SW (sample weights, include/crossclr.h): the exponential of an intra-modal column q counts k_q times in the row
+//    sums, and -- mirrored -- the exponential of row p counts k_p times in the column sums; the tile's 32 k_q ride
+//    along with the tile DMA (one more 128-byte LDS-DMA per tile).
+template <int DK, bool SYM, int NW, bool SW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
-                                                          float* part, float* colpart, int* header) {
+                                                          float* part, float* colpart, int* header,
+                                                          const float* krows, const float* kcols) {
     constexpr int RB = DK * 32;            // bytes per operand row
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
     constexpr int RPB = 32 * NW;           // rows per thread block
     constexpr int NST = (4 * TILE + 4096 <= 160 * 1024) ? 4 : 2;
-    constexpr int NOPS = QT * RB / 1024 / NW;  // DMA wave-instructions per tile per wave
+    constexpr int NOPS = QT * RB / 1024 / NW + (SW ? 1 : 0);  // VMEM wave-instructions per tile per wave
     constexpr int CS = NW * QT * 4;        // one column-sum slot: [NW waves][32 columns] floats
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + (SYM ? 2 * CS : 0)];
+    constexpr int KQ0 = NST * TILE + (SYM ? 2 * CS : 0);   // [NST][32] floats: k of the tile's columns
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[KQ0 + (SW ? NST * 128 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -265,8 +275,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
     }
     const size_t pitch = RB;
     auto issue = [&](const Cursor& c, int stage) {
-        issue_tile_dma<RB, NW, QT>(reinterpret_cast<const unsigned char*>(cols) + col_tile(g, tile_of(c), QT).row0 * pitch,
-                                  lds + stage * TILE, wave, lane, nullptr, nullptr);
+        const ColTile ic = col_tile(g, tile_of(c), QT);
+        issue_tile_dma<RB, NW, QT>(reinterpret_cast<const unsigned char*>(cols) + ic.row0 * pitch, lds + stage * TILE, wave, lane,
+                                  SW ? kcols + ic.stat0 : nullptr, lds + KQ0 + stage * 128);
     };
     auto wait_keep = [&](int tiles_in_flight) {
         if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
@@ -300,7 +311,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
         if (w + k < w_end) issue(cq[k], k);
     int stage = 0;
     int my_rb = -1, row0w = 0, rmod = 0, r_in_mod = 0;
-    float rowacc = 0.f;
+    float rowacc = 0.f, kp = 1.f;
     bf16x8 pf[DK];
     auto store_rows = [&]() {
         float v = rowacc + wave_xor_f32(rowacc, 32);
@@ -314,6 +325,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             row0w = my_rb * RPB + 32 * wave;
             rmod = row0w / g.bpad;
             r_in_mod = row0w - rmod * g.bpad + l31;
+            if (SW) kp = krows[row0w + l31];
             if (CROSSCLR_FABL & 16) {
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
@@ -388,10 +400,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             }
         }
         float e[16];
+        if (SW && same_mod) {
+            const float* kq = reinterpret_cast<const float*>(lds + KQ0 + stage * 128);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
-            rowacc += e[r];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kq + 8 * r4 + 4 * half);   // columns frag_row(4 r4 + j, half)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = fast_exp2(acc[4 * r4 + j]);
+                    rowacc += x * k4[j];
+                    e[4 * r4 + j] = x * kp;     // what the mirrored tile's rows (these columns) see of row p
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
+                rowacc += e[r];
+            }
         }
         if (upper) {
             const float colsum = (CROSSCLR_FABL & 8) ? e[l31 & 15] : halving_sum16(e, l31);
@@ -421,19 +447,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
 // slice y walks its share of the column tiles and writes its own gradient slice (summed by the
 // finish kernel) -- that is what fills all 256 CUs at B=8192 without atomics.
 // ---------------------------------------------------------------------------------------------
-template <int DK>
+// SW (sample weights): intra-modal W = s E (wrz_p k_q + wrz_q k_p); the tile's k_q are a second 128-byte
+// statistics DMA per tile.
+template <int DK, bool SW>
 __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
                                                           const float* rz_rows, const float* wrz_rows,
                                                           const float* rz_cols, const float* wrz_cols, float* gbuf,
-                                                          int accumulate, int tiles_per_slice) {
+                                                          int accumulate, int tiles_per_slice,
+                                                          const float* krows, const float* kcols) {
     constexpr int RB = DK * 32;
     constexpr int QT = 32;                 // columns per tile
     constexpr int TILE = QT * RB;
     constexpr int NST = 4;                 // ring depth (power of two): one tile consumed, up to three in flight
     constexpr int PF = (CROSSCLR_PF < DK / 2) ? CROSSCLR_PF : DK / 2;
     constexpr int DT = DK / 2;             // 32-wide output fragments
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128];
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128 * (SW ? 2 : 1)];
     unsigned char* stat = lds + NST * TILE;  // [NST][32] floats: 1/Z (or w/Z) of the tile's columns
+    unsigned char* statk = stat + NST * 128; // SW: [NST][32] floats: k of the tile's columns
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -449,6 +479,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
     }
     const float rzp_inter = rz_rows[row0w + l31];
     const float rzp_intra = wrz_rows[row0w + l31];
+    const float kp = SW ? krows[row0w + l31] : 1.f;
 
     int off8[8];
 #pragma unroll
@@ -482,13 +513,14 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         return x < t_end ? x : t_end;
     };
     const size_t pitch = RB;
-    constexpr int NOPS = DK / 4 + 1;  // VMEM operations one tile costs each wave (DMA pieces + statistics)
+    constexpr int NOPS = DK / 4 + 1 + (SW ? 1 : 0);  // VMEM operations one tile costs each wave (DMA pieces + statistics)
     // a block's 128 rows never straddle the modality boundary (bpad is a multiple of 128), so all four
     // waves agree on which per-column statistics array (1/Z or w/Z) a tile needs
     auto issue = [&](int tile, int stage) {
         const ColTile c = col_tile(g, tile, QT);
         issue_tile_dma<RB, 4, QT>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE, wave,
-                                  lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128);
+                                  lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128,
+                                  SW ? kcols + c.stat0 : nullptr, statk + stage * 128);
     };
     auto wait_keep = [&](int tiles_in_flight) {  // block until all but the newest `tiles_in_flight` tiles landed
         if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
@@ -523,8 +555,9 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         return acc;
     };
     // ---- W = s E (1/Z_p + 1/Z_q), packed to bf16: the A fragments of the second product ----
-    auto weights = [&](f32x16 x, const ColTile& ct, const float* rzq, bf16x8 (&af)[2]) {
+    auto weights = [&](f32x16 x, const ColTile& ct, const float* rzq, const float* kqs, bf16x8 (&af)[2]) {
         const bool same_mod = (ct.mod == rmod);
+        const bool weighted = SW && same_mod;
         const float c2 = same_mod ? g.c_intra : g.c_inter;
         const float rzp = same_mod ? rzp_intra : rzp_inter;
         if (!(CROSSCLR_ABL & 2)) {
@@ -545,10 +578,13 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
             for (int r4 = 0; r4 < 2; ++r4) {
                 const int q0 = 16 * th + 8 * r4 + 4 * half;  // = frag_row(8th + 4r4, half)
                 const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
+                f32x4 kq = {1.f, 1.f, 1.f, 1.f};
+                if (weighted) kq = *reinterpret_cast<const f32x4*>(kqs + q0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = x[8 * th + 4 * r4 + j];
-                    pk.e[4 * r4 + j] = f32_to_bf16_bits((CROSSCLR_ABL & 2) ? v : fast_exp2(v) * (rzp + rq[j]));
+                    const float zz = weighted ? (rzp * kq[j] + rq[j] * kp) : (rzp + rq[j]);
+                    pk.e[4 * r4 + j] = f32_to_bf16_bits((CROSSCLR_ABL & 2) ? v : fast_exp2(v) * zz);
                 }
             }
             af[th] = __builtin_bit_cast(bf16x8, pk);
@@ -581,7 +617,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         const ColTile ct = col_tile(g, t, QT);
         const f32x16 acc = gemm1(bt, ct);
         bf16x8 af[2];
-        weights(acc, ct, reinterpret_cast<const float*>(stat + stage * 128), af);
+        weights(acc, ct, reinterpret_cast<const float*>(stat + stage * 128), reinterpret_cast<const float*>(statk + stage * 128), af);
         // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows), PF-deep fragment ring ----
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
@@ -631,11 +667,12 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 // the ds_read_b128 of the first product (a 16-lane group mixes two k-groups: even/odd slots) and for the
 // transpose reads of the second (8 rows x 2 chunks -> 16 distinct slots per 32 lanes).
 // ---------------------------------------------------------------------------------------------
-template <int DKK, int NW>
+template <int DKK, int NW, bool SW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_t* rows, const bf16_t* cols, Geo g,
                                                                     const float* rz_rows, const float* wrz_rows,
                                                                     const float* rz_cols, const float* wrz_cols,
-                                                                    float* gbuf, int accumulate, int tiles_per_slice) {
+                                                                    float* gbuf, int accumulate, int tiles_per_slice,
+                                                                    const float* krows, const float* kcols) {
     constexpr int DP = DKK * 32;           // padded embedding width
     constexpr int RB = DP * 2;             // bytes per operand row
     constexpr int QT = 32;
@@ -643,9 +680,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
     constexpr int NST = (4 * TILE + 512 <= 160 * 1024) ? 4 : 2;   // ring depth
     constexpr int DS = DP / 16;            // 16-wide output fragments
     constexpr int PF = (CROSSCLR_PF < DKK / 2) ? CROSSCLR_PF : (DKK / 2 > 0 ? DKK / 2 : 1);
-    constexpr int NOPS = QT * RB / 1024 / NW + 1;
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128];
+    constexpr int NOPS = QT * RB / 1024 / NW + 1 + (SW ? 1 : 0);
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NST * TILE + NST * 128 * (SW ? 2 : 1)];
     unsigned char* stat = lds + NST * TILE;
+    unsigned char* statk = stat + NST * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -661,6 +699,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
     }
     const float rzp_inter = rz_rows[row0w + i16];
     const float rzp_intra = wrz_rows[row0w + i16];
+    const float kp = SW ? krows[row0w + i16] : 1.f;
 
     // first product: row q = i16 (+16) of the tile, chunk 4ks + g4
     int offA[4];
@@ -693,7 +732,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
     auto issue = [&](int tile, int stage) {
         const ColTile c = col_tile(g, tile, QT);
         issue_tile_dma<RB, NW, QT, 1>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE,
-                                      wave, lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128);
+                                      wave, lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128,
+                                      SW ? kcols + c.stat0 : nullptr, statk + stage * 128);
     };
     auto wait_keep = [&](int tiles_in_flight) {
         if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
@@ -759,10 +799,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(rzq + 4 * g4);
         const f32x4 q1 = *reinterpret_cast<const f32x4*>(rzq + 16 + 4 * g4);
         struct { bf16_t e[8]; } pk;
+        if (SW && same_mod) {
+            const float* kqs = reinterpret_cast<const float*>(statk + stage * 128);
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(kqs + 4 * g4);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kqs + 16 + 4 * g4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pk.e[r] = f32_to_bf16_bits(fast_exp2(x0[r]) * (rzp + q0[r]));
-            pk.e[4 + r] = f32_to_bf16_bits(fast_exp2(x1[r]) * (rzp + q1[r]));
+            for (int r = 0; r < 4; ++r) {
+                pk.e[r] = f32_to_bf16_bits(fast_exp2(x0[r]) * (rzp * k0[r] + q0[r] * kp));
+                pk.e[4 + r] = f32_to_bf16_bits(fast_exp2(x1[r]) * (rzp * k1[r] + q1[r] * kp));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pk.e[r] = f32_to_bf16_bits(fast_exp2(x0[r]) * (rzp + q0[r]));
+                pk.e[4 + r] = f32_to_bf16_bits(fast_exp2(x1[r]) * (rzp + q1[r]));
+            }
         }
         const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
         // ---- G[p][:] += W[p][q] . Xq[q][:] : one k-step (32 columns) per 16-wide output fragment ----
@@ -819,17 +870,23 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
 }
 
 static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
-                               float* colpart, int* header, bool symmetric, void* stream) {
+                               float* colpart, int* header, bool symmetric, const float* krows, const float* kcols,
+                               void* stream) {
     const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
     const FwdWork wk = fast_forward_work(p, g.col_ranks, skipping ? g.skip_rank : -1, symmetric);
     if (wk.total <= 0) return CROSSCLR_OK;
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
     dim3 grid(wk.nblk);
-#define CROSSCLR_LF(DK, NW)                                                                                                   \
-    do {                                                                                                                       \
-        if (symmetric) CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, true, NW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, false, NW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header);         \
+    const bool sw = krows != nullptr && kcols != nullptr;
+#define CROSSCLR_LF2(DK, NW, SYM, SW) \
+    CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols)
+#define CROSSCLR_LF(DK, NW)                                        \
+    do {                                                            \
+        if (symmetric && sw) CROSSCLR_LF2(DK, NW, true, true);      \
+        else if (symmetric) CROSSCLR_LF2(DK, NW, true, false);      \
+        else if (sw) CROSSCLR_LF2(DK, NW, false, true);             \
+        else CROSSCLR_LF2(DK, NW, false, false);                    \
     } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LF(8, 8); break;
@@ -841,6 +898,7 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_LF
+#undef CROSSCLR_LF2
     return CROSSCLR_OK;
 }
 
@@ -850,14 +908,21 @@ static inline int fast_bwd_rows_per_block(int Dpad, int use16) { return use16 ? 
 
 static inline int fast_backward16(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                                   const float* rz_rows, const float* wrz_rows, const float* rz_cols,
-                                  const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
+                                  const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
+                                  const float* kcols, void* stream) {
+    const bool sw = krows != nullptr && kcols != nullptr;
     const int ntiles = g.col_ranks * 2 * p->bpad / 32;
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
-#define CROSSCLR_L16(DKK, NW)                                                                                      \
-    CROSSCLR_FAST_LAUNCH((fast_bwd16_kernel<DKK, NW>), dim3(2 * p->bpad / (16 * NW), p->bwd_slices), dim3(64 * NW), stream, r, c, g, \
-                         rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps)
+#define CROSSCLR_L16B(DKK, NW, SW)                                                                                  \
+    CROSSCLR_FAST_LAUNCH((fast_bwd16_kernel<DKK, NW, SW>), dim3(2 * p->bpad / (16 * NW), p->bwd_slices), dim3(64 * NW), stream, r, c, g, \
+                         rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols)
+#define CROSSCLR_L16(DKK, NW)                  \
+    do {                                        \
+        if (sw) CROSSCLR_L16B(DKK, NW, true);   \
+        else CROSSCLR_L16B(DKK, NW, false);     \
+    } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_L16(4, 8); break;
         case 256: CROSSCLR_L16(8, 8); break;
@@ -868,24 +933,33 @@ static inline int fast_backward16(const crossclr_plan* p, const Geo& g, const vo
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_L16
+#undef CROSSCLR_L16B
     return CROSSCLR_OK;
 }
 
 static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                                 const float* rz_rows, const float* wrz_rows, const float* rz_cols,
-                                const float* wrz_cols, float* gbuf, int accumulate, void* stream) {
+                                const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
+                                const float* kcols, void* stream) {
+    const bool sw = krows != nullptr && kcols != nullptr;
     const int ntiles = g.col_ranks * 2 * p->bpad / 32;
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
+#define CROSSCLR_L32(DK)                                                                                              \
+    do {                                                                                                               \
+        if (sw) CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<DK, true>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols); \
+        else CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<DK, false>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols);  \
+    } while (0)
     switch (p->Dpad) {
-        case 128: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<8>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
-        case 256: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<16>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
-        case 384: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<24>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
-        case 512: CROSSCLR_FAST_LAUNCH((fast_bwd_kernel<32>), grid, block, stream, r, c, g, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps); break;
+        case 128: CROSSCLR_L32(8); break;
+        case 256: CROSSCLR_L32(16); break;
+        case 384: CROSSCLR_L32(24); break;
+        case 512: CROSSCLR_L32(32); break;
         default: return CROSSCLR_E_ARG;
     }
+#undef CROSSCLR_L32
     return CROSSCLR_OK;
 }
 

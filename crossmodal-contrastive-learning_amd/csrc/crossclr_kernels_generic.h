@@ -169,9 +169,10 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 //   grid = (2*bpad/128 row blocks, nsplit column splits); each (row block, split) writes its own
 //   slot -> no atomics, deterministic.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+//   SW (sample weights): the exponential of an INTRA-modal column q is multiplied by kcols[q] (include/crossclr.h).
+template <typename T, bool SW>
 __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
-                                                       float* part) {
+                                                       float* part, const float* kcols) {
     typedef Operand<T> Op;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
@@ -245,12 +246,19 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
             for (int pi = 0; pi < 2; ++pi) {
                 const int p_t = 64 * wr + 32 * pi + l31;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q_t = 64 * wc + 32 * qi + frag_row(r, half);
-                    float e = fast_exp2(acc[qi][pi][r] * c2 - g.m2);
-                    if (ragged && ct.in_mod0 + q_t >= g.b) e = 0.f;
-                    if (diag_tile && q_t == p_t) e = 0.f;
-                    rowacc[pi] += e;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 kq = {1.f, 1.f, 1.f, 1.f};
+                    if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * r4 + j;
+                        const int q_t = 64 * wc + 32 * qi + frag_row(r, half);
+                        float e = fast_exp2(acc[qi][pi][r] * c2 - g.m2);
+                        if (SW) e *= kq[j];
+                        if (ragged && ct.in_mod0 + q_t >= g.b) e = 0.f;
+                        if (diag_tile && q_t == p_t) e = 0.f;
+                        rowacc[pi] += e;
+                    }
                 }
             }
     }
@@ -283,7 +291,7 @@ __device__ __forceinline__ int fin_prefix(int kind, int tpr, int NT, int rb) {
 __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nlaunch, int slots_per_launch, Geo g,
                                                          const float* diag_cos, float inv_tau, float neg_w, float* logz,
                                                          float* rz, float* wrz, double* loss_ws, const float* colpart,
-                                                         const int* header) {
+                                                         const int* header, const float* krows, const float* lw) {
     CROSSCLR_SHARED double red[4];
     const int n = 2 * g.bpad;
     const double shift = (double)g.m2 * (double)kLn2;
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     double acc = 0.0;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         const int mod = p / g.bpad, i = p - mod * g.bpad;
-        double s = self_term;
+        double s = krows ? self_term * (double)krows[p] : self_term;   // the masked self pair travels with its column
         for (int L = 0; L < nlaunch; ++L) {
             const int kind = header[4 * L], tpr = header[4 * L + 1], NT = header[4 * L + 2], per = header[4 * L + 3];
             const float* base = part + (size_t)L * slots_per_launch * n;
@@ -307,12 +315,13 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
         const bool valid = i < g.b;
         const double lz = shift + log(s);
         logz[p] = valid ? (float)lz : 0.f;
-        const float r = valid ? (float)(1.0 / s) : 0.f;
+        const double om = lw ? (double)lw[p] : 1.0;
+        const float r = valid ? (float)(om / s) : 0.f;
         rz[p] = r;
         wrz[p] = neg_w * r;
         if (valid) {
-            acc += lz;
-            if (mod == 0) acc -= 2.0 * (double)diag_cos[i] * (double)inv_tau;
+            acc += om * lz;
+            if (mod == 0) acc -= (lw ? om + (double)lw[g.bpad + i] : 2.0) * (double)diag_cos[i] * (double)inv_tau;
         }
     }
     acc = wave_sum_f64(acc);
@@ -417,10 +426,12 @@ __device__ __forceinline__ void bwd_gemm2(const unsigned char* wt, const unsigne
     }
 }
 
-template <typename T, int DC>
+// SW (sample weights): the intra-modal weight is s E (wrz_p k_q + wrz_q k_p) instead of s E (wrz_p + wrz_q).
+template <typename T, int DC, bool SW>
 __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, Geo g, const float* rz_rows,
                                                   const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
-                                                  float* gbuf, int accumulate, int tiles_per_slice) {
+                                                  float* gbuf, int accumulate, int tiles_per_slice,
+                                                  const float* krows, const float* kcols) {
     typedef Operand<T> Op;
     typedef BwdLds<T, DC> L;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[L::kTotal];
@@ -454,6 +465,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
     const int p_t = 32 * wp + l31;  // this lane's row inside the block (phase B)
     const float rzp_inter = rz_rows[row0 + p_t];
     const float rzp_intra = wrz_rows[row0 + p_t];
+    const float kp = SW ? krows[row0 + p_t] : 1.f;
 
     const int ntiles = g.col_ranks * 2 * g.bpad / 64;
     const int t_begin = blockIdx.z * tiles_per_slice;   // column slice z walks its share of the tiles ...
@@ -507,11 +519,14 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
         for (int r4 = 0; r4 < 4; ++r4) {
             const int q0 = 32 * wq + 8 * r4 + 4 * half;  // frag_row(4*r4 + j, half) = q0 - 32wq + j
             const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
+            f32x4 kq = {1.f, 1.f, 1.f, 1.f};
+            if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + q0);
+            const float kpe = (SW && same_mod) ? kp : 1.f;
             f32x4 w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float e = fast_exp2(acc[4 * r4 + j] * c2 - g.m2);
-                float v = e * (rzp + rq[j]);
+                float v = SW ? e * (rzp * kq[j] + rq[j] * kpe) : e * (rzp + rq[j]);
                 if (diag_tile && q0 + j == p_t) v = 0.f;
                 w[j] = v;
             }
@@ -543,7 +558,7 @@ template <typename TIN>
 __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int nslices, const TIN* video, const TIN* text, long ldv,
                                                          long ldt, Geo g, const float* inv_norm, float inv_tau,
                                                          int Bglobal, const double* grad_out, TIN* gvideo,
-                                                         TIN* gtext, long ldgv, long ldgt) {
+                                                         TIN* gtext, long ldgv, long ldgt, const float* lw) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + wave;  // 0 .. 2*b-1
     if (idx >= 2 * g.b) return;
@@ -556,7 +571,8 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     const float* grow = gbuf + ((size_t)mod * g.bpad + i) * g.Dpad;
     const size_t slice = (size_t)2 * g.bpad * g.Dpad;
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
-    const double pc = (double)inv_tau / (double)Bglobal;
+    // positive pair: -(omega_v,i + omega_t,i)/(2 B tau) * partner  (= -1/(B tau) without sample weights)
+    const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
     const bool clamped = io >= 1e12;  // ||x|| < eps: x/eps, no projection term
     const double go = grad_out[0];
     if (g.D <= 256 * kRowCache) {
@@ -608,6 +624,146 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
         double x = in_load(own, d) * io;
         double v = clamped ? ghd : (ghd - x * dot);
         in_store(out, d, v * io * go);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: influential-sample statistics (NOT in the reference @ v1 -- the recipe is stated in
+// oracle/influence_oracle.py).  All O(B Din) / O(B): HBM-bound row kernels, no B x B product:
+//   conn_i = mean_j xhat_i . xhat_j (self pair masked) = (xhat_i . sum_j xhat_j - xhat_i . xhat_i) / B
+//   a) partial column sums of the normalised rows (+ 1/||x_i||), b) their total, c) conn_i,
+//   d) keep_i = conn_i / max(conn) < threshold,  omega_i = B rho_i / sum(rho),  rho = exp(conn / sum(conn) / kappa)
+// blockIdx.y = modality (0 video, 1 text).
+// ---------------------------------------------------------------------------------------------
+constexpr int kInflBlocks = 256;    // partial column sums per modality (one block of 4 waves each)
+constexpr int kInflMaxCols = 16;    // Din <= 256 * kInflMaxCols
+
+// a) one wave per row at a time; a lane owns 4 consecutive columns of every 256-column stretch and keeps its running
+//    column sums in registers; the 4 waves of a block meet in LDS at the end.  Rows are read once.
+template <typename TIN, int KC>
+__global__ void __launch_bounds__(256) infl_colsum_kernel(const TIN* xv, const TIN* xt, long ldv, long ldt, int n, int Din,
+                                                          float* inv_norm, float* partial) {
+    CROSSCLR_SHARED float red[4][256 * KC];
+    const TIN* x = blockIdx.y == 0 ? xv : xt;
+    const long ld = blockIdx.y == 0 ? ldv : ldt;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float acc[KC][4];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+        const TIN* xr = x + (size_t)row * ld;
+        double v[KC][4];
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < Din) {
+                row_load4(xr, d, Din, v[k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss += v[k][j] * v[k][j];
+            }
+        }
+        ss = wave_sum_f64(ss);
+        const double nrm = sqrt(ss);
+        const float inv = (float)(1.0 / (nrm > 1e-12 ? nrm : 1e-12));
+        if (lane == 0) inv_norm[(size_t)blockIdx.y * n + row] = inv;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < Din) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[k][j] += (float)v[k][j] * inv;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave][256 * k + 4 * lane + j] = acc[k][j];
+    __syncthreads();
+    for (int d = tid; d < Din; d += 256)
+        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Din + d] = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+}
+// b) total of the block partials: 64 columns x 4 groups of blocks per thread block, fixed order
+__global__ void __launch_bounds__(256) infl_colsum_finish_kernel(const float* partial, int nblocks, int Din, double* colsum) {
+    CROSSCLR_SHARED double red[4][64];
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + c;
+    double s = 0.0;
+    if (d < Din) {
+        const float* src = partial + (size_t)blockIdx.y * nblocks * Din + d;
+#pragma unroll 16
+        for (int b = grp; b < nblocks; b += 4) s += (double)src[(size_t)b * Din];   // independent loads, fixed order
+    }
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && d < Din) colsum[(size_t)blockIdx.y * Din + d] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+// one wave per row: conn = (xhat . colsum_total - xhat . xhat) / B_global
+template <typename TIN>
+__global__ void __launch_bounds__(256) infl_conn_kernel(const TIN* xv, const TIN* xt, long ldv, long ldt, int n, int Din,
+                                                        const float* inv_norm, const double* colsum, int Bglobal,
+                                                        double* conn) {
+    const TIN* x = blockIdx.y == 0 ? xv : xt;
+    const long ld = blockIdx.y == 0 ? ldv : ldt;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    const double inv = (double)inv_norm[(size_t)blockIdx.y * n + row];
+    const double* cs = colsum + (size_t)blockIdx.y * Din;
+    double dot = 0.0, self = 0.0;
+    for (int d = lane; d < Din; d += 64) {
+        const double a = (double)(float)(in_load(x + (size_t)row * ld, d) * inv);   // xhat in fp32, like the column sums
+        dot += a * cs[d];
+        self += a * a;
+    }
+    dot = wave_sum_f64(dot);
+    self = wave_sum_f64(self);
+    if (lane == 0) conn[(size_t)blockIdx.y * n + row] = (dot - self) / (double)Bglobal;
+}
+// block-wide reductions over 1024 threads
+__device__ __forceinline__ double block_reduce_f64(double v, bool take_max, double* red) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = wave_xor_f64(v, m);
+        v = take_max ? (o > v ? o : v) : v + o;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int k = 1; k < 16; ++k) r = take_max ? (red[k] > r ? red[k] : r) : r + red[k];
+    return r;
+}
+// conn_all[world][2][n]; one block per modality writes keep / omega of THIS rank's rows in the [2][bpad] layout
+__global__ void __launch_bounds__(1024) infl_finish_kernel(const double* conn_all, int world, int rank, int n, int bpad,
+                                                           double threshold, double kappa, float* neg_scale, float* loss_weight) {
+    CROSSCLR_SHARED double red[16];
+    const int mod = blockIdx.x, tid = threadIdx.x;
+    const int total = world * n;
+    auto at = [&](int g) { return conn_all[((size_t)(g / n) * 2 + mod) * n + (g % n)]; };
+    double mx = -1e300, mn = 1e300, sm = 0.0;
+#pragma unroll 8
+    for (int g = tid; g < total; g += 1024) { const double c = at(g); mx = c > mx ? c : mx; mn = c < mn ? c : mn; sm += c; }
+    mx = block_reduce_f64(mx, true, red);
+    mn = -block_reduce_f64(-mn, true, red);
+    sm = block_reduce_f64(sm, false, red);
+    const double zs = 1.0 / (sm * kappa);                 // z = conn * zs is monotone in conn: its maximum is analytic
+    const double zmax = zs >= 0.0 ? mx * zs : mn * zs;
+    double rs = 0.0;
+#pragma unroll 8
+    for (int g = tid; g < total; g += 1024) rs += exp(at(g) * zs - zmax);
+    rs = block_reduce_f64(rs, false, red);
+    for (int i = tid; i < bpad; i += 1024) {
+        float k = 0.f, om = 0.f;
+        if (i < n) {
+            const double c = conn_all[((size_t)rank * 2 + mod) * n + i];
+            k = (mx <= 0.0 || c / mx < threshold) ? 1.f : 0.f;
+            om = (float)((double)total * exp(c * zs - zmax) / rs);
+        }
+        neg_scale[(size_t)mod * bpad + i] = k;
+        loss_weight[(size_t)mod * bpad + i] = om;
     }
 }
 

@@ -19,6 +19,13 @@ Keyword-only additions (defaults reproduce the reference's single-process behavi
   process_group  a torch.distributed group: the batch is the concatenation of every rank's rows
                  (equal count per rank); the returned loss is the GLOBAL loss on every rank and the
                  gradients are exactly d(global loss)/d(local rows).
+  negative_scale (functional form) per-sample multipliers (k_video[b], k_text[b]) >= 0 of the sample's
+                 exponential wherever it is an intra-modal NEGATIVE column (0 prunes it from the negative
+                 set), and
+  loss_weight    per-sample weights (w_video[b], w_text[b]) of the sample's own loss term (all ones = the
+                 reference's mean).  Both are constants (no gradient); None = the reference's loss.  This
+                 is the hook for influential-sample pruning / weighting (`influence.py`),
+                 which the reference @ v1 does not contain.
 """
 from __future__ import annotations
 
@@ -63,11 +70,39 @@ def _resolve_mode(compute_mode: str, global_batch: int) -> int:
 class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
-                 "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded")
+                 "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
+                 "k_rows", "k_cols", "lw")
+
+
+def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor]:
+    """(video[b], text[b]) -> float32 [2][bpad] in the statistics layout, zero padded."""
+    if pair is None:
+        return None
+    packed = getattr(pair, "packed", None)   # influence.PackedPair: already in the kernels' layout
+    if packed is not None:
+        if packed.numel() != 2 * bpad or packed.dtype != torch.float32 or packed.device != dev or pair.b != b:
+            raise ValueError(f"{what}: packed weights do not match this batch")
+        return packed
+    if not (isinstance(pair, (tuple, list)) and len(pair) == 2):
+        raise ValueError(f"{what} must be a (video[b], text[b]) pair of 1-D tensors")
+    out = torch.zeros(2, bpad, dtype=torch.float32, device=dev)
+    for m, x in enumerate(pair):
+        if not torch.is_tensor(x) or x.dim() != 1 or x.shape[0] != b:
+            raise ValueError(f"{what}[{m}] must be a 1-D tensor with one entry per local sample ({b})")
+        out[m, :b] = x.detach().to(device=dev, dtype=torch.float32)
+    return out.view(-1)
+
+
+def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
+    if k_rows is None and lw is None:
+        return None
+    s = nat.SampleWeights(0 if k_rows is None else k_rows.data_ptr(), 0 if k_cols is None else k_cols.data_ptr(),
+                          0 if lw is None else lw.data_ptr())
+    return ctypes.pointer(s)
 
 
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
-                  compute_mode: str, group) -> "tuple[torch.Tensor, _Workspace]":
+                  compute_mode: str, group, negative_scale=None, loss_weight=None) -> "tuple[torch.Tensor, _Workspace]":
     import torch.distributed as dist
     lib = nat.library()
     dev = video.device
@@ -97,6 +132,9 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.wrz = torch.empty(2 * plan.bpad, **f32)
     ws.loss_sum = torch.empty(plan.loss_ws_doubles, dtype=torch.float64, device=dev)
     pp = ctypes.byref(plan)
+    ws.k_rows = _pack_pair(negative_scale, b, plan.bpad, dev, "negative_scale")
+    ws.lw = _pack_pair(loss_weight, b, plan.bpad, dev, "loss_weight")
+    ws.k_cols = ws.k_rows
 
     nat.check(lib.crossclr_normalize(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
                                      _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
@@ -106,17 +144,20 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         # while the local column block is processed on the compute stream
         ws.xcols = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device=dev)
         gather = dist.all_gather_into_tensor(ws.xcols, ws.xhat, group=group, async_op=True)
+        if ws.k_rows is not None:
+            ws.k_cols = torch.empty(world * ws.k_rows.numel(), **f32)
+            dist.all_gather_into_tensor(ws.k_cols, ws.k_rows, group=group)
     else:
         ws.xcols = ws.xhat
-    nat.check(lib.crossclr_forward(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
-                                   _ptr(part), 0, stream))
+    nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                     _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, stream))
     if sharded:
         gather.wait()
-        nat.check(lib.crossclr_forward(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
-                                       ws.negative_w, _ptr(part), plan.fwd_slots, stream))
-    nat.check(lib.crossclr_forward_finish(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), ws.temperature,
-                                          ws.negative_w, _ptr(ws.logz), _ptr(ws.rz), _ptr(ws.wrz),
-                                          _ptr(ws.loss_sum), stream))
+        nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
+                                         ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, stream))
+    nat.check(lib.crossclr_forward_finish_w(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), ws.temperature,
+                                            ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.logz), _ptr(ws.rz),
+                                            _ptr(ws.wrz), _ptr(ws.loss_sum), stream))
     if sharded:
         stats = torch.cat([ws.rz, ws.wrz])
         allstats = torch.empty(world * stats.numel(), **f32)
@@ -142,26 +183,27 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
     rank, world = ws.rank, ws.world
     rz_loc, wrz_loc = ws.rz, ws.wrz   # column statistics of the local block = this rank's row statistics
-    nat.check(lib.crossclr_backward(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
-                                    _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc), _ptr(gbuf), 0, stream))
+    nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                      _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
+                                      _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
     if ws.sharded:
-        nat.check(lib.crossclr_backward(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
-                                        ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols),
-                                        _ptr(ws.wrz_cols), _ptr(gbuf), 1, stream))
+        nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
+                                          ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols),
+                                          _ptr(ws.wrz_cols), _sw(ws.k_rows, ws.k_cols, None), _ptr(gbuf), 1, stream))
     go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
     gv = torch.empty(video.shape, dtype=video.dtype, device=dev)
     gt = torch.empty(text.shape, dtype=text.dtype, device=dev)
-    nat.check(lib.crossclr_backward_finish(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
-                                           ws.in_dtype, _ptr(ws.inv_norm), ws.temperature, _ptr(go), _ptr(gv),
-                                           _ptr(gt), gv.stride(0), gt.stride(0), stream))
+    nat.check(lib.crossclr_backward_finish_w(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
+                                             ws.in_dtype, _ptr(ws.inv_norm), ws.temperature, _sw(None, None, ws.lw),
+                                             _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0), stream))
     return gv, gt
 
 
 class _CrossCLRFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, video, text, temperature, negative_w, compute_mode, group):
+    def forward(ctx, video, text, temperature, negative_w, compute_mode, group, negative_scale, loss_weight):
         video_c, text_c = _row_major(video.detach()), _row_major(text.detach())
-        loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group)
+        loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight)
         ctx.ws = ws
         ctx.save_for_backward(video_c, text_c)
         return loss
@@ -171,7 +213,7 @@ class _CrossCLRFunction(torch.autograd.Function):
         video_c, text_c = ctx.saved_tensors
         gv, gt = _backward_impl(ctx.ws, video_c, text_c, grad_out)
         return (gv if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def _validate(video: torch.Tensor, text: torch.Tensor) -> None:
@@ -195,8 +237,9 @@ def _validate(video: torch.Tensor, text: torch.Tensor) -> None:
 
 
 def crossclr_loss(video_features: torch.Tensor, text_features: torch.Tensor, temperature: float = 0.03,
-                  negative_weight: float = 0.8, *, compute_mode: str = "auto", process_group=None) -> torch.Tensor:
-    """Functional form of `CrossCLR_onlyIntraModality.forward`."""
+                  negative_weight: float = 0.8, *, compute_mode: str = "auto", process_group=None,
+                  negative_scale=None, loss_weight=None) -> torch.Tensor:
+    """Functional form of `CrossCLR_onlyIntraModality.forward` (+ the optional per-sample weights, see module doc)."""
     _validate(video_features, text_features)
     if not video_features.is_cuda and nat.backend() != "emu-host":
         # the reference hard-codes .cuda() (trainer/loss.py:66,103,104); so does this path
@@ -204,7 +247,7 @@ def crossclr_loss(video_features: torch.Tensor, text_features: torch.Tensor, tem
     if video_features.shape[0] == 0:
         return torch.full((), float("nan"), dtype=torch.float64, device=video_features.device)
     return _CrossCLRFunction.apply(video_features, text_features, float(temperature), float(negative_weight),
-                                   compute_mode, process_group)
+                                   compute_mode, process_group, negative_scale, loss_weight)
 
 
 class CrossCLR_onlyIntraModality(nn.Module):

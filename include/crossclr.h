@@ -14,6 +14,9 @@
  *   crossclr_forward_finish trainer/loss.py:60 (-log), :114 (means)  -> per-row logZ, loss sum
  *   crossclr_backward       autograd of :83-112 (SURVEY.md section 3.5 closed form)
  *   crossclr_backward_finish autograd of :79-80 (normalize backward) + the analytic -2*delta term
+ *   crossclr_*_w            the same four with per-sample weights (influential-sample
+ *                           pruning / loss weighting -- NOT in the reference @ v1, whose only weight is the scalar
+ *                           `negative_weight` of :56,99-100); NULL weights == the plain entry points
  *
  * Data layout ("packed operand"): one rank's normalised embeddings are a dense row-major array
  *   X[2][bpad][Dpad]   (modality 0 = video rows, 1 = text rows), zero padded,
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CROSSCLR_ABI_VERSION 1
+#define CROSSCLR_ABI_VERSION 2
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
 #define CROSSCLR_IN_F32 0
@@ -124,6 +127,67 @@ int crossclr_backward_finish(const crossclr_plan* plan, const float* gbuf,
                              int in_dtype, const float* inv_norm, float temperature,
                              const double* grad_out, void* grad_video, void* grad_text,
                              long ld_gvideo, long ld_gtext, void* stream);
+
+/* ---- per-sample weights (ABI version 2) ------------------------------------------------------------
+ * k >= 0  "negative scale": multiplier of exp(logit) wherever the sample is an INTRA-modal negative column
+ *         (0 = pruned from the negative set, 1 = reference); its masked self pair (logit 0, loss.py:96-97)
+ *         travels with the column:   Z_p = sum_inter E + sum_{q != p, same modality} k_q E_pq + k_p e^0
+ * omega   weight of the sample's own loss term, normalised so that omega == 1 is the reference's mean:
+ *         loss = sum_p omega_p (log Z_p - A_pp) / (2 B)
+ * Both are constants w.r.t. the embeddings.  Arrays use the [2][bpad] / [col_ranks][2][bpad] indexing of
+ * the statistics; padding entries are ignored.  Any pointer (or the struct) may be NULL = all ones.      */
+typedef struct crossclr_sample_weights {
+    const float* neg_scale_rows; /* k of this rank's rows            [2][bpad]            */
+    const float* neg_scale_cols; /* k of the column operand's rows   [col_ranks][2][bpad] */
+    const float* loss_weight;    /* omega of this rank's rows        [2][bpad]            */
+} crossclr_sample_weights;
+
+/* uses neg_scale_cols (and neg_scale_rows for the mirrored tiles of the symmetric evaluation) */
+int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                       int col_ranks, int col_rank0, int skip_rank,
+                       float temperature, float negative_weight, const crossclr_sample_weights* sw,
+                       float* part, int slot0, void* stream);
+/* uses neg_scale_rows (self pair) and loss_weight:  rz = omega/Z, wrz = negative_weight*omega/Z,
+ * loss_sum[0] = sum_p omega_p log Z_p - sum_i (omega_v,i + omega_t,i) A_ii                          */
+int crossclr_forward_finish_w(const crossclr_plan* plan, const float* part, int nslots,
+                              const float* diag_cos, float temperature, float negative_weight,
+                              const crossclr_sample_weights* sw,
+                              float* logz, float* rz, float* wrz, double* loss_sum, void* stream);
+/* intra-modal weight becomes  s E (wrz_p k_q + wrz_q k_p);  uses neg_scale_rows and neg_scale_cols */
+int crossclr_backward_w(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                        int col_ranks, int col_rank0, int skip_rank,
+                        float temperature, float negative_weight,
+                        const float* rz_rows, const float* wrz_rows,
+                        const float* rz_cols, const float* wrz_cols,
+                        const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+/* positive-pair term becomes -(omega_v,i + omega_t,i)/(2 B tau) partner_hat;  uses loss_weight      */
+int crossclr_backward_finish_w(const crossclr_plan* plan, const float* gbuf,
+                               const void* video, const void* text, long ld_video, long ld_text,
+                               int in_dtype, const float* inv_norm, float temperature,
+                               const crossclr_sample_weights* sw,
+                               const double* grad_out, void* grad_video, void* grad_text,
+                               long ld_gvideo, long ld_gtext, void* stream);
+
+/* ---- influential-sample statistics (ABI version 2; SURVEY.md 8(f) rank 1, not in the reference @ v1) ----
+ * From INPUT-space features x[b][Din] of both modalities (any float dtype, row stride ld):
+ *   conn_i = mean_j xhat_i . xhat_j (self pair masked) = (xhat_i . sum_j xhat_j - xhat_i . xhat_i) / B     O(B Din)
+ *   neg_scale_i = conn_i / max(conn) < score_threshold          (1 keeps the sample among the negatives, 0 prunes it)
+ *   loss_weight = B rho / sum(rho),  rho = exp(conn / sum(conn) / temperature_weights)
+ * Three calls so that a sharded caller can all-reduce `colsum` and all-gather `conn` in between:
+ *   _colsum: inv_norm[2][b] = 1/max(||x||,1e-12), colsum[2][Din] = sum of this rank's normalised rows (double);
+ *            partial_ws = 2*CROSSCLR_INFL_BLOCKS*Din floats of scratch
+ *   _conn:   conn[2][b] (double) from colsum summed over all ranks and B_global
+ *   _finish: conn_all[world][2][b] -> neg_scale[2][bpad], loss_weight[2][bpad] of plan->rank's rows (padding 0),
+ *            ready to be used as crossclr_sample_weights                                                      */
+#define CROSSCLR_INFL_BLOCKS 256
+#define CROSSCLR_INFL_MAX_DIN 4096
+int crossclr_influence_colsum(const void* x_video, const void* x_text, long ld_video, long ld_text, int in_dtype,
+                              int b, int Din, float* inv_norm, float* partial_ws, double* colsum, void* stream);
+int crossclr_influence_conn(const void* x_video, const void* x_text, long ld_video, long ld_text, int in_dtype,
+                            int b, int Din, const float* inv_norm, const double* colsum_total, int B_global,
+                            double* conn, void* stream);
+int crossclr_influence_finish(const crossclr_plan* plan, const double* conn_all, float score_threshold,
+                              float temperature_weights, float* neg_scale, float* loss_weight, void* stream);
 
 /* Hardware assumption checks (MFMA fragment layouts, ds_read_b64_tr_b16 gather).  `out` is a
  * device buffer of at least 64 KiB; the caller compares it with the documented layouts.        */

@@ -1,0 +1,90 @@
+"""MI355X parity of the per-sample weights (negative_scale / loss_weight, `crossclr_*_w`; SURVEY.md 8(f) rank 1,
+BASELINE config 5) against the weighted float64 oracle.  The weighting is not in the reference @ v1 (parity
+unpinned, see oracle/influence_oracle.py); what IS pinned: unit weights reproduce the reference path bit for bit."""
+import pytest
+import torch
+
+import crossclr_amd
+from crossclr_amd import _native as nat
+from oracle import crossclr_oracle as orc
+from oracle import influence_oracle as inf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _hip_only():
+    nat.use_library_for_testing(None)
+    assert nat.backend() == "hip-gfx950"
+    yield
+
+
+def weights(B, seed, binary):
+    g = torch.Generator().manual_seed(seed)
+    kv = (torch.rand(B, generator=g) > 0.3).float()
+    kt = (torch.rand(B, generator=g) > 0.5).float() if binary else 2 * torch.rand(B, generator=g)
+    return kv, kt, 2 * torch.rand(B, generator=g), 0.5 + torch.rand(B, generator=g)
+
+
+def run(v, t, mode, kv, kt, ov, ot, tau=0.03, w=0.8):
+    vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    loss = crossclr_amd.crossclr_loss(vd, td, tau, w, compute_mode=mode,
+                                      negative_scale=None if kv is None else (kv.cuda(), kt.cuda()),
+                                      loss_weight=None if ov is None else (ov.cuda(), ot.cuda()))
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss, vd.grad.cpu(), td.grad.cpu()
+
+
+@pytest.mark.parametrize("B,D,mode,binary,ltol,gtol", [
+    (64, 256, "fp32", True, 2e-5, 2e-4),
+    (300, 100, "fp32", False, 2e-5, 2e-4),
+    (2048, 512, "fp32", True, 2e-5, 2e-4),
+    (300, 100, "bf16", False, 1e-3, 1e-2),      # register-resident kernels, ragged tiles, symmetric forward
+    (2048, 512, "bf16", True, 1e-3, 1e-2),      # 32-row backward
+    (1024, 1024, "bf16", False, 1e-3, 1e-2),    # BASELINE config 5's width: 4-wave forward, 16-row backward
+    (640, 768, "bf16", True, 1e-3, 1e-2),
+    (512, 1536, "bf16", True, 1e-3, 1e-2),      # generic tiled kernels
+])
+def test_weighted_loss_and_grads_match_oracle(B, D, mode, binary, ltol, gtol):
+    v, t = orc.make_inputs("randn", B, D, 11)
+    kv, kt, ov, ot = weights(B, 5, binary)
+    ref = inf.streaming_weighted_loss_and_grads(v, t, 0.03, 0.8, kv, kt, ov, ot)
+    loss, gv, gt = run(v, t, mode, kv, kt, ov, ot)
+    assert abs(loss.item() - float(ref["loss"])) <= ltol * max(1.0, abs(float(ref["loss"])))
+    sc = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+    assert (gv.double() - ref["grad_v"]).abs().max().item() <= gtol * sc
+    assert (gt.double() - ref["grad_t"]).abs().max().item() <= gtol * sc
+
+
+@pytest.mark.parametrize("B,D,mode", [(64, 256, "fp32"), (2048, 512, "bf16"), (1024, 1024, "bf16"), (4096, 512, "bf16")])
+def test_unit_weights_are_bit_identical_to_the_reference_path(B, D, mode):
+    v, t = orc.make_inputs("randn", B, D, 8)
+    one = torch.ones(B)
+    l0, gv0, gt0 = run(v, t, mode, None, None, None, None)
+    l1, gv1, gt1 = run(v, t, mode, one, one, one, one)
+    assert l0.item() == l1.item() and torch.equal(gv0, gv1) and torch.equal(gt0, gt1)
+
+
+def test_influential_sample_module_at_size():
+    """The full recipe through the module at B = 4096: input-space features -> keep mask + weights (O(B D) glue on the
+    GPU) -> weighted fused kernels; checked against the dense statement + streaming oracle on the host."""
+    B, D = 4096, 512
+    v, t = orc.make_inputs("randn", B, D, 21)
+    xv, xt = orc.make_inputs("cluster", B, 256, 22)
+    w = inf.influence_weights(xv, xt, 0.9, 0.0035)
+    assert 0 < w["keep_v"].sum() < B
+    crit = crossclr_amd.CrossCLR(0.03, 0.0035, 0.8, 0.9, compute_mode="bf16").cuda()
+    vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    loss = crit(vd, td, xv.cuda(), xt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    (kv, kt), (ov, ot) = crossclr_amd.influential_sample_weights(xv.cuda(), xt.cuda(), 0.9, 0.0035)
+    # a sample whose normalised connectivity sits within float rounding of the threshold may flip: use the GPU's mask
+    assert (kv.cpu().double() != w["keep_v"]).sum() <= 2 and (kt.cpu().double() != w["keep_t"]).sum() <= 2
+    assert torch.allclose(ov.cpu().double(), w["omega_v"], rtol=1e-3, atol=1e-9)
+    ref = inf.streaming_weighted_loss_and_grads(v, t, 0.03, 0.8, kv.cpu(), kt.cpu(), ov.cpu(), ot.cpu())
+    assert abs(loss.item() - float(ref["loss"])) <= 1e-3
+    sc = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+    assert (vd.grad.cpu().double() - ref["grad_v"]).abs().max().item() <= 1e-2 * sc
+    assert (td.grad.cpu().double() - ref["grad_t"]).abs().max().item() <= 1e-2 * sc
