@@ -56,6 +56,9 @@ __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirs
 #ifndef CROSSCLR_ABL
 #define CROSSCLR_ABL 0
 #endif
+#ifndef CROSSCLR_G1CHAINS
+#define CROSSCLR_G1CHAINS 1   // accumulator chains of the 32-row backward's first product (2: measured)
+#endif
 #if defined(CROSSCLR_EMU) || CROSSCLR_SCHED == 0
 #define SCHED_PIPELINE(nmfma, reads_per_mfma, pf) do {} while (0)
 #elif CROSSCLR_SCHED == 1
@@ -537,6 +540,11 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#if CROSSCLR_G1CHAINS == 2
+        f32x16 acc_odd;   // second accumulator chain: consecutive MFMAs independent
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+#endif
         bf16x8 ring[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(bt + off8[i & 7] + (i >> 3) * 256);
@@ -549,9 +557,17 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
             const bf16x8 a_cur = ring[ks % PF];
             if (ks + PF < DK)
                 ring[ks % PF] = *reinterpret_cast<const bf16x8*>(bt + off8[(ks + PF) & 7] + ((ks + PF) >> 3) * 256);
+#if CROSSCLR_G1CHAINS == 2
+            if (ks & 1) acc_odd = mfma_32x32x16_bf16(a_cur, pf[ks], acc_odd);
+            else
+#endif
             acc = mfma_32x32x16_bf16(a_cur, pf[ks], acc);
         }
         if (!(CROSSCLR_ABL & 32)) SCHED_PIPELINE(DK, 1, PF);
+#if CROSSCLR_G1CHAINS == 2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc_odd[r];
+#endif
         return acc;
     };
     // ---- W = s E (1/Z_p + 1/Z_q), packed to bf16: the A fragments of the second product ----

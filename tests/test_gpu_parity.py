@@ -365,3 +365,38 @@ def test_global_batch_scale_on_one_gpu():
     # the normalise-backward leaves every gradient row orthogonal to its input row
     radial = (v.grad.double() * v.detach().double()).sum(1).abs().max().item()
     assert radial <= 1e-3 * v.grad.double().norm(dim=1).max().item() * v.detach().double().norm(dim=1).max().item()
+
+
+def test_step_is_hip_graph_capturable():
+    """No entry point synchronises the host or allocates device memory itself, so a whole fwd+bwd step can be
+    captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new data."""
+    B, D = 512, 256
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()
+    v0, t0 = orc.make_inputs("randn", B, D, 1)
+    v1, t1 = orc.make_inputs("randn", B, D, 2)
+    sv = v0.cuda().requires_grad_(True)
+    st = t0.cuda().requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):          # warm-up off the default stream, as torch's capture rules ask
+        for _ in range(2):
+            sv.grad = st.grad = None
+            crit(sv, st).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    sv.grad = st.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = crit(sv, st)
+        static_loss.backward()
+    with torch.no_grad():
+        sv.copy_(v1.cuda())
+        st.copy_(t1.cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    ev = v1.cuda().requires_grad_(True)
+    et = t1.cuda().requires_grad_(True)
+    eager = crit(ev, et)
+    eager.backward()
+    torch.cuda.synchronize()
+    assert static_loss.item() == eager.item()
+    assert torch.equal(sv.grad, ev.grad) and torch.equal(st.grad, et.grad)
