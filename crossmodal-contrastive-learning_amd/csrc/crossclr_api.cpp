@@ -326,7 +326,8 @@ static int backward_generic(const crossclr_plan* p, const Geo& g, const void* ro
                             void* stream) {
     dim3 block(256);
     const int rb = 2 * p->bpad / 64;
-    const int ntiles = g.col_ranks * 2 * p->bpad / 64;
+    const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
+    const int ntiles = (g.col_ranks - (skipping ? 1 : 0)) * 2 * p->bpad / 64;   // usable column tiles
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     const unsigned nz = (unsigned)p->bwd_slices;
 #define CROSSCLR_LB(DC)                                                                                                       \

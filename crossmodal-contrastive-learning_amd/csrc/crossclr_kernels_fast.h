@@ -505,22 +505,22 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
 
-    const int ntiles = g.col_ranks * 2 * g.bpad / QT;
+    // slice y walks USABLE tiles [y*tiles_per_slice, ...): the skipped rank's segment is cut out of the numbering, so the
+    // slices stay balanced whichever rank is skipped
     const int per_rank = 2 * g.bpad / QT;
-    int t = blockIdx.y * tiles_per_slice;
+    const int skip_seg = (g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
+    const int usable = (g.col_ranks - (skip_seg >= 0 ? 1 : 0)) * per_rank;
+    int t = blockIdx.y * tiles_per_slice;   // t, t1, t2, t3: usable-tile indices
     int t_end = t + tiles_per_slice;
-    if (t_end > ntiles) t_end = ntiles;
-    auto next = [&](int x) {  // first tile >= x outside the skipped rank; t_end if none
-        if (x >= t_end) return t_end;
-        if (g.skip_rank >= 0 && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
-        return x < t_end ? x : t_end;
-    };
+    if (t_end > usable) t_end = usable;
+    auto tile_of = [&](int u) { return (skip_seg >= 0 && u >= skip_seg * per_rank) ? u + per_rank : u; };
+    auto next = [&](int x) { return x < t_end ? x : t_end; };
     const size_t pitch = RB;
     constexpr int NOPS = DK / 4 + 1 + (SW ? 1 : 0);  // VMEM operations one tile costs each wave (DMA pieces + statistics)
     // a block's 128 rows never straddle the modality boundary (bpad is a multiple of 128), so all four
     // waves agree on which per-column statistics array (1/Z or w/Z) a tile needs
-    auto issue = [&](int tile, int stage) {
-        const ColTile c = col_tile(g, tile, QT);
+    auto issue = [&](int u, int stage) {
+        const ColTile c = col_tile(g, tile_of(u), QT);
         issue_tile_dma<RB, 4, QT>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE, wave,
                                   lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128,
                                   SW ? kcols + c.stat0 : nullptr, statk + stage * 128);
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
             if (t3 < t_end) issue(t3, (stage + 3) & (NST - 1));
         }
         const unsigned char* bt = lds + stage * TILE;
-        const ColTile ct = col_tile(g, t, QT);
+        const ColTile ct = col_tile(g, tile_of(t), QT);
         const f32x16 acc = gemm1(bt, ct);
         bf16x8 af[2];
         weights(acc, ct, reinterpret_cast<const float*>(stat + stage * 128), reinterpret_cast<const float*>(statk + stage * 128), af);
@@ -734,19 +734,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[d][r] = 0.f;
 
-    const int ntiles = g.col_ranks * 2 * g.bpad / QT;
     const int per_rank = 2 * g.bpad / QT;
-    int t0 = blockIdx.y * tiles_per_slice;
+    const int skip_seg = (g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
+    const int usable = (g.col_ranks - (skip_seg >= 0 ? 1 : 0)) * per_rank;
+    int t0 = blockIdx.y * tiles_per_slice;   // usable-tile indices (the skipped rank's segment is cut out of the numbering)
     int t_end = t0 + tiles_per_slice;
-    if (t_end > ntiles) t_end = ntiles;
-    auto next = [&](int x) {
-        if (x >= t_end) return t_end;
-        if (g.skip_rank >= 0 && g.col_rank0 + x / per_rank == g.skip_rank) x = (x / per_rank + 1) * per_rank;
-        return x < t_end ? x : t_end;
-    };
+    if (t_end > usable) t_end = usable;
+    auto tile_of = [&](int u) { return (skip_seg >= 0 && u >= skip_seg * per_rank) ? u + per_rank : u; };
+    auto next = [&](int x) { return x < t_end ? x : t_end; };
     const size_t pitch = RB;
-    auto issue = [&](int tile, int stage) {
-        const ColTile c = col_tile(g, tile, QT);
+    auto issue = [&](int u, int stage) {
+        const ColTile c = col_tile(g, tile_of(u), QT);
         issue_tile_dma<RB, NW, QT, 1>(reinterpret_cast<const unsigned char*>(cols) + c.row0 * pitch, lds + stage * TILE,
                                       wave, lane, ((c.mod == rmod) ? wrz_cols : rz_cols) + c.stat0, stat + stage * 128,
                                       SW ? kcols + c.stat0 : nullptr, statk + stage * 128);
@@ -773,7 +771,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
         __syncthreads();
         if (tl[NST - 1] < t_end) issue(tl[NST - 1], (stage + NST - 1) % NST);
         const unsigned char* bt = lds + stage * TILE;
-        const ColTile ct = col_tile(g, tl[0], QT);
+        const ColTile ct = col_tile(g, tile_of(tl[0]), QT);
         // ---- S^T = Xq . Xp^T: two 16x16 fragments (columns 0-15 and 16-31 of the tile), independent chains ----
         f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
         {
@@ -927,7 +925,8 @@ static inline int fast_backward16(const crossclr_plan* p, const Geo& g, const vo
                                   const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
                                   const float* kcols, void* stream) {
     const bool sw = krows != nullptr && kcols != nullptr;
-    const int ntiles = g.col_ranks * 2 * p->bpad / 32;
+    const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
+    const int ntiles = (g.col_ranks - (skipping ? 1 : 0)) * 2 * p->bpad / 32;   // usable column tiles
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
@@ -958,7 +957,8 @@ static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void
                                 const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
                                 const float* kcols, void* stream) {
     const bool sw = krows != nullptr && kcols != nullptr;
-    const int ntiles = g.col_ranks * 2 * p->bpad / 32;
+    const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
+    const int ntiles = (g.col_ranks - (skipping ? 1 : 0)) * 2 * p->bpad / 32;   // usable column tiles
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
     const bf16_t* r = (const bf16_t*)rows;

@@ -467,14 +467,17 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
     const float rzp_intra = wrz_rows[row0 + p_t];
     const float kp = SW ? krows[row0 + p_t] : 1.f;
 
-    const int ntiles = g.col_ranks * 2 * g.bpad / 64;
-    const int t_begin = blockIdx.z * tiles_per_slice;   // column slice z walks its share of the tiles ...
+    // column slice z walks its share of the USABLE tiles (the skipped rank's segment is cut out of the numbering,
+    // so the slices stay balanced) ...
+    const int per_rank = 2 * g.bpad / 64;
+    const int skip_seg = (g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
+    const int usable = (g.col_ranks - (skip_seg >= 0 ? 1 : 0)) * per_rank;
+    const int t_begin = blockIdx.z * tiles_per_slice;
     int t_stop = t_begin + tiles_per_slice;
-    if (t_stop > ntiles) t_stop = ntiles;
+    if (t_stop > usable) t_stop = usable;
     KTileStage<64, 256> sp, sq;
-    for (int t = t_begin; t < t_stop; ++t) {
-        const ColTile ct = col_tile(g, t, 64);
-        if (ct.rank == g.skip_rank) continue;
+    for (int u = t_begin; u < t_stop; ++u) {
+        const ColTile ct = col_tile(g, (skip_seg >= 0 && u >= skip_seg * per_rank) ? u + per_rank : u, 64);
         const unsigned char* cbase = reinterpret_cast<const unsigned char*>(cols) + ct.row0 * pitch;
         // ---------------- phase A ----------------
         f32x16 acc;

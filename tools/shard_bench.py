@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Compute time of ONE rank of an N-rank run, measured on one GPU (no communication): the kernel sequence of the
+sharded step (local block, then the gathered operand with skip_rank) against a synthetic gathered operand.
+Projects the weak-scaling metric B_global^2 / t for N = 1, 2, 4, 8 at b rows per rank (communication excluded).
+usage: shard_bench.py [b] [D]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, crossclr_amd
+from crossclr_amd import _native as nat, loss as L
+from oracle import crossclr_oracle as orc
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+lib, p = nat.library(), L._ptr
+v, t = orc.make_inputs("randn", b, D, 1234)
+v, t = v.cuda(), t.cuda()
+stream = L._stream_for(v)
+f32 = dict(dtype=torch.float32, device="cuda")
+base = None
+for world in (1, 2, 4, 8):
+    rank = world // 2
+    plan = nat.make_plan(b, D, world, rank, nat.MODE_BF16)
+    pp = ctypes.byref(plan)
+    xall = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device="cuda")
+    inv, diag = torch.empty(2 * plan.bpad, **f32), torch.empty(plan.bpad, **f32)
+    for r in range(world):   # every "rank" holds the same rows: values do not matter for timing
+        nat.check(lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32,
+                                         p(xall[r * plan.operand_bytes:]), p(inv), p(diag), stream))
+    xr = xall[rank * plan.operand_bytes:(rank + 1) * plan.operand_bytes]
+    part = torch.empty(plan.fwd_ws_floats, **f32)
+    logz, rz, wrz = (torch.empty(2 * plan.bpad, **f32) for _ in range(3))
+    rzc, wrzc = torch.empty(world * 2 * plan.bpad, **f32), torch.empty(world * 2 * plan.bpad, **f32)
+    ls = torch.empty(plan.loss_ws_doubles, dtype=torch.float64, device="cuda")
+    gbuf = torch.empty(plan.gbuf_bytes // 4, **f32)
+    go = torch.ones(1, dtype=torch.float64, device="cuda")
+    gv, gt = torch.empty_like(v), torch.empty_like(t)
+    stages = {}
+    def run(name, fn):
+        for _ in range(2): nat.check(fn())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): nat.check(fn())
+        e1.record(); torch.cuda.synchronize()
+        stages[name] = e0.elapsed_time(e1) / 5
+    run("normalize", lambda: lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xr), p(inv), p(diag), stream))
+    run("fwd_local", lambda: lib.crossclr_forward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(part), 0, stream))
+    if world > 1:
+        run("fwd_remote", lambda: lib.crossclr_forward(pp, p(xr), p(xall), world, 0, rank, 0.03, 0.8, p(part), plan.fwd_slots, stream))
+    n = (2 if world > 1 else 1) * plan.fwd_slots
+    run("fwd_finish", lambda: lib.crossclr_forward_finish(pp, p(part), n, p(diag), 0.03, 0.8, p(logz), p(rz), p(wrz), p(ls), stream))
+    for r in range(world):
+        rzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = rz
+        wrzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = wrz
+    run("bwd_local", lambda: lib.crossclr_backward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(rz), p(wrz), p(rz), p(wrz), p(gbuf), 0, stream))
+    if world > 1:
+        run("bwd_remote", lambda: lib.crossclr_backward(pp, p(xr), p(xall), world, 0, rank, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc), p(gbuf), 1, stream))
+    run("bwd_finish", lambda: lib.crossclr_backward_finish(pp, p(gbuf), p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(inv), 0.03, p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream))
+    tot = sum(stages.values())
+    val = (b * world) ** 2 / (tot * 1e-3)
+    base = base or val
+    print(f"N={world}: " + " ".join(f"{k}={x:.3f}" for k, x in stages.items()) + f" | compute {tot:.3f} ms/step -> {val:.3e} pairs/s = {val/base:.2f}x of N=1 "
+          f"(all-gather payload in: {(world-1)*plan.operand_bytes/1e6:.0f} MB)")
