@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         const unsigned char* bt = lds + stage * TILE;
         const ColTile ct = col_tile(g, tile_of(t), QT);
         const f32x16 acc = gemm1(bt, ct);
+
         bf16x8 af[2];
         weights(acc, ct, reinterpret_cast<const float*>(stat + stage * 128), reinterpret_cast<const float*>(statk + stage * 128), af);
         // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows), PF-deep fragment ring ----
