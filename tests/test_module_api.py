@@ -109,3 +109,8 @@ def test_reference_import_path_works():
     import importlib
     mod = importlib.import_module("trainer.loss")
     assert mod.CrossCLR_onlyIntraModality is crossclr_amd.CrossCLR_onlyIntraModality
+    # the module's other two top-level names import too; MaxMargin_coot is as unconstructible as in the reference
+    a, b = torch.randn(3, 5), torch.randn(4, 5)
+    assert torch.equal(mod.cosine_sim(a, b), a @ b.t())
+    with pytest.raises(NameError):
+        mod.MaxMargin_coot(use_cuda=False)
