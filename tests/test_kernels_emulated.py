@@ -83,7 +83,7 @@ def test_bf16_generic_kernels_match_bf16_model(monkeypatch):
 @pytest.mark.parametrize("w", [0.0, -0.5, 1.7])
 def test_zero_negative_and_large_negative_weight(w):
     # the masks are applied to the SCALED logit (-inf), so the sign / zero of negative_weight must not matter
-    v, t = orc.make_inputs("randn", 40, 24, 23)
+    v, t = orc.make_inputs("randn", 24, 24, 23)
     ref = orc.streaming_loss_and_grads(v, t, 0.1, w)
     for mode, ltol, gtol in (("fp32", 1e-5, 2e-4), ("bf16", 3e-3, 2e-2)):
         loss, gv, gt = run(v, t, 0.1, w, mode)
@@ -107,7 +107,7 @@ def test_symmetric_forward_upper_triangle(B, D, monkeypatch):
     assert abs(sym - full) <= 1e-6 * max(1.0, abs(full))
 
 
-@pytest.mark.parametrize("B,D", [(8, 16), (70, 48), (150, 100)])
+@pytest.mark.parametrize("B,D", [(8, 16), (70, 48), (100, 70)])
 def test_bf16_16row_backward_matches_reference(B, D, monkeypatch):
     """The 16-row-wavefront backward (v_mfma_f32_16x16x32_bf16; the default for 512 < D <= 1024) forced onto
     small widths so the emulator can run it."""
