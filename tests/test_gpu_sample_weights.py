@@ -88,3 +88,68 @@ def test_influential_sample_module_at_size():
     sc = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
     assert (vd.grad.cpu().double() - ref["grad_v"]).abs().max().item() <= 1e-2 * sc
     assert (td.grad.cpu().double() - ref["grad_t"]).abs().max().item() <= 1e-2 * sc
+
+
+def test_weighted_sharded_kernel_path_on_one_gpu():
+    """One GPU plays 4 ranks through the weighted C-ABI entry points (row weights local, negative scales gathered like
+    the operand): loss and gradients must equal the single-rank weighted result and the float64 oracle."""
+    import ctypes
+    from crossclr_amd import loss as L
+    world, B, D = 4, 1024, 256
+    b = B // world
+    v, t = orc.make_inputs("randn", B, D, 41)
+    kv, kt, ov, ot = weights(B, 6, False)
+    ref = inf.streaming_weighted_loss_and_grads(v, t, 0.03, 0.8, kv, kt, ov, ot)
+    vd, td = v.cuda(), t.cuda()
+    lib, p = nat.library(), L._ptr
+    stream = L._stream_for(vd)
+    f32 = dict(dtype=torch.float32, device="cuda")
+    plans = [nat.make_plan(b, D, world, r, nat.MODE_BF16) for r in range(world)]
+    pl = plans[0]
+    xall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device="cuda")
+    kall = torch.zeros(world, 2, pl.bpad, **f32)
+    lw = torch.zeros(world, 2, pl.bpad, **f32)
+    inv = [torch.empty(2 * pl.bpad, **f32) for _ in range(world)]
+    diag = [torch.empty(pl.bpad, **f32) for _ in range(world)]
+    for r in range(world):
+        sl = slice(r * b, (r + 1) * b)
+        kall[r, 0, :b], kall[r, 1, :b] = kv[sl].cuda(), kt[sl].cuda()
+        lw[r, 0, :b], lw[r, 1, :b] = ov[sl].cuda(), ot[sl].cuda()
+        nat.check(lib.crossclr_normalize(ctypes.byref(plans[r]), p(vd[r * b:]), p(td[r * b:]), vd.stride(0), td.stride(0),
+                                         nat.IN_F32, p(xall[r * pl.operand_bytes:]), p(inv[r]), p(diag[r]), stream))
+    rz, wrz = torch.empty(world, 2 * pl.bpad, **f32), torch.empty(world, 2 * pl.bpad, **f32)
+    total = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+        part = torch.empty(pl.fwd_ws_floats, **f32)
+        nat.check(lib.crossclr_forward_w(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, L._sw(kall[r], kall[r], None), p(part), 0, stream))
+        nat.check(lib.crossclr_forward_w(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, L._sw(kall[r], kall, None), p(part),
+                                         pl.fwd_slots, stream))
+        logz = torch.empty(2 * pl.bpad, **f32)
+        ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device="cuda")
+        nat.check(lib.crossclr_forward_finish_w(pp, p(part), 2 * pl.fwd_slots, p(diag[r]), 0.03, 0.8, L._sw(kall[r], kall[r], lw[r]),
+                                                p(logz), p(rz[r]), p(wrz[r]), p(ls), stream))
+        total += ls[:1]
+    loss = (total / (2.0 * B)).item()
+    gv, gt = torch.empty_like(vd), torch.empty_like(td)
+    go = torch.ones(1, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+        gbuf = torch.empty(pl.gbuf_bytes // 4, **f32)
+        nat.check(lib.crossclr_backward_w(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz[r]), p(wrz[r]),
+                                          L._sw(kall[r], kall[r], None), p(gbuf), 0, stream))
+        nat.check(lib.crossclr_backward_w(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
+                                          L._sw(kall[r], kall, None), p(gbuf), 1, stream))
+        nat.check(lib.crossclr_backward_finish_w(pp, p(gbuf), p(vd[r * b:]), p(td[r * b:]), vd.stride(0), td.stride(0), nat.IN_F32,
+                                                 p(inv[r]), 0.03, L._sw(None, None, lw[r]), p(go), p(gv[r * b:]), p(gt[r * b:]),
+                                                 gv.stride(0), gt.stride(0), stream))
+    torch.cuda.synchronize()
+    assert abs(loss - float(ref["loss"])) <= 1e-3
+    sc = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+    assert (gv.cpu().double() - ref["grad_v"]).abs().max().item() <= 1e-2 * sc
+    assert (gt.cpu().double() - ref["grad_t"]).abs().max().item() <= 1e-2 * sc
+    l1, gv1, gt1 = run(v, t, "bf16", kv, kt, ov, ot)
+    assert abs(loss - l1.item()) <= 1e-6 * max(1.0, abs(loss))
+    assert (gv.cpu() - gv1).abs().max().item() <= 2e-3 * sc
