@@ -215,6 +215,7 @@ def main():
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None,
+                     "hbm_gbps_at_that_traffic": round(traffic["bytes"] / (st[dom] * 1e-3) / 1e9, 1) if traffic else None,
                      "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
                      "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
                      "whole_step_algorithmic_tflops_per_gpu": round(step_tf, 2),
