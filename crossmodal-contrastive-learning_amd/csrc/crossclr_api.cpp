@@ -88,7 +88,8 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     if (b < 1 || D < 1) return fail(CROSSCLR_E_ARG, "need b >= 1 and D >= 1 (got b=%d D=%d)", b, D);
     if (world < 1 || rank < 0 || rank >= world) return fail(CROSSCLR_E_ARG, "bad world/rank %d/%d", world, rank);
     if (mode != CROSSCLR_MODE_FP32 && mode != CROSSCLR_MODE_BF16) return fail(CROSSCLR_E_ARG, "bad mode %d", mode);
-    if ((long long)b * world > (1 << 22)) return fail(CROSSCLR_E_ARG, "global batch too large");
+    // the forward's flat work list is indexed with 32-bit integers: (2b/256 row blocks) x (2B/32 column tiles) < 2^31
+    if ((long long)b * world > (1 << 21)) return fail(CROSSCLR_E_ARG, "global batch %lld too large (limit 2^21 rows)", (long long)b * world);
     memset(plan, 0, sizeof(*plan));
     plan->b = b; plan->D = D; plan->world = world; plan->rank = rank; plan->mode = mode;
     plan->bpad = round_up(b, kRowPad);
