@@ -15,6 +15,10 @@ with an RCCL all-gather of the packed normalised embeddings.
 metric = contrastive pairs per second = B_global^2 / t_step (every video<->text pair of the global
 batch is scored once per step); samples/s = B_global / t_step is reported next to it.
 Rank 0 prints ONE JSON line.
+
+Timing: `--prewarm` (default 40) untimed settle steps, then `--warmup` untimed steps, then exactly `--steps` timed steps
+between barrier + synchronize fences, max over ranks.  The settle steps exist because an MI355X that has just been
+handed to the process runs its first ~20-50 steps ~9 % slower (clock ramp); they are reported as `prewarm_steps`.
 """
 import argparse
 import json
@@ -99,6 +103,9 @@ def main():
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--rows", type=int, default=B_PER_GPU, help="rows per GPU (default = BASELINE config)")
     ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--prewarm", type=int, default=40,
+                    help="untimed device settle steps BEFORE the --warmup steps (GPU clocks / allocator reach steady state "
+                         "only after ~20-50 steps: 0.79 -> 0.72 ms/step); reported in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--influential", action="store_true",
                     help="BASELINE config 5: influential-sample pruning + loss weighting from synthetic input-space "
@@ -157,6 +164,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    for _ in range(max(0, args.prewarm)):
+        step()
     for _ in range(args.warmup):
         loss = step()
     fence()
@@ -199,7 +208,8 @@ def main():
     step_tf = 14.0 * b * B * d / t_step / 1e12  # per-GPU algorithmic fwd+bwd flops over the whole step
     out = {
         "metric": "contrastive-pairs/sec (fwd+bwd)", "value": B * B / t_step, "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm),
+        "ms_per_step": t_step * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
         "samples_per_s": B / t_step,
