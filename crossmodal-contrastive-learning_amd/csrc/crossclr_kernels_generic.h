@@ -307,9 +307,12 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
             if (kind != 0) {
                 const int rb = p / (32 * tpr);
                 count = (fin_prefix(kind, tpr, NT, rb + 1) - 1) / per - fin_prefix(kind, tpr, NT, rb) / per + 1;
-                if (kind == 1)
-                    for (int k = 0; k < rb; ++k) s += (double)colpart[(size_t)k * n + p];
+                if (kind == 1) {
+#pragma unroll 8
+                    for (int k = 0; k < rb; ++k) s += (double)colpart[(size_t)k * n + p];   // independent loads, fixed order
+                }
             }
+#pragma unroll 4
             for (int k = 0; k < count; ++k) s += (double)base[(size_t)k * n + p];
         }
         const bool valid = i < g.b;
