@@ -15,6 +15,13 @@ v, t = orc.make_inputs("randn", b, D, 1234)
 v, t = v.cuda(), t.cuda()
 stream = L._stream_for(v)
 f32 = dict(dtype=torch.float32, device="cuda")
+# settle: a freshly acquired GPU runs its first steps ~9 % slower (bench.py does the same)
+_crit = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()
+_v, _t = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+for _ in range(60):
+    _v.grad = _t.grad = None
+    _crit(_v, _t).backward()
+torch.cuda.synchronize()
 base = None
 for world in (1, 2, 4, 8):
     rank = world // 2
