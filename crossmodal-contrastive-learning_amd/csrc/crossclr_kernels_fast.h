@@ -1,10 +1,11 @@
 // crossclr_kernels_fast.h -- register-resident bf16 kernels (the BASELINE headline path).
 //
 // Shape of both kernels (flash-attention-like, nothing O(B^2) ever leaves the CU):
-//   * a wavefront owns 32 rows p of the batch and keeps their normalised embeddings in VGPRs as
-//     MFMA B-fragments for the whole kernel (Dpad/4 VGPRs: 128 at D=512);
-//   * 64-column tiles of the column operand stream through a 2-deep LDS ring filled by LDS-DMA
-//     (global_load_lds, 16 B/lane), one barrier per tile, the next tile in flight during compute;
+//   * a wavefront owns 32 rows p of the batch (16 in fast_bwd16_kernel) and keeps their normalised embeddings in
+//     VGPRs as MFMA B-fragments for the whole kernel (Dpad/4 VGPRs: 128 at D=512);
+//   * 32-column tiles of the column operand stream through a 4-deep (2-deep for 48/64 KiB tiles) LDS ring filled
+//     by LDS-DMA (global_load_lds, 16 B/lane, wave-uniform base + 32-bit lane offset), one barrier per tile, counted
+//     s_waitcnt vmcnt(N) so that up to three tiles stay in flight during compute;
 //   * S^T = Xq . Xp^T is computed with SWAPPED operands so lane (l&31) owns row p and 16 columns:
 //     row-wise soft-max sums need no cross-lane traffic, and in the backward the 32x32 fragment,
 //     turned into W = s E (1/Z_p + 1/Z_q) and packed to bf16, IS the A operand of the second MFMA
