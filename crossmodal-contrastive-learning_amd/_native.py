@@ -70,6 +70,9 @@ _SIGNATURES = {
     "crossclr_backward_finish_w": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long,
                                                   ctypes.c_int, _P, ctypes.c_float, ctypes.POINTER(SampleWeights), _P, _P, _P,
                                                   ctypes.c_long, ctypes.c_long, _P]),
+    "crossclr_forward_pairs": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                              ctypes.c_float, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P]),
+    "crossclr_forward_add": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_int, _P, _P]),
     "crossclr_influence_colsum": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  _P, _P, _P, _P]),
     "crossclr_influence_conn": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,

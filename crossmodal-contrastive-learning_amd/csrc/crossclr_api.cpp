@@ -56,9 +56,18 @@ extern "C" const char* crossclr_backend(void) {
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// forward workspace ("part") layout, in floats:  [2*fwd_slots slots][2*bpad] | colpart [<= 2*bpad/128 row blocks][2*bpad] | header
-static size_t ws_colpart_off(const crossclr_plan* p) { return (size_t)2 * p->fwd_slots * 2 * p->bpad; }
-static size_t ws_flag_off(const crossclr_plan* p) { return ws_colpart_off(p) + (size_t)(2 * p->bpad / 128 + 1) * 2 * p->bpad; }
+// forward workspace ("part") layout, in floats:
+//   [4 launch groups][fwd_slots][2*bpad] | colpart (symmetric launch) [<= 2*bpad/128 row blocks][2*bpad]
+//   | colpart (pairs launch) [row blocks][(world-1)/2 ranks * 2*bpad] | header [4][4] ints
+// (the symmetric launch's column sums are read by the finish kernel, so the pairs launch needs its own region)
+static const int kLaunchGroups = 4;
+static size_t ws_colpart_off(const crossclr_plan* p) { return (size_t)kLaunchGroups * p->fwd_slots * 2 * p->bpad; }
+static size_t ws_colpart_rows(const crossclr_plan* p) { return (size_t)(2 * p->bpad / 128 + 1); }
+static size_t ws_paircol_off(const crossclr_plan* p) { return ws_colpart_off(p) + ws_colpart_rows(p) * 2 * p->bpad; }
+static size_t ws_flag_off(const crossclr_plan* p) {
+    const size_t k = p->world > 2 ? (size_t)(p->world - 1) / 2 : 0;
+    return ws_paircol_off(p) + ws_colpart_rows(p) * k * 2 * p->bpad;
+}
 
 static int device_zero(void* where, size_t bytes, void* stream) {
 #ifdef CROSSCLR_EMU
@@ -137,6 +146,10 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
             int s3 = fwd_max_slots(fast_forward_work(plan, world, 0, false));
             if (s3 > slots) slots = s3;
         }
+        if (world > 2) {   // crossclr_forward_pairs over (world-1)/2 ranks
+            int s4 = fwd_max_slots(fast_forward_work(plan, (world - 1) / 2, -1, false, true));
+            if (s4 > slots) slots = s4;
+        }
         nsplit = slots;
     }
 #endif
@@ -184,6 +197,7 @@ static int make_geo(const crossclr_plan* p, int col_ranks, int col_rank0, int sk
     if (col_ranks < 1) return fail(CROSSCLR_E_ARG, "col_ranks must be >= 1");
     g->b = p->b; g->bpad = p->bpad; g->D = p->D; g->Dpad = p->Dpad;
     g->col_ranks = col_ranks; g->col_rank0 = col_rank0; g->row_rank = p->rank; g->skip_rank = skip_rank;
+    g->col_wrap = 0;
     const double it = 1.0 / (double)temperature;
     const double aw = fabs((double)negative_weight);
     const double bound = it * (aw > 1.0 ? aw : 1.0);  // |logit| <= bound because the rows are unit vectors
@@ -256,9 +270,10 @@ extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_ro
     Geo g;
     int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g);
     if (rc) return rc;
-    if (slot0 != 0 && slot0 != plan->fwd_slots) return fail(CROSSCLR_E_ARG, "slot0 must be 0 or plan->fwd_slots");
+    if (plan->fwd_slots <= 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
     float* out = part + (size_t)slot0 * 2 * plan->bpad;
-    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + (slot0 == 0 ? 0 : 4);
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
 #ifndef CROSSCLR_NO_FAST
     if (plan->fast_path) {
         // rows and columns are the same packed operand (the single-GPU case and the local block of a
@@ -292,6 +307,49 @@ extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_ro
     return launch_status("fwd_sums_kernel");
 }
 
+extern "C" int crossclr_forward_pairs(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank,
+                                      int nranks, float temperature, float negative_weight,
+                                      const crossclr_sample_weights* sw, float* part, int slot0, float* colsum_out,
+                                      void* stream) {
+    if (!plan || !xhat_rows || !xhat_all || !part || !colsum_out) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_forward_pairs needs the register-resident path");
+#else
+    if (!plan->fast_path) return fail(CROSSCLR_E_ARG, "crossclr_forward_pairs needs the register-resident bf16 path");
+    if (first_rank < 0 || first_rank >= plan->world || nranks < 1 || nranks > (plan->world - 1) / 2)
+        return fail(CROSSCLR_E_ARG, "bad first_rank/nranks %d/%d for world %d", first_rank, nranks, plan->world);
+    if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    for (int i = 0; i < nranks; ++i)
+        if ((first_rank + i) % plan->world == plan->rank) return fail(CROSSCLR_E_ARG, "the pair range must not contain this rank");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = make_geo(plan, nranks, first_rank, -1, temperature, negative_weight, &g);
+    if (rc) return rc;
+    g.col_wrap = plan->world;
+    float* out = part + (size_t)slot0 * 2 * plan->bpad;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    float* colpart = part + ws_paircol_off(plan);
+    rc = fast_forward(plan, g, xhat_rows, xhat_all, out, colpart, header, false, krows, kcols, stream, true);
+    if (rc) return fail(rc, "fast_forward: unsupported Dpad %d", plan->Dpad);
+    const int nrb = 2 * plan->bpad / (32 * fast_fwd_tpr(plan->Dpad));
+    const int ncols = nranks * 2 * plan->bpad;
+    LAUNCH(colsum_reduce_kernel, dim3((ncols + 255) / 256), dim3(256), stream, (const float*)colpart, nrb, ncols, colsum_out);
+    return launch_status("fast_fwd_kernel (pairs)");
+#endif
+}
+
+extern "C" int crossclr_forward_add(const crossclr_plan* plan, float* part, int slot0, const float* vec, void* stream) {
+    if (!plan || !part) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    const int n = 2 * plan->bpad;
+    LAUNCH(fwd_add_kernel, dim3((n + 255) / 256), dim3(256), stream, vec, n, part + (size_t)slot0 * n,
+           reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots));
+    return launch_status("fwd_add_kernel");
+}
+
 extern "C" int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int nslots,
                                        const float* diag_cos, float temperature, float negative_weight,
                                        float* logz, float* rz, float* wrz, double* loss_sum, void* stream) {
@@ -303,9 +361,9 @@ extern "C" int crossclr_forward_finish_w(const crossclr_plan* plan, const float*
                                          const float* diag_cos, float temperature, float negative_weight,
                                          const crossclr_sample_weights* sw, float* logz, float* rz, float* wrz,
                                          double* loss_sum, void* stream) {
-    if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum ||
-        (nslots != plan->fwd_slots && nslots != 2 * plan->fwd_slots))
-        return fail(CROSSCLR_E_ARG, "NULL argument / nslots must be fwd_slots (one launch) or 2*fwd_slots (two)");
+    if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum || plan->fwd_slots <= 0 || nslots <= 0 ||
+        nslots % plan->fwd_slots != 0 || nslots / plan->fwd_slots > kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "NULL argument / nslots must be fwd_slots times the number of launch groups (1..%d)", kLaunchGroups);
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
     if (rc) return rc;

@@ -41,6 +41,8 @@ struct Geo {
     int col_rank0;  // rank id of column segment 0
     int row_rank;   // rank id owning the row operand
     int skip_rank;  // column rank to skip (-1: none)
+    int col_wrap;   // 0: column segment i is rank col_rank0+i at offset i; W > 0: the column operand is the WHOLE gathered
+                    // array of W ranks and segment i is rank (col_rank0+i) mod W at offset of that rank
     float c_inter;  // log2(e)/tau
     float c_intra;  // negative_weight*log2(e)/tau
     float m2;       // soft-max shift, log2 domain
@@ -174,9 +176,14 @@ __device__ __forceinline__ ColTile col_tile(const Geo& g, int t, int W) {
     int per_mod = g.bpad / W;
     ColTile ct;
     ct.rank = g.col_rank0 + seg;
+    int seg_mem = seg;
+    if (g.col_wrap > 0) {
+        if (ct.rank >= g.col_wrap) ct.rank -= g.col_wrap;
+        seg_mem = ct.rank;
+    }
     ct.mod = in_seg / per_mod;
     ct.in_mod0 = (in_seg - ct.mod * per_mod) * W;
-    ct.row0 = (size_t)seg * 2 * g.bpad + (size_t)in_seg * W;
+    ct.row0 = (size_t)seg_mem * 2 * g.bpad + (size_t)in_seg * W;
     ct.stat0 = ct.row0;
     return ct;
 }

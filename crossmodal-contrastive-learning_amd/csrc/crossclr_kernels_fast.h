@@ -183,7 +183,7 @@ __device__ __forceinline__ int halving_elem16(int l31) {
 // A row block's partial row sums land in slot (block - first block touching that row block).
 // ---------------------------------------------------------------------------------------------
 struct FwdWork {
-    int kind;   // 1 symmetric, 2 rectangular (0 in the workspace header = dense slots of the generic kernel)
+    int kind;   // 1 symmetric, 2 rectangular, 3 rectangular + column sums (0 in the workspace header = dense slots)
     int tpr;    // 32-column tiles per row block (= waves per thread block)
     int NB;     // row blocks
     int NT;     // symmetric: column tiles of the operand; rectangular: usable column tiles
@@ -236,7 +236,9 @@ static inline int fwd_max_slots(const FwdWork& w) {
 //  SW (sample weights, include/crossclr.h): the exponential of an intra-modal column q counts k_q times in the row
 //    sums, and -- mirrored -- the exponential of row p counts k_p times in the column sums; the tile's 32 k_q ride
 //    along with the tile DMA (one more 128-byte LDS-DMA per tile).
-template <int DK, bool SYM, int NW, bool SW>
+//  SYM = 2 ("pairs", sharded runs): rectangular like SYM = 0, but EVERY tile also yields its column sums over this rank's
+//    rows -- the row sums the column ranks would otherwise have to compute themselves from the transposed block.
+template <int DK, int SYM, int NW, bool SW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
                                                           float* part, float* colpart, int* header,
                                                           const float* krows, const float* kcols) {
@@ -256,18 +258,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
         header[0] = wk.kind; header[1] = wk.tpr; header[2] = wk.NT; header[3] = wk.per;
     }
     const int per_rank = 2 * g.bpad / QT;
-    const int skip_seg = (!SYM && g.skip_rank >= 0) ? g.skip_rank - g.col_rank0 : -1;
+    const int skip_seg = (SYM == 0 && g.skip_rank >= 0) ? g.skip_rank - g.col_rank0 : -1;
     // flat work items [w, w_end): item -> (row block, column tile)
     int w = blockIdx.x * wk.per;
     int w_end = w + wk.per;
     if (w_end > wk.total) w_end = wk.total;
     struct Cursor { int rb, j; };  // j = index inside the row block's tile list
     auto tile_of = [&](const Cursor& c) {
-        if (SYM) return NW * c.rb + c.j;
+        if (SYM == 1) return NW * c.rb + c.j;
         return (skip_seg >= 0 && c.j >= skip_seg * per_rank) ? c.j + per_rank : c.j;
     };
     auto advance = [&](Cursor& c) {
-        const int n = SYM ? wk.NT - NW * c.rb : wk.NT;
+        const int n = SYM == 1 ? wk.NT - NW * c.rb : wk.NT;
         if (++c.j == n) { c.j = 0; ++c.rb; }
     };
     Cursor cur;
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             float sum = c[tid];
 #pragma unroll
             for (int k = 1; k < NW; ++k) sum += c[k * QT + tid];
-            colpart[(size_t)prb * 2 * g.bpad + QT * ptile + tid] = sum;
+            colpart[(size_t)prb * wk.NT * QT + QT * ptile + tid] = sum;   // row stride = all columns of this launch
         }
     };
     // ring: cq[0] = item w being consumed, cq[1..NST-2] in flight, cq[NST-1] issued after the next barrier
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             for (int r = 0; r < 16; ++r)
                 if (frag_row(r, half) == l31) acc[r] = ninf;
         }
-        const bool upper = SYM && t >= NW * (my_rb + 1);  // strictly right of the diagonal block
+        const bool upper = SYM == 2 || (SYM == 1 && t >= NW * (my_rb + 1));  // strictly right of the diagonal block / any pair tile
         if (upper && (r_in_mod - l31) + 32 > g.b) {      // padding ROWS must not reach the column sums
             if (r_in_mod >= g.b) {
 #pragma unroll
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             pbuf ^= 1;
             if (l31 < 16) cs[pbuf * (NW * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
             pending = true;
-            ptile = t;
+            ptile = SYM == 1 ? t : cq[0].j;   // column position inside this launch's column range
             prb = my_rb;
         }
         stage = (stage + 1) % NST;
@@ -880,16 +882,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 
 static inline int fast_fwd_tpr(int Dpad) { return Dpad <= 512 ? 8 : 4; }   // waves per block = 32-column tiles per row block
 
-static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, int skip_rank, bool symmetric) {
+static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, int skip_rank, bool symmetric, bool pairs = false) {
     const int usable = (col_ranks - (skip_rank >= 0 ? 1 : 0)) * (2 * p->bpad / 32);
-    return fwd_make_work(symmetric ? 1 : 2, p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
+    return fwd_make_work(symmetric ? 1 : (pairs ? 3 : 2), p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
 }
 
 static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
                                float* colpart, int* header, bool symmetric, const float* krows, const float* kcols,
-                               void* stream) {
+                               void* stream, bool pairs = false) {
     const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
-    const FwdWork wk = fast_forward_work(p, g.col_ranks, skipping ? g.skip_rank : -1, symmetric);
+    const FwdWork wk = fast_forward_work(p, g.col_ranks, skipping ? g.skip_rank : -1, symmetric, pairs);
     if (wk.total <= 0) return CROSSCLR_OK;
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
@@ -899,10 +901,12 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols)
 #define CROSSCLR_LF(DK, NW)                                        \
     do {                                                            \
-        if (symmetric && sw) CROSSCLR_LF2(DK, NW, true, true);      \
-        else if (symmetric) CROSSCLR_LF2(DK, NW, true, false);      \
-        else if (sw) CROSSCLR_LF2(DK, NW, false, true);             \
-        else CROSSCLR_LF2(DK, NW, false, false);                    \
+        if (pairs && sw) CROSSCLR_LF2(DK, NW, 2, true);             \
+        else if (pairs) CROSSCLR_LF2(DK, NW, 2, false);             \
+        else if (symmetric && sw) CROSSCLR_LF2(DK, NW, 1, true);    \
+        else if (symmetric) CROSSCLR_LF2(DK, NW, 1, false);         \
+        else if (sw) CROSSCLR_LF2(DK, NW, 0, true);                 \
+        else CROSSCLR_LF2(DK, NW, 0, false);                        \
     } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LF(8, 8); break;

@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
 // ---------------------------------------------------------------------------------------------
 // header[4*L .. 4*L+3] of launch L (written by the forward launch itself): {kind, tpr, NT, per}
 // (tpr = 32-column tiles = 32-row groups per row block: row block I = p / (32*tpr)).
-//   kind 0: dense -- all `slots_per_launch` slots of the launch are valid for every row
+//   kind 0: dense -- header[1] = 0: all `slots_per_launch` slots of the launch are valid for every row;
+//           header[1] = c > 0: the first c slots; header[1] < 0: none (an unused launch group)
 //   kind 1/2: persistent fast forward (symmetric / rectangular): row block I owns slots
 //             0 .. last_block(I) - first_block(I); kind 1 additionally has column sums colpart[I' < I][p]
 __device__ __forceinline__ int fin_prefix(int kind, int tpr, int NT, int rb) {
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
             const int kind = header[4 * L], tpr = header[4 * L + 1], NT = header[4 * L + 2], per = header[4 * L + 3];
             const float* base = part + (size_t)L * slots_per_launch * n;
             int count = slots_per_launch;
+            if (kind == 0 && tpr != 0) count = tpr > 0 ? tpr : 0;
             if (kind != 0) {
                 const int rb = p / (32 * tpr);
                 count = (fin_prefix(kind, tpr, NT, rb + 1) - 1) / per - fin_prefix(kind, tpr, NT, rb) / per + 1;
@@ -331,6 +333,21 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) loss_ws[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// pairs exchange (sharded forward): out[c] = sum over row blocks of the column sums a kind-3 launch left in colpart
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* colpart, int nrb, int ncols, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int rb = 0; rb < nrb; ++rb) s += colpart[(size_t)rb * ncols + c];
+    out[c] = s;
+}
+// a launch group made of ONE ready-made slot (partial sums received from other ranks), or an empty group
+__global__ void __launch_bounds__(256) fwd_add_kernel(const float* vec, int n, float* slot, int* header) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { header[0] = 0; header[1] = vec ? 1 : -1; header[2] = 0; header[3] = 0; }
+    if (vec && i < n) slot[i] = vec[i];
 }
 __global__ void __launch_bounds__(64) fwd_finish_reduce_kernel(double* loss_ws, int nblocks) {
     double acc = 0.0;

@@ -151,7 +151,38 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         ws.xcols = ws.xhat
     nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                      _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, stream))
-    if sharded:
+    # Pair evaluation (bf16 register-resident path, >= 3 ranks): the (r, s) block of the symmetric matrix of exponentials
+    # is evaluated by ONE of the two ranks, which ships its column sums to the other -- 3 instead of 7 remote blocks at
+    # 8 ranks (+ the antipodal one, evaluated by both).  CROSSCLR_DISABLE_PAIR_FORWARD=1: every rank evaluates all blocks.
+    use_pairs = (sharded and plan.fast_path == 1 and world >= 3 and
+                 os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1")
+    if sharded and use_pairs:
+        gather.wait()
+        n2 = 2 * plan.bpad
+        npairs = (world - 1) // 2
+        colsum = torch.empty(npairs * n2, **f32)
+        nat.check(lib.crossclr_forward_pairs(pp, _ptr(ws.xhat), _ptr(ws.xcols), (rank + 1) % world, npairs, ws.temperature,
+                                             ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots,
+                                             _ptr(colsum), stream))
+        if world % 2 == 0:   # the antipodal rank: both sides evaluate their own rows
+            opp = (rank + world // 2) % world
+            sw_opp = None
+            if ws.k_rows is not None:
+                sw_opp = ctypes.pointer(nat.SampleWeights(ws.k_rows.data_ptr(), ws.k_cols.data_ptr() + 4 * opp * n2, 0))
+            nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), ctypes.c_void_p(ws.xcols.data_ptr() + opp * plan.operand_bytes),
+                                             1, opp, -1, ws.temperature, ws.negative_w, sw_opp, _ptr(part),
+                                             2 * plan.fwd_slots, stream))
+        else:
+            nat.check(lib.crossclr_forward_add(pp, _ptr(part), 2 * plan.fwd_slots, None, stream))
+        # ship colsum[k] to rank+1+k: one all-gather of every rank's [world][2*bpad] outbox (zeros elsewhere)
+        outbox = torch.zeros(world, n2, **f32)
+        outbox[[(rank + 1 + k) % world for k in range(npairs)]] = colsum.view(npairs, n2)
+        inbox = torch.empty(world * world * n2, **f32)
+        dist.all_gather_into_tensor(inbox, outbox.view(-1), group=group)
+        received = inbox.view(world, world, n2)[:, rank].sum(0)
+        nat.check(lib.crossclr_forward_add(pp, _ptr(part), 3 * plan.fwd_slots, _ptr(received), stream))
+        nlaunch = 4
+    elif sharded:
         gather.wait()
         nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                          ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, stream))

@@ -88,8 +88,8 @@ int crossclr_normalize(const crossclr_plan* plan, const void* video, const void*
                        void* xhat, float* inv_norm, float* diag_cos, void* stream);
 
 /* Shifted soft-max denominators of the plan's rows against the given columns, into the forward
- * workspace `part` (plan->fwd_ws_floats floats; at most two launches per step: slot0 = 0 and
- * slot0 = fwd_slots):
+ * workspace `part` (plan->fwd_ws_floats floats; up to four launch groups per step: slot0 = L * fwd_slots,
+ * L = 0..3 -- the plain sharded scheme uses two):
  *   part[slot][2*bpad] = sum over the slot's columns q of exp(s(p,q) * xhat_p . xhat_q / tau - shift)
  * with s = 1 across modalities, negative_weight inside a modality, the intra-modal self pair
  * skipped (its exp(0) = 1 is added by crossclr_forward_finish).  Writes `plan->fwd_slots` slots
@@ -103,7 +103,7 @@ int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const voi
                      float temperature, float negative_weight,
                      float* part, int slot0, void* stream);
 
-/* Reduce `nslots` partial slots: logz[2][bpad] (natural log of the full denominator),
+/* Reduce `nslots` (= fwd_slots times the number of launch groups used, 1..4) partial slots: logz[2][bpad] (natural log of the full denominator),
  * rz = 1/Z_shifted, wrz = negative_weight * rz (both 0 on padding rows) and
  * loss_sum[0] = sum over valid rows of (logZv + logZt - 2 A_ii)  (double); loss_sum must hold
  * plan->loss_ws_doubles doubles ([1..] are per-block partials, added in index order).          */
@@ -167,6 +167,22 @@ int crossclr_backward_finish_w(const crossclr_plan* plan, const float* gbuf,
                                const crossclr_sample_weights* sw,
                                const double* grad_out, void* grad_video, void* grad_text,
                                long ld_gvideo, long ld_gtext, void* stream);
+
+/* ---- pair evaluation for sharded runs (ABI version 2) -----------------------------------------------------
+ * Ranks r and s both need the (r, s) block of the stacked matrix of exponentials; it is symmetric, so it is enough
+ * that ONE of them evaluates it: crossclr_forward_pairs evaluates this rank's rows against ranks
+ * first_rank, first_rank+1, ... (mod plan->world; `nranks` of them) of the WHOLE gathered operand `xhat_all`
+ * [world][2][bpad][Dpad], writes this rank's partial row sums to the slots at slot0 like crossclr_forward, AND
+ * colsum_out[nranks][2][bpad] = for each of those ranks' rows the sum over THIS rank's rows -- the partial row sums
+ * that rank needs from this block.  The caller ships colsum_out[i] to rank first_rank+i and feeds what it receives
+ * (summed) back with crossclr_forward_add, which makes a launch group out of one ready-made slot (vec == NULL: an empty
+ * group).  A step may use up to four launch groups (slot0 = L * fwd_slots, L = 0..3; crossclr_forward_finish:
+ * nslots = 4 * fwd_slots then).  bf16 register-resident path only (plan->fast_path); sample weights: sw->neg_scale_cols
+ * is indexed like xhat_all.                                                                                   */
+int crossclr_forward_pairs(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
+                           int first_rank, int nranks, float temperature, float negative_weight,
+                           const crossclr_sample_weights* sw, float* part, int slot0, float* colsum_out, void* stream);
+int crossclr_forward_add(const crossclr_plan* plan, float* part, int slot0, const float* vec, void* stream);
 
 /* ---- influential-sample statistics (ABI version 2; SURVEY.md 8(f) rank 1, not in the reference @ v1) ----
  * From INPUT-space features x[b][Din] of both modalities (any float dtype, row stride ld):

@@ -45,9 +45,14 @@ def _worker(rank, world, port, B, D, mode, q):
         q.put((rank, "error", traceback.format_exc(), 0, 0))
 
 
+# bf16 with >= 3 ranks takes the pair scheme (crossclr_forward_pairs + column-sum exchange): 3 ranks = one pair each,
+# 4 ranks = one pair + the antipodal rank, 5 ranks = two pairs with rank wrap-around
 @pytest.mark.parametrize("world,B,D,mode,ltol,gtol", [(2, 24, 20, "fp32", 1e-5, 2e-4),
                                                        (2, 40, 48, "bf16", 5e-3, 2e-2),
-                                                       (3, 18, 16, "fp32", 1e-5, 2e-4)])
+                                                       (3, 18, 16, "fp32", 1e-5, 2e-4),
+                                                       (3, 24, 16, "bf16", 5e-3, 2e-2),
+                                                       (4, 24, 16, "bf16", 5e-3, 2e-2),
+                                                       (5, 20, 16, "bf16", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()

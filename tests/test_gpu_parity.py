@@ -400,3 +400,68 @@ def test_step_is_hip_graph_capturable():
     torch.cuda.synchronize()
     assert static_loss.item() == eager.item()
     assert torch.equal(sv.grad, ev.grad) and torch.equal(st.grad, et.grad)
+
+
+@pytest.mark.parametrize("world,B,D", [(3, 768, 128), (4, 1024, 256), (5, 640, 512), (8, 2048, 512)])
+def test_pair_forward_scheme_equals_single_device(world, B, D):
+    """crossclr_forward_pairs: every (r, s) block of the symmetric matrix is evaluated by ONE rank, whose column sums
+    become the other rank's partial row sums (crossclr_forward_add).  One GPU plays all ranks; logZ / loss / rz must
+    equal what the plain scheme (every rank evaluates every block) and the single-device run give."""
+    v, t = orc.make_inputs("randn", B, D, 77)
+    vd, td = v.cuda(), t.cuda()
+    lib, p = nat.library(), L._ptr
+    b = B // world
+    stream = L._stream_for(vd)
+    f32 = dict(dtype=torch.float32, device="cuda")
+    plans = [nat.make_plan(b, D, world, r, nat.MODE_BF16) for r in range(world)]
+    pl = plans[0]
+    assert pl.fast_path == 1
+    n2, K = 2 * pl.bpad, (world - 1) // 2
+    xall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device="cuda")
+    inv = [torch.empty(n2, **f32) for _ in range(world)]
+    diag = [torch.empty(pl.bpad, **f32) for _ in range(world)]
+    for r in range(world):
+        nat.check(lib.crossclr_normalize(ctypes.byref(plans[r]), p(vd[r * b:]), p(td[r * b:]), vd.stride(0), td.stride(0),
+                                         nat.IN_F32, p(xall[r * pl.operand_bytes:]), p(inv[r]), p(diag[r]), stream))
+    parts = [torch.empty(pl.fwd_ws_floats, **f32) for _ in range(world)]
+    colsums = [torch.empty(K, n2, **f32) for _ in range(world)]
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+        nat.check(lib.crossclr_forward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(parts[r]), 0, stream))
+        nat.check(lib.crossclr_forward_pairs(pp, p(xr), p(xall), (r + 1) % world, K, 0.03, 0.8, None, p(parts[r]), pl.fwd_slots,
+                                             p(colsums[r]), stream))
+        if world % 2 == 0:
+            opp = (r + world // 2) % world
+            nat.check(lib.crossclr_forward(pp, p(xr), p(xall[opp * pl.operand_bytes:]), 1, opp, -1, 0.03, 0.8, p(parts[r]),
+                                           2 * pl.fwd_slots, stream))
+        else:
+            nat.check(lib.crossclr_forward_add(pp, p(parts[r]), 2 * pl.fwd_slots, None, stream))
+    logz_pairs, loss_pairs = [], torch.zeros(1, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        received = torch.zeros(n2, **f32)
+        for k in range(K):                     # rank (r-1-k) evaluated the pair and computed my sums as its colsum[k]
+            received += colsums[(r - 1 - k) % world][k]
+        nat.check(lib.crossclr_forward_add(pp, p(parts[r]), 3 * pl.fwd_slots, p(received), stream))
+        logz, rz, wrz = (torch.empty(n2, **f32) for _ in range(3))
+        ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device="cuda")
+        nat.check(lib.crossclr_forward_finish(pp, p(parts[r]), 4 * pl.fwd_slots, p(diag[r]), 0.03, 0.8, p(logz), p(rz), p(wrz),
+                                              p(ls), stream))
+        logz_pairs.append(logz)
+        loss_pairs += ls[:1]
+    torch.cuda.synchronize()
+    loss_pairs = (loss_pairs / (2.0 * B)).item()
+    ref = orc.streaming_stats(v, t, 0.03, 0.8)
+    assert abs(loss_pairs - float(ref["loss"])) <= 1e-3
+    # per-row: against the single-device run of the same bf16 kernels (same operands, different summation order only)
+    _, ws1 = L._forward_impl(vd, td, 0.03, 0.8, "bf16", None)
+    torch.cuda.synchronize()
+    p1 = ws1.plan
+    for r in range(world):
+        lz = logz_pairs[r].cpu().double()
+        assert (lz[:b] - ws1.logz[r * b:(r + 1) * b].cpu().double()).abs().max().item() <= 2e-5
+        assert (lz[pl.bpad:pl.bpad + b] - ws1.logz[p1.bpad + r * b:p1.bpad + (r + 1) * b].cpu().double()).abs().max().item() <= 2e-5
+        assert (lz[:b] - ref["logZv"][r * b:(r + 1) * b]).abs().max().item() <= 3e-2     # bf16 operands vs float64
+    loss1 = crossclr_amd.crossclr_loss(vd, td, 0.03, 0.8, compute_mode="bf16").item()
+    assert abs(loss_pairs - loss1) <= 2e-6 * max(1.0, abs(loss1))

@@ -201,9 +201,10 @@ def _worker(rank, world, port, B, D, mode, q):
         q.put((rank, "error", traceback.format_exc(), 0, 0))
 
 
-@pytest.mark.parametrize("mode,ltol,gtol", [("fp32", 1e-4, 1e-3), ("bf16", 5e-3, 2e-2)])
-def test_sharded_weighted_loss_over_gloo(mode, ltol, gtol):
-    world, B, D = 2, 32, 16
+@pytest.mark.parametrize("mode,world,B,ltol,gtol", [("fp32", 2, 32, 1e-4, 1e-3),
+                                                    ("bf16", 3, 24, 5e-3, 2e-2)])   # 3 ranks + bf16: pair scheme, weighted
+def test_sharded_weighted_loss_over_gloo(mode, world, B, ltol, gtol):
+    D = 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000)

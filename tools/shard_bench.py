@@ -50,9 +50,24 @@ for world in (1, 2, 4, 8):
         stages[name] = e0.elapsed_time(e1) / 5
     run("normalize", lambda: lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xr), p(inv), p(diag), stream))
     run("fwd_local", lambda: lib.crossclr_forward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(part), 0, stream))
-    if world > 1:
+    if world > 2:   # pair scheme: (world-1)/2 blocks with column sums (+ the antipodal block when world is even)
+        K = (world - 1) // 2
+        colsum = torch.empty(K * 2 * plan.bpad, **f32)
+        run("fwd_pairs", lambda: lib.crossclr_forward_pairs(pp, p(xr), p(xall), (rank + 1) % world, K, 0.03, 0.8, None, p(part),
+                                                            plan.fwd_slots, p(colsum), stream))
+        if world % 2 == 0:
+            opp = (rank + world // 2) % world
+            run("fwd_antipode", lambda: lib.crossclr_forward(pp, p(xr), p(xall[opp * plan.operand_bytes:]), 1, opp, -1, 0.03, 0.8,
+                                                             p(part), 2 * plan.fwd_slots, stream))
+        else:
+            nat.check(lib.crossclr_forward_add(pp, p(part), 2 * plan.fwd_slots, None, stream))
+        run("fwd_add", lambda: lib.crossclr_forward_add(pp, p(part), 3 * plan.fwd_slots, p(colsum), stream))
+        n = 4 * plan.fwd_slots
+    elif world > 1:
         run("fwd_remote", lambda: lib.crossclr_forward(pp, p(xr), p(xall), world, 0, rank, 0.03, 0.8, p(part), plan.fwd_slots, stream))
-    n = (2 if world > 1 else 1) * plan.fwd_slots
+        n = 2 * plan.fwd_slots
+    else:
+        n = plan.fwd_slots
     run("fwd_finish", lambda: lib.crossclr_forward_finish(pp, p(part), n, p(diag), 0.03, 0.8, p(logz), p(rz), p(wrz), p(ls), stream))
     for r in range(world):
         rzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = rz
