@@ -402,8 +402,9 @@ def test_step_is_hip_graph_capturable():
     assert torch.equal(sv.grad, ev.grad) and torch.equal(st.grad, et.grad)
 
 
-@pytest.mark.parametrize("world,B,D", [(3, 768, 128), (4, 1024, 256), (5, 640, 512), (8, 2048, 512)])
-def test_pair_forward_scheme_equals_single_device(world, B, D):
+@pytest.mark.parametrize("world,B,D,weighted", [(3, 768, 128, False), (4, 1024, 256, False), (5, 640, 512, False),
+                                                (8, 2048, 512, False), (5, 1280, 256, True), (8, 2048, 512, True)])
+def test_pair_forward_scheme_equals_single_device(world, B, D, weighted):
     """crossclr_forward_pairs: every (r, s) block of the symmetric matrix is evaluated by ONE rank, whose column sums
     become the other rank's partial row sums (crossclr_forward_add).  One GPU plays all ranks; logZ / loss / rz must
     equal what the plain scheme (every rank evaluates every block) and the single-device run give."""
@@ -425,16 +426,25 @@ def test_pair_forward_scheme_equals_single_device(world, B, D):
                                          nat.IN_F32, p(xall[r * pl.operand_bytes:]), p(inv[r]), p(diag[r]), stream))
     parts = [torch.empty(pl.fwd_ws_floats, **f32) for _ in range(world)]
     colsums = [torch.empty(K, n2, **f32) for _ in range(world)]
+    kall = None
+    if weighted:   # negative scales in the statistics layout [world][2][bpad]; columns pruned / re-weighted at random
+        gen = torch.Generator().manual_seed(3)
+        kv, kt = (torch.rand(B, generator=gen) > 0.4).float(), 2 * torch.rand(B, generator=gen)
+        kall = torch.zeros(world, 2, pl.bpad, **f32)
+        for r in range(world):
+            kall[r, 0, :b], kall[r, 1, :b] = kv[r * b:(r + 1) * b].cuda(), kt[r * b:(r + 1) * b].cuda()
+    sw = (lambda rows, cols: L._sw(rows, cols, None)) if weighted else (lambda rows, cols: None)
     for r in range(world):
         pp = ctypes.byref(plans[r])
         xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
-        nat.check(lib.crossclr_forward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(parts[r]), 0, stream))
-        nat.check(lib.crossclr_forward_pairs(pp, p(xr), p(xall), (r + 1) % world, K, 0.03, 0.8, None, p(parts[r]), pl.fwd_slots,
-                                             p(colsums[r]), stream))
+        kr = kall[r] if weighted else None
+        nat.check(lib.crossclr_forward_w(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, sw(kr, kr), p(parts[r]), 0, stream))
+        nat.check(lib.crossclr_forward_pairs(pp, p(xr), p(xall), (r + 1) % world, K, 0.03, 0.8, sw(kr, kall), p(parts[r]),
+                                             pl.fwd_slots, p(colsums[r]), stream))
         if world % 2 == 0:
             opp = (r + world // 2) % world
-            nat.check(lib.crossclr_forward(pp, p(xr), p(xall[opp * pl.operand_bytes:]), 1, opp, -1, 0.03, 0.8, p(parts[r]),
-                                           2 * pl.fwd_slots, stream))
+            nat.check(lib.crossclr_forward_w(pp, p(xr), p(xall[opp * pl.operand_bytes:]), 1, opp, -1, 0.03, 0.8,
+                                             sw(kr, kall[opp] if weighted else None), p(parts[r]), 2 * pl.fwd_slots, stream))
         else:
             nat.check(lib.crossclr_forward_add(pp, p(parts[r]), 2 * pl.fwd_slots, None, stream))
     logz_pairs, loss_pairs = [], torch.zeros(1, dtype=torch.float64, device="cuda")
@@ -446,22 +456,25 @@ def test_pair_forward_scheme_equals_single_device(world, B, D):
         nat.check(lib.crossclr_forward_add(pp, p(parts[r]), 3 * pl.fwd_slots, p(received), stream))
         logz, rz, wrz = (torch.empty(n2, **f32) for _ in range(3))
         ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device="cuda")
-        nat.check(lib.crossclr_forward_finish(pp, p(parts[r]), 4 * pl.fwd_slots, p(diag[r]), 0.03, 0.8, p(logz), p(rz), p(wrz),
-                                              p(ls), stream))
+        nat.check(lib.crossclr_forward_finish_w(pp, p(parts[r]), 4 * pl.fwd_slots, p(diag[r]), 0.03, 0.8,
+                                                sw(kall[r] if weighted else None, None), p(logz), p(rz), p(wrz), p(ls), stream))
         logz_pairs.append(logz)
         loss_pairs += ls[:1]
     torch.cuda.synchronize()
     loss_pairs = (loss_pairs / (2.0 * B)).item()
     ref = orc.streaming_stats(v, t, 0.03, 0.8)
-    assert abs(loss_pairs - float(ref["loss"])) <= 1e-3
+    if not weighted:
+        assert abs(loss_pairs - float(ref["loss"])) <= 1e-3
     # per-row: against the single-device run of the same bf16 kernels (same operands, different summation order only)
-    _, ws1 = L._forward_impl(vd, td, 0.03, 0.8, "bf16", None)
+    _, ws1 = L._forward_impl(vd, td, 0.03, 0.8, "bf16", None, (kv.cuda(), kt.cuda()) if weighted else None, None)
     torch.cuda.synchronize()
     p1 = ws1.plan
     for r in range(world):
         lz = logz_pairs[r].cpu().double()
         assert (lz[:b] - ws1.logz[r * b:(r + 1) * b].cpu().double()).abs().max().item() <= 2e-5
         assert (lz[pl.bpad:pl.bpad + b] - ws1.logz[p1.bpad + r * b:p1.bpad + (r + 1) * b].cpu().double()).abs().max().item() <= 2e-5
-        assert (lz[:b] - ref["logZv"][r * b:(r + 1) * b]).abs().max().item() <= 3e-2     # bf16 operands vs float64
-    loss1 = crossclr_amd.crossclr_loss(vd, td, 0.03, 0.8, compute_mode="bf16").item()
+        if not weighted:
+            assert (lz[:b] - ref["logZv"][r * b:(r + 1) * b]).abs().max().item() <= 3e-2     # bf16 operands vs float64
+    loss1 = crossclr_amd.crossclr_loss(vd, td, 0.03, 0.8, compute_mode="bf16",
+                                       negative_scale=(kv.cuda(), kt.cuda()) if weighted else None).item()
     assert abs(loss_pairs - loss1) <= 2e-6 * max(1.0, abs(loss1))
