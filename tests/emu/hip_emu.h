@@ -9,6 +9,8 @@
 // Nothing in the product package includes this file.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -32,12 +34,35 @@ struct dim3 {
 
 namespace emu {
 
+// Barrier for many more threads than cores: arrive on an atomic counter, then yield until the generation flips.
+// (pthread_barrier_t parks every waiter on a futex; with 64-512 threads per block on a handful of cores the wake-ups
+// dominate the emulation time.)
+struct YieldBarrier {
+    std::atomic<int> count{0};
+    std::atomic<int> gen{0};
+    int n = 1;
+    void init(int nthreads) { n = nthreads; count.store(0); gen.store(0); }
+    void wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == g) {
+                if (++spins < 64) continue;
+                sched_yield();
+            }
+        }
+    }
+};
+
 struct WaveCtx {
-    pthread_barrier_t bar;
+    YieldBarrier bar;
     alignas(64) unsigned char slot[64][64];  // per-lane exchange area
 };
 struct BlockCtx {
-    pthread_barrier_t bar;
+    YieldBarrier bar;
     std::vector<WaveCtx*> waves;
     int nthreads;
 };
@@ -50,7 +75,7 @@ extern dim3 g_blockDim, g_gridDim;
 
 inline WaveCtx& my_wave() { return *t_block->waves[t_tid >> 6]; }
 inline int my_lane() { return t_tid & 63; }
-inline void wave_sync() { pthread_barrier_wait(&my_wave().bar); }
+inline void wave_sync() { my_wave().bar.wait(); }
 
 template <typename K, typename... Args>
 void launch(K kernel, dim3 grid, dim3 block, Args... args) {
@@ -63,11 +88,11 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 BlockCtx ctx;
                 ctx.nthreads = nthreads;
-                pthread_barrier_init(&ctx.bar, nullptr, nthreads);
+                ctx.bar.init(nthreads);
                 for (int w = 0; w < nwaves; ++w) {
                     WaveCtx* wc = new WaveCtx;
                     int lanes = nthreads - w * 64 < 64 ? nthreads - w * 64 : 64;
-                    pthread_barrier_init(&wc->bar, nullptr, lanes);
+                    wc->bar.init(lanes);
                     ctx.waves.push_back(wc);
                 }
                 std::vector<std::thread> th;
@@ -82,11 +107,7 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
                     });
                 }
                 for (auto& x : th) x.join();
-                for (auto* wc : ctx.waves) {
-                    pthread_barrier_destroy(&wc->bar);
-                    delete wc;
-                }
-                pthread_barrier_destroy(&ctx.bar);
+                for (auto* wc : ctx.waves) delete wc;
             }
 }
 
@@ -97,7 +118,7 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 #define blockDim (emu::g_blockDim)
 #define gridDim (emu::g_gridDim)
 
-inline void __syncthreads() { pthread_barrier_wait(&emu::t_block->bar); }
+inline void __syncthreads() { emu::t_block->bar.wait(); }
 
 namespace crossclr {
 

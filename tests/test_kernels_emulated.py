@@ -32,10 +32,9 @@ def run(v, t, tau, w, mode, scale=1.0):
     return loss, vv.grad, tt.grad
 
 
-# (the remaining goldens -- float16 inputs, w = 0, tau = 0.1 -- run on the MI355X in tests/test_gpu_parity.py; every
-# emulated launch costs seconds on CPU)
-TINY = ["g2_b8_d16_s1", "g4_b16_d32_s3_float32", "g4_b16_d32_s3_float64", "g4_b16_d32_s3_bfloat16",
-        "g5_zero_row_b16_d32", "g5_b1_d32", "g5_tau002_b32_d64"]
+TINY = ["g2_b8_d16_s1", "g4_b16_d32_s3_float32", "g4_b16_d32_s3_float64", "g4_b16_d32_s3_float16",
+        "g4_b16_d32_s3_bfloat16", "g5_zero_row_b16_d32", "g5_b1_d32", "g5_w0_tau01_b16_d32", "g5_tau01_b16_d32",
+        "g5_tau002_b32_d64"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -81,7 +80,7 @@ def test_bf16_generic_kernels_match_bf16_model(monkeypatch):
     assert np.abs(gv.numpy() - arr["grad_v"]).max() <= 2e-2 * m["grad_v_absmax"]
 
 
-@pytest.mark.parametrize("w", [0.0, -0.5])
+@pytest.mark.parametrize("w", [0.0, -0.5, 1.7])
 def test_zero_negative_and_large_negative_weight(w):
     # the masks are applied to the SCALED logit (-inf), so the sign / zero of negative_weight must not matter
     v, t = orc.make_inputs("randn", 24, 24, 23)

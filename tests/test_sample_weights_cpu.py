@@ -121,7 +121,7 @@ def test_only_one_kind_of_weight():
     check(v, t, "bf16", None, None, ov, ot, 3e-3, 2e-2)
 
 
-@pytest.mark.parametrize("mode,B,D", [("bf16", 150, 32)])   # fp32: on the MI355X (tests/test_gpu_sample_weights.py)
+@pytest.mark.parametrize("mode,B,D", [("fp32", 24, 16), ("bf16", 150, 32)])
 def test_unit_weights_are_bit_identical_to_the_reference_path(mode, B, D):
     v, t = orc.make_inputs("randn", B, D, 8)
     one = torch.ones(B)
