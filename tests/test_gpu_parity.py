@@ -403,7 +403,8 @@ def test_step_is_hip_graph_capturable():
 
 
 @pytest.mark.parametrize("world,B,D,weighted", [(3, 768, 128, False), (4, 1024, 256, False), (5, 640, 512, False),
-                                                (8, 2048, 512, False), (5, 1280, 256, True), (8, 2048, 512, True)])
+                                                (8, 2048, 512, False), (5, 1280, 256, True), (8, 2048, 512, True),
+                                                (4, 1024, 1024, True), (3, 900, 700, False)])   # 4-wave forward (D > 512), ragged
 def test_pair_forward_scheme_equals_single_device(world, B, D, weighted):
     """crossclr_forward_pairs: every (r, s) block of the symmetric matrix is evaluated by ONE rank, whose column sums
     become the other rank's partial row sums (crossclr_forward_add).  One GPU plays all ranks; logZ / loss / rz must
