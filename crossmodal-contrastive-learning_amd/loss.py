@@ -71,7 +71,7 @@ class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
-                 "k_rows", "k_cols", "lw")
+                 "k_rows", "k_cols", "lw", "stats_work")
 
 
 def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor]:
@@ -190,16 +190,15 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                                             ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.logz), _ptr(ws.rz),
                                             _ptr(ws.wrz), _ptr(ws.loss_sum), stream))
     if sharded:
-        stats = torch.cat([ws.rz, ws.wrz])
-        allstats = torch.empty(world * stats.numel(), **f32)
-        dist.all_gather_into_tensor(allstats, stats, group=group)
-        allstats = allstats.view(world, 2, 2 * plan.bpad)
-        ws.rz_cols = allstats[:, 0].contiguous()
-        ws.wrz_cols = allstats[:, 1].contiguous()
+        # the backward's remote launch needs every rank's omega/Z: gathered asynchronously, waited for in the backward
+        # (w * omega/Z of the columns is recomputed there: the same fp32 product the finish kernel forms)
+        ws.rz_cols = torch.empty(world * ws.rz.numel(), **f32)
+        ws.stats_work = dist.all_gather_into_tensor(ws.rz_cols, ws.rz, group=group, async_op=True)
+        ws.wrz_cols = None
         total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
     else:
-        ws.rz_cols, ws.wrz_cols = ws.rz, ws.wrz
+        ws.rz_cols, ws.wrz_cols, ws.stats_work = ws.rz, ws.wrz, None
         total = ws.loss_sum[:1]
     loss = (total / (2.0 * b * world)).reshape(())
     return loss, ws
@@ -218,6 +217,9 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
                                       _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
                                       _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
     if ws.sharded:
+        if ws.wrz_cols is None:
+            ws.stats_work.wait()
+            ws.wrz_cols = ws.rz_cols * ws.negative_w
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                           ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols),
                                           _ptr(ws.wrz_cols), _sw(ws.k_rows, ws.k_cols, None), _ptr(gbuf), 1, stream))
