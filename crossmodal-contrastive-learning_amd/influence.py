@@ -25,7 +25,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _native as nat
-from .loss import _IN_DTYPE, CrossCLR_onlyIntraModality, _ptr, _row_major, _stream_for, crossclr_loss
+from .loss import _IN_DTYPE, CrossCLR_onlyIntraModality, _device_of, _ptr, _row_major, _stream_for, crossclr_loss
 
 
 class PackedPair(tuple):
@@ -41,7 +41,6 @@ def influential_sample_weights(input_vid: torch.Tensor, input_txt: torch.Tensor,
                                temperature_weights: float = 0.0035, process_group=None) -> Tuple[PackedPair, PackedPair]:
     """(negative_scale, loss_weight) for `crossclr_loss` from the input-space features of the LOCAL rows
     (`process_group`: the statistics are those of the concatenated global batch)."""
-    import torch.distributed as dist
     if input_vid.dim() != 2 or input_txt.dim() != 2 or input_vid.shape != input_txt.shape:
         raise RuntimeError("input_vid / input_txt must be [batch, features] tensors of the same shape")
     if input_vid.dtype != input_txt.dtype or input_vid.dtype not in _IN_DTYPE or input_vid.device != input_txt.device:
@@ -50,6 +49,12 @@ def influential_sample_weights(input_vid: torch.Tensor, input_txt: torch.Tensor,
         raise RuntimeError("influential_sample_weights needs inputs on the GPU; there is no CPU fallback")
     lib = nat.library()
     xv, xt = _row_major(input_vid.detach()), _row_major(input_txt.detach())
+    with _device_of(xv):
+        return _influence_impl(lib, xv, xt, score_threshold, temperature_weights, process_group)
+
+
+def _influence_impl(lib, xv, xt, score_threshold, temperature_weights, process_group):
+    import torch.distributed as dist
     b, din = xv.shape
     dev = xv.device
     world = dist.get_world_size(process_group) if process_group is not None else 1

@@ -232,11 +232,27 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     return gv, gt
 
 
+class _device_of:
+    """The C-ABI launches on the stream it is given; HIP requires that stream's device to be current (the inputs may
+    live on another GPU than the process's current one, and the backward runs on an autograd engine thread)."""
+    def __init__(self, t: torch.Tensor):
+        self._guard = torch.cuda.device(t.device) if t.is_cuda else None
+
+    def __enter__(self):
+        if self._guard is not None:
+            self._guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self._guard is not None:
+            self._guard.__exit__(*exc)
+
+
 class _CrossCLRFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, video, text, temperature, negative_w, compute_mode, group, negative_scale, loss_weight):
         video_c, text_c = _row_major(video.detach()), _row_major(text.detach())
-        loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight)
+        with _device_of(video_c):
+            loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight)
         ctx.ws = ws
         ctx.save_for_backward(video_c, text_c)
         return loss
@@ -244,7 +260,8 @@ class _CrossCLRFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         video_c, text_c = ctx.saved_tensors
-        gv, gt = _backward_impl(ctx.ws, video_c, text_c, grad_out)
+        with _device_of(video_c):
+            gv, gt = _backward_impl(ctx.ws, video_c, text_c, grad_out)
         return (gv if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
                 None, None, None, None, None, None)
 
