@@ -14,9 +14,17 @@ every case it can afford to run twice, and refuses to write fixtures otherwise.
 
     python tests/golden/make_golden.py            # small + medium cases
     python tests/golden/make_golden.py --large    # adds B=4096 / B=8192 (12.5 GB RAM, ~1 min)
+    python tests/golden/make_golden.py --check    # regenerate in memory, compare with the committed
+                                                  # index.json / *.npz bit for bit, write nothing
+    python tests/golden/make_golden.py --check --only g1_b64_d256_s0 g2_b8_d16_s1
+
+The reference module is loaded BY FILE PATH under the private name `ref_loss` (the repository
+has its own `trainer/loss.py` drop-in shim, so `import trainer.loss` would find the product, not
+the reference); the script asserts that the class it calls comes from that file.
 """
 import argparse
 import hashlib
+import importlib.util
 import json
 import os
 import sys
@@ -27,10 +35,25 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference")
+REFERENCE_FILE = os.environ.get("CROSSCLR_REFERENCE_FILE", "/root/reference/trainer/loss.py")
+
+
+def load_reference():
+    """The reference class, loaded from its file (never through `import trainer.loss`)."""
+    if not os.path.exists(REFERENCE_FILE):
+        raise SystemExit(f"{REFERENCE_FILE} not found: this script runs only in the build container")
+    spec = importlib.util.spec_from_file_location("ref_loss", REFERENCE_FILE)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = mod.CrossCLR_onlyIntraModality
+    assert ref.__module__ == "ref_loss" and os.path.samefile(mod.__file__, REFERENCE_FILE), \
+        "the class under test is not the reference"
+    assert not hasattr(ref, "compute_mode") and "crossclr_amd" not in sys.modules, "product code leaked in"
+    return ref
+
 
 torch.Tensor.cuda = lambda self, *a, **k: self          # oracle process only
-from trainer.loss import CrossCLR_onlyIntraModality as Reference  # noqa: E402
+Reference = load_reference()
 from oracle import crossclr_oracle as orc                          # noqa: E402
 
 DT = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32,
@@ -54,11 +77,23 @@ def run_reference(v, t, tau, w):
     return loss.detach(), v.grad, t.grad
 
 
+CHECK = {"on": False, "only": None, "bad": [], "seen": 0}
+
+
+def same_arrays(a, b):
+    return set(a) == set(b) and all(a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and
+                                    np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+
+
 def case(name, kind, B, D, seed, tau=0.03, w=0.8, dtype="float32", full=True, mutate=None,
          check_eager=True):
+    if CHECK["only"] is not None and name not in CHECK["only"]:
+        return None
     v, t = orc.make_inputs(kind, B, D, seed, DT[dtype])
     if mutate == "zero_row":
         v[min(3, B - 1)] = 0
+    if mutate == "tiny_row":   # 0 < ||v_3|| < eps of F.normalize: its clamp_min backward drops the projection term
+        v[min(3, B - 1)] *= 1e-14 / float(v[min(3, B - 1)].double().norm())
     loss, gv, gt = run_reference(v, t, tau, w)
     if check_eager:
         el, egv, egt = orc.eager_loss_and_grads(v, t, tau, w)
@@ -87,6 +122,16 @@ def case(name, kind, B, D, seed, tau=0.03, w=0.8, dtype="float32", full=True, mu
         arrays["logZt"] = st["logZt"].numpy()
         arrays["diag"] = st["diag"].numpy()
         meta["streaming_loss"] = float(st["loss"])
+    if CHECK["on"]:
+        CHECK["seen"] += 1
+        committed = {m["name"]: m for m in json.load(open(os.path.join(HERE, "index.json")))["cases"]}.get(name)
+        stored = dict(np.load(os.path.join(HERE, name + ".npz"))) if os.path.exists(os.path.join(HERE, name + ".npz")) else None
+        ok = committed is not None and stored is not None and committed == json.loads(json.dumps(meta)) and \
+            same_arrays(arrays, stored)
+        print(f"{name:28s} {'identical to the committed fixture' if ok else 'DIFFERS from the committed fixture'}")
+        if not ok:
+            CHECK["bad"].append(name)
+        return meta
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
     print(f"{name:28s} loss={meta['loss_repr']:>22s}  |gv|={meta['grad_v_norm']:.6e}")
     return meta
@@ -95,9 +140,17 @@ def case(name, kind, B, D, seed, tau=0.03, w=0.8, dtype="float32", full=True, mu
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare with the committed fixtures instead of writing")
+    ap.add_argument("--only", nargs="*", default=None, help="restrict to these case names")
     args = ap.parse_args()
+    CHECK["on"], CHECK["only"] = args.check, (set(args.only) if args.only else None)
     torch.manual_seed(0)
-    metas = []
+
+    class _Metas(list):
+        def append(self, m):
+            if m is not None:
+                super().append(m)
+    metas = _Metas()
     # G1: BASELINE config 1 (B=64, D=256)
     for s in (0, 7, 1234):
         metas.append(case(f"g1_b64_d256_s{s}", "randn", 64, 256, s))
@@ -116,15 +169,29 @@ def main():
     metas.append(case("g5_ragged_b100_d48", "randn", 100, 48, 5))
     metas.append(case("g5_ragged_b130_d200", "randn", 130, 200, 6, tau=0.05, w=0.5))
     metas.append(case("g5_tau002_b32_d64", "randn", 32, 64, 8, tau=0.02, w=1.0))
+    # small temperatures: |logit| up to 1/tau = 200 / 500, beyond any fixed soft-max shift in fp32 (the reference's
+    # soft-max is float64 with a per-row maximum, loss.py:60,96-100)
+    metas.append(case("g5_tau0005_b32_d64", "randn", 32, 64, 9, tau=0.005, w=0.8))
+    metas.append(case("g5_tau0002_b64_d128", "randn", 64, 128, 10, tau=0.002, w=1.0))
+    metas.append(case("g5_tau0002_aligned_b128_d96", "aligned", 128, 96, 14, tau=0.002, w=0.8))
+    metas.append(case("g5_tau0005_w4_b48_d40", "cluster", 48, 40, 15, tau=0.005, w=4.0))
+    metas.append(case("g5_tiny_row_b16_d32", "randn", 16, 32, 3, mutate="tiny_row"))
     # G6: aligned / clustered (bf16 stress), sampled rows only
     metas.append(case("g6_aligned_b2048_d512", "aligned", 2048, 512, 11, full=False))
     metas.append(case("g6_cluster_b2048_d512", "cluster", 2048, 512, 12, full=False))
     metas.append(case("g6_aligned_b256_d128", "aligned", 256, 128, 13))
+    metas.append(case("g6_tau0005_b2048_d512", "randn", 2048, 512, 16, tau=0.005, full=False))
+    metas.append(case("g6_tau0002_cluster_b1024_d256", "cluster", 1024, 256, 17, tau=0.002, w=1.0, full=False))
     # G7: large
     if args.large:
         metas.append(case("g7_b4096_d512_s1234", "randn", 4096, 512, 1234, full=False))
         metas.append(case("g7_b8192_d512_s1234", "randn", 8192, 512, 1234, full=False,
                           check_eager=False))
+    if args.check:
+        if CHECK["bad"] or not CHECK["seen"]:
+            raise SystemExit(f"golden check FAILED: {CHECK['bad'] or 'no case selected'}")
+        print(f"golden check ok: {CHECK['seen']} cases regenerated from {REFERENCE_FILE} match the committed fixtures")
+        return
     out = os.path.join(HERE, "index.json")
     prev = {}
     if os.path.exists(out):

@@ -1,10 +1,14 @@
 """The oracle against the committed golden vectors (generated from the reference
 by tests/golden/make_golden.py).  CPU only."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_arrays, golden_index, golden_inputs
+from conftest import GOLDEN_DIR, golden_arrays, golden_index, golden_inputs
 from oracle import crossclr_oracle as orc
 
 IDX = golden_index()
@@ -37,7 +41,10 @@ def test_streaming_form_matches_reference(name):
         for k, g in (("grad_v", out["grad_v"]), ("grad_t", out["grad_t"])):
             ref = arr[k].astype(np.float64)
             err = np.abs(g.numpy() - ref).max()
-            assert err <= 5e-6 * max(np.abs(ref).max(), 1e-30), (k, err)
+            # the reference forms its logits from an fp32 GEMM (loss.py:83-93): a 6e-8 rounding of a cosine is a
+            # 6e-8/tau error of the logit, i.e. of the relative size of a soft-max weight
+            rtol = max(5e-6, 2e-7 / m["temperature"])
+            assert err <= rtol * max(np.abs(ref).max(), 1e-30), (k, err)
     # the stored per-row intermediates were produced from the fp32 cast of the inputs
     atol = 1e-9 if m["dtype"] == "float32" else 1e-5
     for k in ("logZv", "logZt", "diag"):
@@ -89,3 +96,15 @@ def test_bf16_operand_model_is_inside_the_loss_bar():
         v, t = golden_inputs(m)
         model = float(orc.bf16_operand_model_loss(v, t, m["temperature"], m["negative_weight"]))
         assert abs(model - m["loss"]) < 1e-3
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/trainer/loss.py"),
+                    reason="the reference exists only in the build container")
+def test_golden_recipe_regenerates_the_committed_fixtures_from_the_reference():
+    """`make_golden.py --check` imports the reference BY FILE PATH, regenerates the small cases in memory and
+    compares them with the committed index.json / *.npz bit for bit (VERDICT r01, weak #1)."""
+    names = [n for n, m in IDX.items() if m["B"] <= 256]
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN_DIR, "make_golden.py"), "--check", "--only"] + names,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"golden check ok: {len(names)} cases" in r.stdout
