@@ -19,7 +19,7 @@ HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcro
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Plan(ctypes.Structure):
@@ -29,7 +29,7 @@ class Plan(ctypes.Structure):
                 ("fwd_ws_floats", ctypes.c_size_t),
                 ("bwd_slices", ctypes.c_int),
                 ("loss_ws_doubles", ctypes.c_int),
-                ("operand_bytes", ctypes.c_size_t), ("gbuf_bytes", ctypes.c_size_t)]
+                ("operand_bytes", ctypes.c_size_t), ("gbuf_bytes", ctypes.c_size_t), ("stash_bytes", ctypes.c_size_t)]
 
 
 class SampleWeights(ctypes.Structure):
@@ -72,6 +72,11 @@ _SIGNATURES = {
                                                   ctypes.c_long, ctypes.c_long, _P]),
     "crossclr_forward_pairs": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                               ctypes.c_float, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P]),
+    # ABI version 3: save-for-backward pair
+    "crossclr_forward_save": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_float, ctypes.c_float,
+                                             ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P]),
+    "crossclr_backward_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
+                                               ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     "crossclr_forward_add": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_int, _P, _P]),
     "crossclr_influence_colsum": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  _P, _P, _P, _P]),

@@ -17,9 +17,12 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
                 compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None
                 ) -> Dict[str, float]:
     """Average milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
-    backward, backward_finish); with sample weights the `_w` entry points are the ones timed."""
+    backward, backward_finish; forward_save / backward_saved when the plan has the save-for-backward pair -- those two
+    are what a training step launches, `forward` / `backward` are the recomputing entry points);
+    with sample weights the `_w` entry points are the ones timed."""
     lib = nat.library()
-    _, ws = L._forward_impl(video, text, temperature, negative_w, compute_mode, None, negative_scale, loss_weight)
+    _, ws = L._forward_impl(video, text, temperature, negative_w, compute_mode, None, negative_scale, loss_weight,
+                            save_for_backward=True)
     sw_k, sw_all, sw_lw = L._sw(ws.k_rows, ws.k_rows, None), L._sw(ws.k_rows, ws.k_rows, ws.lw), L._sw(None, None, ws.lw)
     plan, pp = ws.plan, ctypes.byref(ws.plan)
     dev = video.device
@@ -31,6 +34,7 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
     gv, gt = torch.empty_like(video), torch.empty_like(text)
     t, w = ws.temperature, ws.negative_w
 
+    stash = ws.stash   # None when the plan has no save-for-backward path
     stages = {
         "normalize": lambda: lib.crossclr_normalize(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
                                                     p(ws.xhat), p(ws.inv_norm), p(ws.diag), stream),
@@ -39,12 +43,17 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
                                                                 p(ws.logz), p(ws.rz), p(ws.wrz), p(ws.loss_sum), stream),
         "backward": lambda: lib.crossclr_backward_w(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(ws.rz), p(ws.wrz),
                                                     p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream),
+        "forward_save": (lambda: lib.crossclr_forward_save(pp, p(ws.xhat), t, w, sw_k, p(part), 0, p(stash), stream)) if stash is not None else None,
+        "backward_saved": (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
+                                                               p(gbuf), 0, stream)) if stash is not None else None,
         "backward_finish": lambda: lib.crossclr_backward_finish_w(pp, p(gbuf), p(video), p(text), video.stride(0),
                                                                   text.stride(0), ws.in_dtype, p(ws.inv_norm), t, sw_lw,
                                                                   p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
     }
     out = {}
     for name, fn in stages.items():
+        if fn is None:
+            continue
         for _ in range(warmup):
             nat.check(fn())
         e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
@@ -56,4 +65,8 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
         torch.cuda.synchronize(dev)
         out[name] = sum(a.elapsed_time(b) for a, b in zip(e0, e1)) / iters
     out["fast_path"] = float(plan.fast_path)
+    out["saved_path"] = float(stash is not None)
+    # the stages a training step actually runs
+    out["step_forward"] = out.get("forward_save", out["forward"])
+    out["step_backward"] = out.get("backward_saved", out["backward"])
     return out

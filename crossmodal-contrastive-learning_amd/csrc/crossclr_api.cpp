@@ -186,6 +186,10 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     const size_t esz = mode == CROSSCLR_MODE_FP32 ? 4 : 2;
     plan->operand_bytes = (size_t)2 * plan->bpad * plan->Dpad * esz;
     plan->gbuf_bytes = (size_t)plan->bwd_slices * 2 * plan->bpad * plan->Dpad * 4;
+    plan->stash_bytes = 0;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->fast_path && plan->fast_bwd && !getenv("CROSSCLR_DISABLE_SAVE")) plan->stash_bytes = fast_stash_bytes(plan->bpad, plan->Dpad);
+#endif
     return CROSSCLR_OK;
 }
 
@@ -305,6 +309,47 @@ extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_ro
         else LAUNCH((fwd_sums_kernel<bf16_t, false>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out, kcols);
     }
     return launch_status("fwd_sums_kernel");
+}
+
+extern "C" int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
+                                     const crossclr_sample_weights* sw, float* part, int slot0, void* stash, void* stream) {
+    if (!plan || !xhat || !part || !stash || slot0 < 0) return fail(CROSSCLR_E_ARG, "NULL/negative argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_forward_save needs the register-resident path");
+#else
+    if (!plan->stash_bytes) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path (stash_bytes == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    if (krows != kcols) return fail(CROSSCLR_E_ARG, "the local block's row and column negative scales are the same array");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
+    if (rc) return rc;
+    if (plan->fwd_slots <= 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    float* out = part + (size_t)slot0 * 2 * plan->bpad;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    rc = fast_forward_save(plan, g, xhat, out, part + ws_colpart_off(plan), header, krows, stash, stream);
+    return rc ? fail(rc, "fast_forward_save: unsupported Dpad %d", plan->Dpad) : launch_status("fast_fwd_kernel (save)");
+#endif
+}
+
+extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash, float temperature,
+                                       float negative_weight, const float* rz, const float* wrz,
+                                       const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat || !stash || !rz || !wrz || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_saved needs the register-resident path");
+#else
+    if (!plan->stash_bytes) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path (stash_bytes == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    if (krows != kcols) return fail(CROSSCLR_E_ARG, "the local block's row and column negative scales are the same array");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
+    if (rc) return rc;
+    rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, gbuf, accumulate, krows, stream);
+    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_saved_kernel");
+#endif
 }
 
 extern "C" int crossclr_forward_pairs(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank,

@@ -21,6 +21,7 @@
 #pragma once
 #include "crossclr_device.h"
 #include "../../include/crossclr.h"
+#include <utility>
 
 namespace crossclr {
 
@@ -38,6 +39,32 @@ __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" :
 // wait until at most N of this wave's most recent VMEM operations are still in flight
 template <int N> __device__ __forceinline__ void wait_dma_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// LDS byte address of a generic pointer into __shared__ memory
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// Transpose read issued from inline asm: hipcc's s_waitcnt pass treats the ds_read_tr BUILTIN as "may alias every LDS-DMA
+// in flight" and puts s_waitcnt vmcnt(0) in front of it, which drains the whole DMA ring in the middle of every tile.
+// The asm form is invisible to that pass; its completion is counted by hand: wait_lgkm<N>(x) makes x usable once at most
+// N younger LDS operations of this wave are still in flight (LDS returns in order), and -- naming x as read-write --
+// keeps every consumer of x below the wait.
+template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr16_b64_async(unsigned addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(s16x4& a, s16x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+// workgroup barrier that does NOT drain VMEM (an LDS-DMA ring stays in flight across it): LDS operations only
+__device__ __forceinline__ void barrier_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+__device__ __forceinline__ unsigned long lds_addr(const void* p) { return (unsigned long)(uintptr_t)p; }
+template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr16_b64_async(unsigned long addr) {
+    return lds_read_tr16_b64(reinterpret_cast<const unsigned char*>(addr) + OFF);
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(s16x4&, s16x4&) {}
+__device__ __forceinline__ void barrier_keep_dma() { __syncthreads(); }
 #endif
 
 // Tuning switches (compile-time; defaults = best measured on MI355X, see profiles/):
@@ -238,10 +265,24 @@ static inline int fwd_max_slots(const FwdWork& w) {
 //    along with the tile DMA (one more 128-byte LDS-DMA per tile).
 //  SYM = 2 ("pairs", sharded runs): rectangular like SYM = 0, but EVERY tile also yields its column sums over this rank's
 //    rows -- the row sums the column ranks would otherwise have to compute themselves from the transposed block.
-template <int DK, int SYM, int NW, bool SW>
+//  ST (save for backward, SYM = 1 only): every evaluated 32x32 tile of exponentials is also written to `stash` as bf16, in
+//    the layout of the MFMA A fragment the backward feeds on (lane = row p, 8 k-slots per 16-column half: the C layout
+//    of this kernel's product, so the store is two coalesced 1-KiB wave stores and costs 8 v_cvt_pk per tile).  Tile
+//    (r32, t) -- 32-row group r32, 32-column tile t >= NW * (r32 / NW) -- lives at stash_tile_index(...) * 2 KiB.
+//    fast_bwd_saved_kernel turns it into W = E (1/Z_p + 1/Z_q) without recomputing the similarity product.
+__host__ __device__ __forceinline__ size_t stash_tile_index(int tpr, int NT, int r32, int t) {
+    const size_t rb = (size_t)(r32 / tpr), w = (size_t)(r32 % tpr);
+    const size_t before = (size_t)tpr * (rb * NT - (size_t)(tpr / 2) * rb * (rb - 1));   // tiles of row blocks < rb
+    return before + w * ((size_t)NT - tpr * rb) + ((size_t)t - tpr * rb);
+}
+static inline size_t stash_tiles_total(int tpr, int NT) { return stash_tile_index(tpr, NT, NT, NT); }
+
+template <int DK, int SYM, int NW, bool SW, bool ST = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
                                                           float* part, float* colpart, int* header,
-                                                          const float* krows, const float* kcols) {
+                                                          const float* krows, const float* kcols,
+                                                          unsigned char* stash) {
+    static_assert(!ST || SYM == 1, "the exponentials are saved by the symmetric launch only");
     constexpr int RB = DK * 32;            // bytes per operand row
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
@@ -318,6 +359,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
     int stage = 0;
     int my_rb = -1, row0w = 0, rmod = 0, r_in_mod = 0;
     float rowacc = 0.f, kp = 1.f;
+    size_t st_tile0 = 0;   // ST: stash index of this wave's tile j = 0 of the current row block
     bf16x8 pf[DK];
     auto store_rows = [&]() {
         float v = rowacc + wave_xor_f32(rowacc, 32);
@@ -332,6 +374,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             rmod = row0w / g.bpad;
             r_in_mod = row0w - rmod * g.bpad + l31;
             if (SW) kp = krows[row0w + l31];
+            if (ST) st_tile0 = stash_tile_index(NW, wk.NT, NW * my_rb + wave, NW * my_rb);
             if (CROSSCLR_FABL & 16) {
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
@@ -406,6 +449,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
             }
         }
         float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
+        if (ST) {   // save the tile for the backward: registers 8th .. 8th+7 are the A fragment of k-step th
+            unsigned char* dst = stash + (st_tile0 + (size_t)cq[0].j) * 2048 + lane * 16;
+#pragma unroll
+            for (int th = 0; th < 2; ++th) {
+                struct { bf16_t v[8]; } pk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[8 * th + j]);
+                *reinterpret_cast<u32x4*>(dst + 1024 * th) = __builtin_bit_cast(u32x4, pk);
+            }
+        }
         if (SW && same_mod) {
             const float* kq = reinterpret_cast<const float*>(lds + KQ0 + stage * 128);
 #pragma unroll
@@ -413,17 +468,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
                 const f32x4 k4 = *reinterpret_cast<const f32x4*>(kq + 8 * r4 + 4 * half);   // columns frag_row(4 r4 + j, half)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float x = fast_exp2(acc[4 * r4 + j]);
-                    rowacc += x * k4[j];
-                    e[4 * r4 + j] = x * kp;     // what the mirrored tile's rows (these columns) see of row p
+                    rowacc += e[4 * r4 + j] * k4[j];
+                    e[4 * r4 + j] *= kp;        // what the mirrored tile's rows (these columns) see of row p
                 }
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
-                rowacc += e[r];
-            }
+            for (int r = 0; r < 16; ++r) rowacc += e[r];
         }
         if (upper) {
             const float colsum = (CROSSCLR_FABL & 8) ? e[l31 & 15] : halving_sum16(e, l31);
@@ -674,6 +725,218 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward from the SAVED exponentials (single-device step / local block of a sharded run, Dpad <= 512).
+// The symmetric forward (ST) left every evaluated 32x32 tile of E = exp(logit - shift) in HBM as the bf16 A fragment
+// of this kernel's product, so the similarity product is not recomputed: per 32-column tile a wave only forms
+//   W[p][q] = E[p][q] * (omega_p/Z_p + omega_q/Z_q)            (2 ds_read_b128 or 4 transpose reads + 56 VALU)
+//   G[p][:] += W[p][q] . Xq[q][:]                               (32 MFMAs, B fragments by ds_read_b64_tr_b16)
+// i.e. it executes exactly the algorithmic 8 B^2 D flop (fast_bwd_kernel: 16 B^2 D).  The tile of the mirrored half
+// of the matrix (column tile t left of the wave's own 256-row block) was never evaluated: it is the TRANSPOSE of
+// stash tile (t, r32), read through the 16-lane transpose read from an image whose 16-byte chunks were permuted by
+// the DMA source address so that one tr-read delivers k-slots (q) for the lane's own row p -- after the read both
+// cases hold the same logical fragment and share all code.
+// 4 waves x 32 rows per block, ONE wave per SIMD (32 x Dpad fp32 accumulators = 256 AGPRs at D = 512; the 128 VGPRs
+// of row fragments the recomputing kernel needs are gone).  Rings: column tiles NSX deep (32 KiB each at D = 512),
+// saved-exponential tiles NSE deep (2 KiB per wave, they come from HBM rather than L2, so they are fetched further
+// ahead).  Every iteration issues the same number of VMEM operations (past the end the last tile is re-fetched), so ONE
+// counted s_waitcnt vmcnt(NKEEP) per tile is exact.
+// HBM per launch: the stash is read once directly and once transposed (2 x 0.27 GB at B = 8192) -- O(B^2) bytes, which is
+// the price of not recomputing; the kernel stays MFMA-bound.
+// ---------------------------------------------------------------------------------------------
+template <int I> struct IdxC { static constexpr int value = I; };
+template <int... Is, typename F> __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F&& f) {
+    (f(IdxC<Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int DK, bool SW>
+__global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
+                                                                const float* rz, const float* wrz, float* gbuf,
+                                                                int accumulate, int tiles_per_slice, const float* ks) {
+    constexpr int RB = DK * 32;
+    constexpr int QT = 32;
+    constexpr int TILE = QT * RB;
+    constexpr int TPR = 8;                 // 32-row groups per row block of the forward that wrote the stash (Dpad <= 512)
+    constexpr int NSX = 3;                 // column-tile ring
+    constexpr int NSE = 6;                 // saved-exponential ring
+    constexpr int ESTG = 4 * 2048;         // one stage of the E ring: [4 waves][2 KiB]
+    constexpr int DT = DK / 2;             // 32-wide output fragments
+    constexpr int NI = 2 * DT;             // MFMAs per tile: (k-step tp, output fragment dt)
+    constexpr int PF = (CROSSCLR_PF < NI / 2) ? CROSSCLR_PF : NI / 2;   // transpose-read pairs in flight ahead of their MFMA
+    constexpr int NX = DK / 4 + 1 + (SW ? 1 : 0);          // VMEM operations of one column tile per wave
+    constexpr int NKEEP = 2 + (NSX - 2) * (NX + 2);        // operations issued after X(t) that may still be in flight
+    static_assert(NSX * TILE + NSE * ESTG + NSX * 256 <= 160 * 1024, "LDS budget");
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NSX * TILE + NSE * ESTG + NSX * 256];
+    unsigned char* ebuf = lds + NSX * TILE;
+    unsigned char* stat = ebuf + NSE * ESTG;     // [NSX][32] floats: omega/Z (or w omega/Z) of the tile's columns
+    unsigned char* statk = stat + NSX * 128;     // SW: [NSX][32] floats: k of the tile's columns
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int row0w = blockIdx.x * 128 + 32 * wave;
+    const int r32 = uniform(row0w >> 5);
+    const int NT = 2 * g.bpad / QT;              // column tiles; the first NT/2 are modality 0
+    const int rmod = (2 * r32 >= NT) ? 1 : 0;
+    const int rb0 = (r32 / TPR) * TPR;           // first tile the forward evaluated for this wave's rows
+
+    const float rzp_inter = rz[row0w + l31];
+    const float rzp_intra = wrz[row0w + l31];
+    const float kp = SW ? ks[row0w + l31] : 1.f;
+
+    // transpose-read roles (column tile): in a 16-lane group lane 4j+c addresses row j, 8-byte piece c
+    const int grp = lane >> 4, i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3, dsub = grp & 1;
+    int comb[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            comb[k][u] = (4 * half + jrow) * RB + 64 * (k ^ jrow) + 16 * ((2 * dsub + (piece >> 1)) ^ (2 * u + half)) +
+                         8 * (piece & 1);
+    // saved-exponential tile.  direct: the 2-KiB fragment image as stored, lane-linear.  transposed: 16-byte chunk
+    // (th_s, hf, rho) of stash tile (t, r32) [row rho = a column q of ours, chunk = 8 of OUR rows] goes to LDS slot
+    // 16*(rho>>2) + (rho&3) + 4*hf + 8*th_s, so that the four rows a transpose read gathers sit in one 256-byte line
+    // and its 32 lanes touch 32 different 8-byte words (conflict-free); the permutation rides on the DMA source address.
+    // (separate scalars, not arrays: hipcc turns a select between two arrays into a scratch array indexed by the condition)
+    const unsigned eoff_d0 = (unsigned)(lane * 16);
+    const unsigned eoff_t0 = (unsigned)((((lane >> 3) & 1) * 64 + ((lane >> 2) & 1) * 32 + ((lane >> 4) * 4 + (lane & 3))) * 16);
+    // transposed read: lane (half, g1 = grp&1, jj = jrow, c = piece) addresses row rho = 16th + 8u + 4half + jj, chunk
+    // (hf = c&1, th_s = g1), 8-byte half c>>1  ->  th*1024 + u*512 + [half*256 + (jj + 4(c&1) + 8 g1)*16 + 8(c>>1)]
+    const int etr = half * 256 + (jrow + 4 * (piece & 1) + 8 * dsub) * 16 + 8 * (piece >> 1);
+
+    f32x16 acc2[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
+
+    int t = blockIdx.y * tiles_per_slice;
+    int t_end = t + tiles_per_slice;
+    if (t_end > NT) t_end = NT;
+    auto issue_x = [&](int u, int stage) {
+        if (u >= t_end) u = t_end - 1;     // past the end: re-fetch the last tile (keeps the VMEM count per iteration fixed)
+        const bool same = ((2 * u >= NT) ? 1 : 0) == rmod;
+        issue_tile_dma<RB, 4, QT>(reinterpret_cast<const unsigned char*>(cols) + (size_t)u * TILE, lds + stage * TILE, wave,
+                                  lane, (same ? wrz : rz) + QT * u, stat + stage * 128,
+                                  SW ? ks + QT * u : nullptr, statk + stage * 128);
+    };
+    auto issue_e = [&](int u, int estage) {
+        if (u >= t_end) u = t_end - 1;
+        const bool direct = u >= rb0;
+        const size_t idx = direct ? stash_tile_index(TPR, NT, r32, u) : stash_tile_index(TPR, NT, u, r32);
+        const unsigned char* src = stash + idx * 2048;
+        unsigned char* dst = ebuf + estage * ESTG + wave * 2048;
+        const unsigned o0 = direct ? eoff_d0 : eoff_t0;      // second half (LDS chunks 64..127): +1 KiB direct, +16 rows transposed
+        const unsigned o1 = o0 + (direct ? 1024u : 256u);
+        lds_dma16(src + o0, dst);
+        lds_dma16(src + o1, dst + 1024);
+    };
+    struct Pair { s16x4 lo, hi; };
+
+    if (t < t_end) {
+#pragma unroll
+        for (int k = 0; k < NSE - 1; ++k) issue_e(t + k, k);
+#pragma unroll
+        for (int k = 0; k < NSX - 1; ++k) issue_x(t + k, k);
+    }
+    int sx = 0, se = 0;
+    for (; t < t_end; ++t) {
+        wait_dma_keep<NKEEP>();     // X(t), E(t) and this tile's statistics have landed
+        barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1
+        issue_x(t + NSX - 1, sx == 0 ? NSX - 1 : sx - 1);
+        issue_e(t + NSE - 1, se == 0 ? NSE - 1 : se - 1);
+        const unsigned char* bt = lds + sx * TILE;
+        const unsigned char* eb = ebuf + se * ESTG + wave * 2048;
+        // ---- the lane's saved exponentials: row p = l31, k-slot j of k-step th <-> column 16th + 8(j>>2) + 4half + (j&3)
+        bf16x8 ef[2];
+        if (t >= rb0) {
+#pragma unroll
+            for (int th = 0; th < 2; ++th) ef[th] = *reinterpret_cast<const bf16x8*>(eb + 1024 * th + 16 * lane);
+        } else {
+            const auto ea = lds_addr(eb + etr);
+            Pair p0, p1;
+            p0.lo = lds_read_tr16_b64_async<0>(ea);
+            p0.hi = lds_read_tr16_b64_async<512>(ea);
+            p1.lo = lds_read_tr16_b64_async<1024>(ea);
+            p1.hi = lds_read_tr16_b64_async<1536>(ea);
+            wait_lgkm<0>(p0.lo, p0.hi);
+            wait_lgkm<0>(p1.lo, p1.hi);
+            ef[0] = __builtin_bit_cast(bf16x8, p0);
+            ef[1] = __builtin_bit_cast(bf16x8, p1);
+        }
+        // ---- W = E (omega_p/Z_p + omega_q/Z_q), packed to bf16: the A fragments of the product ----
+        const bool same_mod = ((2 * t >= NT) ? 1 : 0) == rmod;
+        const bool weighted = SW && same_mod;
+        const float rzp = same_mod ? rzp_intra : rzp_inter;
+        const float* rzq = reinterpret_cast<const float*>(stat + sx * 128);
+        const float* kqs = reinterpret_cast<const float*>(statk + sx * 128);
+        bf16x8 af[2];
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            struct Bits8 { bf16_t e[8]; };
+            const Bits8 ev = __builtin_bit_cast(Bits8, ef[th]);
+            Bits8 pk;
+#pragma unroll
+            for (int r4 = 0; r4 < 2; ++r4) {
+                const int q0 = 16 * th + 8 * r4 + 4 * half;
+                const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
+                f32x4 kq = {1.f, 1.f, 1.f, 1.f};
+                if (weighted) kq = *reinterpret_cast<const f32x4*>(kqs + q0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
+                    const float zz = weighted ? (rzp * kq[j] + rq[j] * kp) : (rzp + rq[j]);
+                    pk.e[4 * r4 + j] = f32_to_bf16_bits(v * zz);
+                }
+            }
+            af[th] = __builtin_bit_cast(bf16x8, pk);
+        }
+        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows).  Item i = (k-step tp = i / DT, output
+        // fragment dt = i % DT); the B fragments are two transpose reads of the column tile, PF items ahead of their MFMA.
+        {
+            const auto xa = lds_addr(bt);
+            decltype(lds_addr(bt)) base[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) base[k][u] = xa + comb[k][u];
+            Pair ring[PF];
+            auto fetch = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int tp = i / DT, dt = i % DT;
+                ring[i % PF].lo = lds_read_tr16_b64_async<(16 * tp) * RB + 256 * (dt >> 2)>(base[dt & 3][0]);
+                ring[i % PF].hi = lds_read_tr16_b64_async<(16 * tp + 8) * RB + 256 * (dt >> 2)>(base[dt & 3][1]);
+            };
+            static_for<PF>([&](auto ic) { fetch(ic); });
+            static_for<NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int tp = i / DT, dt = i % DT;
+                constexpr int later = (NI - 1 - i) < (PF - 1) ? (NI - 1 - i) : (PF - 1);   // pairs issued after this one
+                wait_lgkm<2 * later>(ring[i % PF].lo, ring[i % PF].hi);
+                acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]), acc2[dt]);
+                if constexpr (i + PF < NI) fetch(IdxC<i + PF>{});
+            });
+        }
+        sx = sx + 1 == NSX ? 0 : sx + 1;
+        se = se + 1 == NSE ? 0 : se + 1;
+    }
+    wait_dma();   // the re-fetches past the end must not outlive the block's LDS
+    float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (DK * 16);
+    if (accumulate) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31] += acc2[dt][r];
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31] = acc2[dt][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, 16-row wavefronts (v_mfma_f32_16x16x32_bf16).  A wave owns 16 rows: 16 x Dpad fp32 gradient
 // accumulators (Dpad/4 registers) + Dpad/8 registers of row fragments -- half of what the 32-row kernel
 // needs, so at Dpad <= 512 TWO waves fit per SIMD (8 waves x 16 rows = 128 rows per block) and hide each
@@ -873,6 +1136,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from crossclr_api.cpp)
 // ---------------------------------------------------------------------------------------------
+#ifndef CROSSCLR_KERNELS_ONLY   // (tools/kernel_asm.py compiles single kernels without the launchers)
 #ifdef CROSSCLR_EMU
 #define CROSSCLR_FAST_LAUNCH(kernel, grid, block, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)
 #else
@@ -898,7 +1162,7 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     dim3 grid(wk.nblk);
     const bool sw = krows != nullptr && kcols != nullptr;
 #define CROSSCLR_LF2(DK, NW, SYM, SW) \
-    CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols)
+    CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW, false>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols, (unsigned char*)nullptr)
 #define CROSSCLR_LF(DK, NW)                                        \
     do {                                                            \
         if (pairs && sw) CROSSCLR_LF2(DK, NW, 2, true);             \
@@ -919,6 +1183,54 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     }
 #undef CROSSCLR_LF
 #undef CROSSCLR_LF2
+    return CROSSCLR_OK;
+}
+
+// the saved-exponentials pair (symmetric local block, Dpad <= 512): bytes of the stash, forward that fills it, backward that reads it
+static inline size_t fast_stash_bytes(int bpad, int Dpad) {
+    return Dpad <= 512 ? stash_tiles_total(8, 2 * bpad / 32) * 2048 : 0;
+}
+static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const void* x, float* part, float* colpart,
+                                    int* header, const float* ks, void* stash, void* stream) {
+    const FwdWork wk = fast_forward_work(p, 1, -1, true);
+    if (wk.total <= 0) return CROSSCLR_OK;
+    const bf16_t* r = (const bf16_t*)x;
+    dim3 grid(wk.nblk);
+#define CROSSCLR_LFS(DK)                                                                                                   \
+    do {                                                                                                                    \
+        if (ks) CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, 1, 8, true, true>), grid, dim3(512), stream, r, r, g, wk, part, colpart, header, ks, ks, (unsigned char*)stash); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, 1, 8, false, true>), grid, dim3(512), stream, r, r, g, wk, part, colpart, header, ks, ks, (unsigned char*)stash);  \
+    } while (0)
+    switch (p->Dpad) {
+        case 128: CROSSCLR_LFS(8); break;
+        case 256: CROSSCLR_LFS(16); break;
+        case 384: CROSSCLR_LFS(24); break;
+        case 512: CROSSCLR_LFS(32); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LFS
+    return CROSSCLR_OK;
+}
+static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* x, const void* stash, const float* rz,
+                                      const float* wrz, float* gbuf, int accumulate, const float* ks, void* stream) {
+    const int ntiles = 2 * p->bpad / 32;
+    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+    dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
+    const bf16_t* c = (const bf16_t*)x;
+    const unsigned char* st = (const unsigned char*)stash;
+#define CROSSCLR_LBS(DK)                                                                                                            \
+    do {                                                                                                                             \
+        if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, true>), grid, block, stream, c, st, g, rz, wrz, gbuf, accumulate, tps, ks); \
+        else CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, false>), grid, block, stream, c, st, g, rz, wrz, gbuf, accumulate, tps, ks);  \
+    } while (0)
+    switch (p->Dpad) {
+        case 128: CROSSCLR_LBS(8); break;
+        case 256: CROSSCLR_LBS(16); break;
+        case 384: CROSSCLR_LBS(24); break;
+        case 512: CROSSCLR_LBS(32); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LBS
     return CROSSCLR_OK;
 }
 
@@ -984,5 +1296,7 @@ static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void
 #undef CROSSCLR_L32
     return CROSSCLR_OK;
 }
+
+#endif  // CROSSCLR_KERNELS_ONLY
 
 }  // namespace crossclr

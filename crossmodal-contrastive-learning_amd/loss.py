@@ -71,7 +71,7 @@ class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
-                 "k_rows", "k_cols", "lw", "stats_work")
+                 "k_rows", "k_cols", "lw", "stats_work", "stash")
 
 
 def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor]:
@@ -102,7 +102,8 @@ def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
 
 
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
-                  compute_mode: str, group, negative_scale=None, loss_weight=None) -> "tuple[torch.Tensor, _Workspace]":
+                  compute_mode: str, group, negative_scale=None, loss_weight=None,
+                  save_for_backward: bool = False) -> "tuple[torch.Tensor, _Workspace]":
     import torch.distributed as dist
     lib = nat.library()
     dev = video.device
@@ -149,8 +150,17 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
             dist.all_gather_into_tensor(ws.k_cols, ws.k_rows, group=group)
     else:
         ws.xcols = ws.xhat
-    nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
-                                     _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, stream))
+    # Local (symmetric) block.  When a backward will follow and the plan offers it, the forward also saves its bf16
+    # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
+    # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
+    ws.stash = None
+    if save_for_backward and plan.stash_bytes > 0:
+        ws.stash = torch.empty(plan.stash_bytes, dtype=torch.uint8, device=dev)
+        nat.check(lib.crossclr_forward_save(pp, _ptr(ws.xhat), ws.temperature, ws.negative_w,
+                                            _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, _ptr(ws.stash), stream))
+    else:
+        nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                         _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, stream))
     # Pair evaluation (bf16 register-resident path, >= 3 ranks): the (r, s) block of the symmetric matrix of exponentials
     # is evaluated by ONE of the two ranks, which ships its column sums to the other -- 3 instead of 7 remote blocks at
     # 8 ranks (+ the antipodal one, evaluated by both).  CROSSCLR_DISABLE_PAIR_FORWARD=1: every rank evaluates all blocks.
@@ -213,9 +223,15 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
     rank, world = ws.rank, ws.world
     rz_loc, wrz_loc = ws.rz, ws.wrz   # column statistics of the local block = this rank's row statistics
-    nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
-                                      _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
-                                      _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
+    if ws.stash is not None:
+        nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
+                                              _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
+                                              stream))
+        ws.stash = None   # consumed: give the 0.27 GB back to the allocator as soon as the launch is queued
+    else:
+        nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                          _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
+                                          _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
     if ws.sharded:
         if ws.wrz_cols is None:
             ws.stats_work.wait()
@@ -251,8 +267,10 @@ class _CrossCLRFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, video, text, temperature, negative_w, compute_mode, group, negative_scale, loss_weight):
         video_c, text_c = _row_major(video.detach()), _row_major(text.detach())
+        needs_grad = any(ctx.needs_input_grad[:2])
         with _device_of(video_c):
-            loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight)
+            loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight,
+                                     save_for_backward=needs_grad)
         ctx.ws = ws
         ctx.save_for_backward(video_c, text_c)
         return loss

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CROSSCLR_ABI_VERSION 2
+#define CROSSCLR_ABI_VERSION 3
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
 #define CROSSCLR_IN_F32 0
@@ -72,6 +72,8 @@ typedef struct crossclr_plan {
     int loss_ws_doubles; /* doubles in the loss_sum buffer of crossclr_forward_finish: [0] = result */
     size_t operand_bytes;   /* one packed operand X[2][bpad][Dpad]          */
     size_t gbuf_bytes;      /* fp32 d(loss)/d(xhat) accumulator [bwd_slices][2][bpad][Dpad] */
+    size_t stash_bytes;     /* ABI 3: bytes of the saved-exponentials buffer of crossclr_forward_save (0: not available
+                               for this plan -- use crossclr_forward / crossclr_backward, which recompute) */
 } crossclr_plan;
 
 int crossclr_abi_version(void);
@@ -183,6 +185,21 @@ int crossclr_forward_pairs(const crossclr_plan* plan, const void* xhat_rows, con
                            int first_rank, int nranks, float temperature, float negative_weight,
                            const crossclr_sample_weights* sw, float* part, int slot0, float* colsum_out, void* stream);
 int crossclr_forward_add(const crossclr_plan* plan, float* part, int slot0, const float* vec, void* stream);
+
+/* ---- save-for-backward pair (ABI version 3) ------------------------------------------------------------------
+ * What autograd's "saved tensors" are for the reference (it keeps every fp64 [B,2B] intermediate of loss.py:96-112
+ * alive for the backward: 12.5 GB at B = 8192), reduced to its minimum: crossclr_forward_save is crossclr_forward_w for
+ * the LOCAL symmetric block (rows = columns = this rank's packed operand) that ALSO writes the bf16 exponentials
+ * E = exp(logit - shift) of the upper triangle of the stacked 2b x 2b matrix to `stash` (plan->stash_bytes bytes,
+ * 0.27 GB at b = 8192; caller-owned), and crossclr_backward_saved is crossclr_backward_w for the same block fed from
+ * that stash instead of recomputing the similarity product: it executes the algorithmic 8 b^2 D flop instead of
+ * 16 b^2 D.  Available when plan->stash_bytes > 0 (bf16 register-resident path, Dpad <= 512); `stash` must reach the
+ * backward unmodified.  sw->neg_scale_rows (== the columns') and rz/wrz are this rank's [2][bpad] arrays.            */
+int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
+                          const crossclr_sample_weights* sw, float* part, int slot0, void* stash, void* stream);
+int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash,
+                            float temperature, float negative_weight, const float* rz, const float* wrz,
+                            const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
 
 /* ---- influential-sample statistics (ABI version 2; SURVEY.md 8(f) rank 1, not in the reference @ v1) ----
  * From INPUT-space features x[b][Din] of both modalities (any float dtype, row stride ld):
