@@ -21,6 +21,8 @@
 #pragma once
 #include "crossclr_device.h"
 #include "../../include/crossclr.h"
+#include <stdlib.h>
+#include <string.h>
 #include <utility>
 
 namespace crossclr {
@@ -56,15 +58,66 @@ template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr16_b64_async(unsi
 template <int N> __device__ __forceinline__ void wait_lgkm(s16x4& a, s16x4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128_async(unsigned addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 // workgroup barrier that does NOT drain VMEM (an LDS-DMA ring stays in flight across it): LDS operations only
 __device__ __forceinline__ void barrier_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Buffer-addressed LDS-DMA (buffer_load_dword[x4] ... offen lds): wave-uniform 128-bit descriptor + per-lane 32-bit byte offset +
+// scalar byte offset.  Per tile only the scalar offset changes: no 64-bit per-lane address arithmetic, and reads past
+// `bytes` return zeros instead of faulting.
+struct BufRsrc { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
+    BufRsrc b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+    return b;
+}
+__device__ __forceinline__ void lds_dma16_buf(const BufRsrc& b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ void lds_dma4_buf(const BufRsrc& b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(const BufRsrc& b, unsigned voff, unsigned soff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// s_waitcnt vmcnt(0) as a BUILTIN: unlike the asm form hipcc's wait-count pass sees it and marks its own pending global
+// loads complete -- otherwise it re-waits for them (vmcnt(N) countdowns that also drain the DMA ring) at every later use
+__device__ __forceinline__ void wait_loads_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 #else
 __device__ __forceinline__ unsigned long lds_addr(const void* p) { return (unsigned long)(uintptr_t)p; }
 template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr16_b64_async(unsigned long addr) {
     return lds_read_tr16_b64(reinterpret_cast<const unsigned char*>(addr) + OFF);
 }
 template <int N> __device__ __forceinline__ void wait_lgkm(s16x4&, s16x4&) {}
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128_async(unsigned long addr) {
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(addr) + OFF);
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4&) {}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4&, u32x4&) {}
 __device__ __forceinline__ void barrier_keep_dma() { __syncthreads(); }
+struct BufRsrc { const unsigned char* base; unsigned bytes; };
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) { return BufRsrc{static_cast<const unsigned char*>(base), bytes}; }
+__device__ __forceinline__ void lds_dma16_buf(const BufRsrc& b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    unsigned char z[16] = {0};
+    const size_t o = (size_t)voff + soff;
+    memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * emu::my_lane(), o + 16 <= b.bytes ? b.base + o : z, 16);
+}
+__device__ __forceinline__ void lds_dma4_buf(const BufRsrc& b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    unsigned char z[4] = {0};
+    const size_t o = (size_t)voff + soff;
+    memcpy(static_cast<unsigned char*>(lds_wave_base) + 4 * emu::my_lane(), o + 4 <= b.bytes ? b.base + o : z, 4);
+}
+__device__ __forceinline__ void buf_store16(const BufRsrc& b, unsigned voff, unsigned soff, u32x4 v) {
+    memcpy(const_cast<unsigned char*>(b.base) + voff + soff, &v, 16);
+}
+__device__ __forceinline__ void sched_fence() {}
+__device__ __forceinline__ void wait_loads_visible() {}
 #endif
 
 // Tuning switches (compile-time; defaults = best measured on MI355X, see profiles/):
@@ -104,6 +157,9 @@ __device__ __forceinline__ void barrier_keep_dma() { __syncthreads(); }
     } while (0)
 #endif
 
+#ifndef CROSSCLR_SABL
+#define CROSSCLR_SABL 0   // fast_bwd_saved_kernel timing ablations (WRONG results): bit0 no E DMA, bit1 no X DMA, bit2 no weight VALU, bit3 no MFMA, bit4 no X transpose reads, bit5 no barrier
+#endif
 #ifndef CROSSCLR_FABL
 #define CROSSCLR_FABL 0   // forward timing ablations (WRONG results): bit0 no exp epilogue, bit1 no MFMA loop, bit2 no DMA/barrier, bit3 no column-sum butterfly
 #endif
@@ -393,7 +449,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
 #pragma unroll
             for (int k = 1; k < NST - 1; ++k) inflight += (w + k < w_end);
             wait_keep(inflight);
-            __syncthreads();  // item w landed everywhere; every wave is done with item w-1's stage
+            barrier_keep_dma();  // item w landed everywhere; every wave is done with item w-1's stage (LDS ops only: the ring stays in flight)
             if (w + NST - 1 < w_end) issue(cq[NST - 1], (stage + NST - 1) % NST);
         }
         if (SYM && pending) { flush(); pending = false; }
@@ -452,13 +508,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
         if (ST) {   // save the tile for the backward: registers 8th .. 8th+7 are the A fragment of k-step th
-            unsigned char* dst = stash + (st_tile0 + (size_t)cq[0].j) * 2048 + lane * 16;
+            const BufRsrc rs_st = make_rsrc(stash + (st_tile0 + (size_t)cq[0].j) * 2048, 2048u);
 #pragma unroll
             for (int th = 0; th < 2; ++th) {
                 struct { bf16_t v[8]; } pk;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[8 * th + j]);
-                *reinterpret_cast<u32x4*>(dst + 1024 * th) = __builtin_bit_cast(u32x4, pk);
+                buf_store16(rs_st, (unsigned)(lane * 16 + 1024 * th), 0u, __builtin_bit_cast(u32x4, pk));
             }
         }
         if (SW && same_mod) {
@@ -759,19 +815,26 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
     constexpr int TPR = 8;                 // 32-row groups per row block of the forward that wrote the stash (Dpad <= 512)
-    constexpr int NSX = 3;                 // column-tile ring
-    constexpr int NSE = 6;                 // saved-exponential ring
+#ifndef CROSSCLR_NSX
+#define CROSSCLR_NSX 3
+#endif
+#ifndef CROSSCLR_NSE
+#define CROSSCLR_NSE 6
+#endif
+    constexpr int NSX = CROSSCLR_NSX;      // column-tile ring (shared by the block's four waves)
+    constexpr int NSE = CROSSCLR_NSE;      // saved-exponential + statistics rings (private to a wave)
     constexpr int ESTG = 4 * 2048;         // one stage of the E ring: [4 waves][2 KiB]
+    constexpr int SSTG = 4 * 256;          // one stage of a statistics ring: [4 waves][64 floats] (the tile's 32 + 32 spare)
     constexpr int DT = DK / 2;             // 32-wide output fragments
-    constexpr int NI = 2 * DT;             // MFMAs per tile: (k-step tp, output fragment dt)
+    constexpr int NI = 2 * DT;             // MFMAs per tile: item i = (k-step tp = i / DT, output fragment dt = i % DT)
     constexpr int PF = (CROSSCLR_PF < NI / 2) ? CROSSCLR_PF : NI / 2;   // transpose-read pairs in flight ahead of their MFMA
-    constexpr int NX = DK / 4 + 1 + (SW ? 1 : 0);          // VMEM operations of one column tile per wave
-    constexpr int NKEEP = 2 + (NSX - 2) * (NX + 2);        // operations issued after X(t) that may still be in flight
-    static_assert(NSX * TILE + NSE * ESTG + NSX * 256 <= 160 * 1024, "LDS budget");
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[NSX * TILE + NSE * ESTG + NSX * 256];
-    unsigned char* ebuf = lds + NSX * TILE;
-    unsigned char* stat = ebuf + NSE * ESTG;     // [NSX][32] floats: omega/Z (or w omega/Z) of the tile's columns
-    unsigned char* statk = stat + NSX * 128;     // SW: [NSX][32] floats: k of the tile's columns
+    constexpr int NXO = DK / 4;            // VMEM operations per wave and tile: column-tile pieces ...
+    constexpr int NEO = 3 + (SW ? 1 : 0);  // ... saved-exponential pieces + statistics
+    constexpr int NKEEP = NEO + (NSX - 2) * (NXO + NEO);   // operations issued after X(t)'s last piece: may still be in flight at tile t
+    static_assert(NSX >= 2 && NSE >= NSX + 2, "E / statistics of tile t+1 must have been issued before the pieces of X(t)");
+    constexpr int E0 = NSX * TILE, S0 = E0 + NSE * ESTG, K0 = S0 + NSE * SSTG;
+    static_assert(K0 + (SW ? NSE * SSTG : 0) <= 160 * 1024, "LDS budget");
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[K0 + (SW ? NSE * SSTG : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -780,6 +843,9 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     const int NT = 2 * g.bpad / QT;              // column tiles; the first NT/2 are modality 0
     const int rmod = (2 * r32 >= NT) ? 1 : 0;
     const int rb0 = (r32 / TPR) * TPR;           // first tile the forward evaluated for this wave's rows
+    unsigned char* ebuf = lds + E0 + wave * 2048;      // + estage * ESTG
+    unsigned char* sbuf = lds + S0 + wave * 256;       // + estage * SSTG: omega/Z (or w omega/Z) of the tile's columns
+    unsigned char* kbuf = lds + K0 + wave * 256;       // SW: k of the tile's columns
 
     const float rzp_inter = rz[row0w + l31];
     const float rzp_intra = wrz[row0w + l31];
@@ -794,16 +860,26 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
         for (int u = 0; u < 2; ++u)
             comb[k][u] = (4 * half + jrow) * RB + 64 * (k ^ jrow) + 16 * ((2 * dsub + (piece >> 1)) ^ (2 * u + half)) +
                          8 * (piece & 1);
+    // column-tile DMA: piece k of this wave fills LDS bytes [(wave + 4k) KiB, +1 KiB) of the stage; lane -> (row, swizzled slot)
+    const BufRsrc rs_x = make_rsrc(cols, (unsigned)((size_t)2 * g.bpad * RB));
+    unsigned voffx[NXO];
+#pragma unroll
+    for (int k = 0; k < NXO; ++k) {
+        const int L = (wave + 4 * k) * 1024 + lane * 16;
+        const int row = L / RB, slot = (L - row * RB) >> 4;
+        voffx[k] = (unsigned)(row * RB + (swz_slot(slot, row) << 4));
+    }
     // saved-exponential tile.  direct: the 2-KiB fragment image as stored, lane-linear.  transposed: 16-byte chunk
     // (th_s, hf, rho) of stash tile (t, r32) [row rho = a column q of ours, chunk = 8 of OUR rows] goes to LDS slot
     // 16*(rho>>2) + (rho&3) + 4*hf + 8*th_s, so that the four rows a transpose read gathers sit in one 256-byte line
-    // and its 32 lanes touch 32 different 8-byte words (conflict-free); the permutation rides on the DMA source address.
-    // (separate scalars, not arrays: hipcc turns a select between two arrays into a scratch array indexed by the condition)
+    // and its 32 lanes touch 32 different 8-byte words (conflict-free); the permutation rides on the DMA source offset.
     const unsigned eoff_d0 = (unsigned)(lane * 16);
     const unsigned eoff_t0 = (unsigned)((((lane >> 3) & 1) * 64 + ((lane >> 2) & 1) * 32 + ((lane >> 4) * 4 + (lane & 3))) * 16);
     // transposed read: lane (half, g1 = grp&1, jj = jrow, c = piece) addresses row rho = 16th + 8u + 4half + jj, chunk
     // (hf = c&1, th_s = g1), 8-byte half c>>1  ->  th*1024 + u*512 + [half*256 + (jj + 4(c&1) + 8 g1)*16 + 8(c>>1)]
     const int etr = half * 256 + (jrow + 4 * (piece & 1) + 8 * dsub) * 16 + 8 * (piece >> 1);
+    const BufRsrc rs_rz = make_rsrc(rz, (unsigned)(2 * g.bpad * 4)), rs_wrz = make_rsrc(wrz, (unsigned)(2 * g.bpad * 4));
+    const BufRsrc rs_k = make_rsrc(SW ? ks : rz, (unsigned)(2 * g.bpad * 4));
 
     f32x16 acc2[DT];
 #pragma unroll
@@ -814,112 +890,158 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     int t = blockIdx.y * tiles_per_slice;
     int t_end = t + tiles_per_slice;
     if (t_end > NT) t_end = NT;
-    auto issue_x = [&](int u, int stage) {
-        if (u >= t_end) u = t_end - 1;     // past the end: re-fetch the last tile (keeps the VMEM count per iteration fixed)
-        const bool same = ((2 * u >= NT) ? 1 : 0) == rmod;
-        issue_tile_dma<RB, 4, QT>(reinterpret_cast<const unsigned char*>(cols) + (size_t)u * TILE, lds + stage * TILE, wave,
-                                  lane, (same ? wrz : rz) + QT * u, stat + stage * 128,
-                                  SW ? ks + QT * u : nullptr, statk + stage * 128);
+    auto clampt = [&](int u) { return u < t_end ? u : t_end - 1; };   // past the end: re-fetch the last tile (fixed VMEM count)
+    auto issue_x_piece = [&](int u, int stage, int k) {
+        if (CROSSCLR_SABL & 2) return;
+        lds_dma16_buf(rs_x, voffx[k], (unsigned)clampt(u) * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
     };
-    auto issue_e = [&](int u, int estage) {
-        if (u >= t_end) u = t_end - 1;
+    auto issue_e = [&](int u, int estage) {      // 2 pieces of the saved exponentials + the tile's statistics
+        if (CROSSCLR_SABL & 1) return;
+        u = clampt(u);
         const bool direct = u >= rb0;
-        const size_t idx = direct ? stash_tile_index(TPR, NT, r32, u) : stash_tile_index(TPR, NT, u, r32);
-        const unsigned char* src = stash + idx * 2048;
-        unsigned char* dst = ebuf + estage * ESTG + wave * 2048;
+        // stash_tile_index in 32-bit scalar arithmetic (the host refuses plans whose stash has 2^31 tiles or more)
+        const unsigned a32 = direct ? (unsigned)r32 : (unsigned)u, b32 = direct ? (unsigned)u : (unsigned)r32;
+        const unsigned rbp = a32 / TPR, wp = a32 % TPR;
+        const unsigned idx = TPR * rbp * ((unsigned)NT - (TPR / 2) * rbp + (TPR / 2)) + wp * ((unsigned)NT - TPR * rbp) + (b32 - TPR * rbp);
+        const BufRsrc rs_e = make_rsrc(stash + (size_t)((CROSSCLR_SABL & 64) ? (idx & 1023) : idx) * 2048, 2048u);   // bit6: E from a 2-MiB window (L2)
         const unsigned o0 = direct ? eoff_d0 : eoff_t0;      // second half (LDS chunks 64..127): +1 KiB direct, +16 rows transposed
-        const unsigned o1 = o0 + (direct ? 1024u : 256u);
-        lds_dma16(src + o0, dst);
-        lds_dma16(src + o1, dst + 1024);
+        lds_dma16_buf(rs_e, o0, 0u, ebuf + estage * ESTG);
+        lds_dma16_buf(rs_e, o0 + (direct ? 1024u : 256u), 0u, ebuf + estage * ESTG + 1024);
+        const bool same = ((2 * u >= NT) ? 1 : 0) == rmod;
+        lds_dma4_buf(same ? rs_wrz : rs_rz, (unsigned)(lane * 4), (unsigned)(u * QT * 4), sbuf + estage * SSTG);
+        if (SW) lds_dma4_buf(rs_k, (unsigned)(lane * 4), (unsigned)(u * QT * 4), kbuf + estage * SSTG);
     };
     struct Pair { s16x4 lo, hi; };
+    struct Bits8 { bf16_t e[8]; };
+    // the lane's saved exponentials of tile u: row p = l31, k-slot j of k-step th <-> column 16th + 8(j>>2) + 4half + (j&3)
+    // (all LDS reads of the main loop are asm: hipcc then puts no s_waitcnt lgkmcnt of its own into the MFMA stream, and
+    // the counted waits below never drain the transpose-read ring)
+    struct Staged { u32x4 e[2]; Pair tr[2]; u32x4 rq[4]; u32x4 kq[4]; };   // tile u: saved exponentials (both forms), omega/Z and k of its columns
+    // Both forms of the saved tile are read -- the lane-linear fragment image (right when the tile was stored for these
+    // rows) and the transposing gather (right when it was stored for the mirrored block) -- and the wanted one is selected
+    // AFTER the counted wait: an asm load's registers count as written when the asm statement ends, so they must never be
+    // live across a control-flow merge (a register copy there would read them before the data lands); six cheap LDS reads
+    // and eight v_cndmask per tile buy a branch-free main loop.
+    auto read_staged = [&](int estage, Staged& st) {
+        const unsigned char* eb = ebuf + estage * ESTG;
+        const auto ed = lds_addr(eb + 16 * lane);
+        st.e[0] = lds_read_b128_async<0>(ed);
+        st.e[1] = lds_read_b128_async<1024>(ed);
+        const auto ea = lds_addr(eb + etr);
+        st.tr[0].lo = lds_read_tr16_b64_async<0>(ea);
+        st.tr[0].hi = lds_read_tr16_b64_async<512>(ea);
+        st.tr[1].lo = lds_read_tr16_b64_async<1024>(ea);
+        st.tr[1].hi = lds_read_tr16_b64_async<1536>(ea);
+        const auto sa = lds_addr(sbuf + estage * SSTG + 16 * half);   // quad (th, r4): columns 16th + 8r4 + 4half ..+3
+        st.rq[0] = lds_read_b128_async<0>(sa);
+        st.rq[1] = lds_read_b128_async<32>(sa);
+        st.rq[2] = lds_read_b128_async<64>(sa);
+        st.rq[3] = lds_read_b128_async<96>(sa);
+        if (SW) {
+            const auto ka = lds_addr(kbuf + estage * SSTG + 16 * half);
+            st.kq[0] = lds_read_b128_async<0>(ka);
+            st.kq[1] = lds_read_b128_async<32>(ka);
+            st.kq[2] = lds_read_b128_async<64>(ka);
+            st.kq[3] = lds_read_b128_async<96>(ka);
+        }
+    };
+    // W = E (omega_p/Z_p + omega_q/Z_q) for four columns (k-step th, register quad r4), packed to bf16 in place
+    // YOUNGER = LDS operations certainly issued after the staged reads (>= that many): the wait is then a no-op in practice
+    auto weigh4 = [&](int u, Staged& st, Bits8 (&pk)[2], int th, int r4, auto younger) {
+        constexpr int YOUNGER = decltype(younger)::value;
+        const bool direct = clampt(u) >= rb0;
+        const bool same_mod = ((2 * clampt(u) >= NT) ? 1 : 0) == rmod;
+        const bool weighted = SW && same_mod;
+        const float rzp = same_mod ? rzp_intra : rzp_inter;
+        wait_lgkm<YOUNGER>(st.e[th], st.rq[2 * th + r4]);
+        wait_lgkm<YOUNGER>(st.tr[th].lo, st.tr[th].hi);
+        if (SW) wait_lgkm<YOUNGER>(st.kq[2 * th + r4]);
+        const f32x4 rq = __builtin_bit_cast(f32x4, st.rq[2 * th + r4]);
+        f32x4 kq = {1.f, 1.f, 1.f, 1.f};
+        if (weighted) kq = __builtin_bit_cast(f32x4, st.kq[2 * th + r4]);
+        const u32x4 etr4 = __builtin_bit_cast(u32x4, st.tr[th]);
+        const u32x4 esel = direct ? st.e[th] : etr4;        // (only the two dwords this quad uses survive dead-code elimination)
+        const Bits8 ev = __builtin_bit_cast(Bits8, esel);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
+            const float zz = weighted ? (rzp * kq[j] + rq[j] * kp) : (rzp + rq[j]);
+            pk[th].e[4 * r4 + j] = (CROSSCLR_SABL & 4) ? ev.e[4 * r4 + j] : f32_to_bf16_bits(v * zz);
+        }
+    };
 
+    bf16x8 af[2];      // A fragments of the tile being multiplied
     if (t < t_end) {
 #pragma unroll
         for (int k = 0; k < NSE - 1; ++k) issue_e(t + k, k);
 #pragma unroll
-        for (int k = 0; k < NSX - 1; ++k) issue_x(t + k, k);
+        for (int k = 0; k < NSX - 1; ++k)
+#pragma unroll
+            for (int j = 0; j < NXO; ++j) issue_x_piece(t + k, k, j);
+        if (!(CROSSCLR_SABL & 3)) wait_dma_keep<(NSX - 1) * NXO>();     // the E / statistics pieces precede the column tiles
+        Bits8 pk[2];
+        Staged st;
+        read_staged(0, st);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) weigh4(t, st, pk, q >> 1, q & 1, IdxC<0>{});
+        af[0] = __builtin_bit_cast(bf16x8, pk[0]);
+        af[1] = __builtin_bit_cast(bf16x8, pk[1]);
     }
     int sx = 0, se = 0;
     for (; t < t_end; ++t) {
-        wait_dma_keep<NKEEP>();     // X(t), E(t) and this tile's statistics have landed
-        barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1
-        issue_x(t + NSX - 1, sx == 0 ? NSX - 1 : sx - 1);
-        issue_e(t + NSE - 1, se == 0 ? NSE - 1 : se - 1);
-        const unsigned char* bt = lds + sx * TILE;
-        const unsigned char* eb = ebuf + se * ESTG + wave * 2048;
-        // ---- the lane's saved exponentials: row p = l31, k-slot j of k-step th <-> column 16th + 8(j>>2) + 4half + (j&3)
-        bf16x8 ef[2];
-        if (t >= rb0) {
+        if (!(CROSSCLR_SABL & 3)) wait_dma_keep<NKEEP>();      // X(t) has landed (and E / statistics of tile t+1, issued long before)
+        if (!(CROSSCLR_SABL & 32)) barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1
+        const int sx_free = sx == 0 ? NSX - 1 : sx - 1;        // stage of tile t-1 = stage of tile t+NSX-1
+        const int se_free = se == 0 ? NSE - 1 : se - 1;
+        const int se_next = se + 1 == NSE ? 0 : se + 1;
+        const auto xa = lds_addr(lds + sx * TILE);
+        decltype(lds_addr(lds)) base[4][2];
 #pragma unroll
-            for (int th = 0; th < 2; ++th) ef[th] = *reinterpret_cast<const bf16x8*>(eb + 1024 * th + 16 * lane);
-        } else {
-            const auto ea = lds_addr(eb + etr);
-            Pair p0, p1;
-            p0.lo = lds_read_tr16_b64_async<0>(ea);
-            p0.hi = lds_read_tr16_b64_async<512>(ea);
-            p1.lo = lds_read_tr16_b64_async<1024>(ea);
-            p1.hi = lds_read_tr16_b64_async<1536>(ea);
-            wait_lgkm<0>(p0.lo, p0.hi);
-            wait_lgkm<0>(p1.lo, p1.hi);
-            ef[0] = __builtin_bit_cast(bf16x8, p0);
-            ef[1] = __builtin_bit_cast(bf16x8, p1);
-        }
-        // ---- W = E (omega_p/Z_p + omega_q/Z_q), packed to bf16: the A fragments of the product ----
-        const bool same_mod = ((2 * t >= NT) ? 1 : 0) == rmod;
-        const bool weighted = SW && same_mod;
-        const float rzp = same_mod ? rzp_intra : rzp_inter;
-        const float* rzq = reinterpret_cast<const float*>(stat + sx * 128);
-        const float* kqs = reinterpret_cast<const float*>(statk + sx * 128);
-        bf16x8 af[2];
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int th = 0; th < 2; ++th) {
-            struct Bits8 { bf16_t e[8]; };
-            const Bits8 ev = __builtin_bit_cast(Bits8, ef[th]);
-            Bits8 pk;
-#pragma unroll
-            for (int r4 = 0; r4 < 2; ++r4) {
-                const int q0 = 16 * th + 8 * r4 + 4 * half;
-                const f32x4 rq = *reinterpret_cast<const f32x4*>(rzq + q0);
-                f32x4 kq = {1.f, 1.f, 1.f, 1.f};
-                if (weighted) kq = *reinterpret_cast<const f32x4*>(kqs + q0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
-                    const float zz = weighted ? (rzp * kq[j] + rq[j] * kp) : (rzp + rq[j]);
-                    pk.e[4 * r4 + j] = f32_to_bf16_bits(v * zz);
-                }
+            for (int u = 0; u < 2; ++u) base[k][u] = xa + comb[k][u];
+        Pair ring[PF];
+        auto fetch = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int tp = i / DT, dt = i % DT;
+            if (CROSSCLR_SABL & 16) { ring[i % PF] = __builtin_bit_cast(Pair, af[tp]); return; }
+            ring[i % PF].lo = lds_read_tr16_b64_async<(16 * tp) * RB + 256 * (dt >> 2)>(base[dt & 3][0]);
+            ring[i % PF].hi = lds_read_tr16_b64_async<(16 * tp + 8) * RB + 256 * (dt >> 2)>(base[dt & 3][1]);
+        };
+        static_for<PF>([&](auto ic) { fetch(ic); });
+        Staged st;             // tile t+1: saved exponentials and column statistics ...
+        Bits8 pk[2];           // ... and its weights, built in the shadow of tile t's MFMAs
+        // One MFMA slot = { wait for the item's B fragment; MFMA; issue the reads PF items ahead; one chore }, pinned by
+        // sched_fence() so that hipcc neither bunches the chores in front of the MFMAs nor the reads behind them.
+        // Chores of tile t: slots 0 .. NXO-1 the pieces of X(t+NSX-1); then E / statistics of tile t+NSE-1; then read E(t+1);
+        // the last four slots-pairs weigh tile t+1 (its E and statistics landed iterations ago, they are private to the wave).
+        constexpr int C_E = NXO, C_RD = NXO + 1, WSTEP = NI >= 16 ? 2 : 1, C_W0 = NI - 4 * WSTEP;
+        static_assert(C_RD < C_W0, "chore schedule");
+        static_for<NI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int tp = i / DT, dt = i % DT;
+            constexpr int later = (NI - 1 - i) < (PF - 1) ? (NI - 1 - i) : (PF - 1);   // pairs issued after this one
+            wait_lgkm<2 * later>(ring[i % PF].lo, ring[i % PF].hi);
+            if (CROSSCLR_SABL & 8) acc2[dt][i & 15] += __builtin_bit_cast(float, ring[i % PF].lo[0] | (ring[i % PF].hi[1] << 16));
+            else
+            acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]), acc2[dt]);
+            if constexpr (i + PF < NI) fetch(IdxC<i + PF>{});
+            if constexpr (i < NXO) issue_x_piece(t + NSX - 1, sx_free, i);
+            if constexpr (i == C_E) issue_e(t + NSE - 1, se_free);
+            if constexpr (i == C_RD) read_staged(se_next, st);
+            if constexpr (i >= C_W0 && (i - C_W0) % WSTEP == 0) {
+                constexpr int q = (i - C_W0) / WSTEP;                      // quad (th = q >> 1, r4 = q & 1)
+                constexpr int last_fetch = NI - PF - 1;                    // last slot that issues transpose reads
+                constexpr int n_after = (i < last_fetch ? i : last_fetch) - C_RD;   // slots C_RD+1 .. i that issued a pair
+                constexpr int younger = n_after <= 0 ? 0 : (2 * n_after < 2 * PF ? 2 * n_after : 2 * PF);
+                weigh4(t + 1, st, pk, q >> 1, q & 1, IdxC<younger>{});
             }
-            af[th] = __builtin_bit_cast(bf16x8, pk);
-        }
-        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows).  Item i = (k-step tp = i / DT, output
-        // fragment dt = i % DT); the B fragments are two transpose reads of the column tile, PF items ahead of their MFMA.
-        {
-            const auto xa = lds_addr(bt);
-            decltype(lds_addr(bt)) base[4][2];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) base[k][u] = xa + comb[k][u];
-            Pair ring[PF];
-            auto fetch = [&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int tp = i / DT, dt = i % DT;
-                ring[i % PF].lo = lds_read_tr16_b64_async<(16 * tp) * RB + 256 * (dt >> 2)>(base[dt & 3][0]);
-                ring[i % PF].hi = lds_read_tr16_b64_async<(16 * tp + 8) * RB + 256 * (dt >> 2)>(base[dt & 3][1]);
-            };
-            static_for<PF>([&](auto ic) { fetch(ic); });
-            static_for<NI>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int tp = i / DT, dt = i % DT;
-                constexpr int later = (NI - 1 - i) < (PF - 1) ? (NI - 1 - i) : (PF - 1);   // pairs issued after this one
-                wait_lgkm<2 * later>(ring[i % PF].lo, ring[i % PF].hi);
-                acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]), acc2[dt]);
-                if constexpr (i + PF < NI) fetch(IdxC<i + PF>{});
-            });
-        }
+            sched_fence();
+        });
+        af[0] = __builtin_bit_cast(bf16x8, pk[0]);
+        af[1] = __builtin_bit_cast(bf16x8, pk[1]);
         sx = sx + 1 == NSX ? 0 : sx + 1;
-        se = se + 1 == NSE ? 0 : se + 1;
+        se = se_next;
     }
     wait_dma();   // the re-fetches past the end must not outlive the block's LDS
     float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (DK * 16);
@@ -1133,6 +1255,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
         }
 }
 
+}  // namespace crossclr
+#include "crossclr_kernels_sym.h"
+namespace crossclr {
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from crossclr_api.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -1161,6 +1287,23 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     const bf16_t* c = (const bf16_t*)cols;
     dim3 grid(wk.nblk);
     const bool sw = krows != nullptr && kcols != nullptr;
+    static const bool old_sym = getenv("CROSSCLR_FWD_KERNEL") && !strcmp(getenv("CROSSCLR_FWD_KERNEL"), "8wave");   // A/B knob
+    if (symmetric && !pairs && p->Dpad <= 512 && !old_sym) {   // software-pipelined 4-wave kernel (crossclr_kernels_sym.h)
+#define CROSSCLR_LSY(DK)                                                                                                      \
+    do {                                                                                                                      \
+        if (sw) CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, true, false>), grid, dim3(256), stream, r, g, wk, part, colpart, header, krows, (unsigned char*)nullptr); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, false, false>), grid, dim3(256), stream, r, g, wk, part, colpart, header, krows, (unsigned char*)nullptr);  \
+    } while (0)
+        switch (p->Dpad) {
+            case 128: CROSSCLR_LSY(8); break;
+            case 256: CROSSCLR_LSY(16); break;
+            case 384: CROSSCLR_LSY(24); break;
+            case 512: CROSSCLR_LSY(32); break;
+            default: return CROSSCLR_E_ARG;
+        }
+#undef CROSSCLR_LSY
+        return CROSSCLR_OK;
+    }
 #define CROSSCLR_LF2(DK, NW, SYM, SW) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW, false>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols, (unsigned char*)nullptr)
 #define CROSSCLR_LF(DK, NW)                                        \
@@ -1198,8 +1341,8 @@ static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const 
     dim3 grid(wk.nblk);
 #define CROSSCLR_LFS(DK)                                                                                                   \
     do {                                                                                                                    \
-        if (ks) CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, 1, 8, true, true>), grid, dim3(512), stream, r, r, g, wk, part, colpart, header, ks, ks, (unsigned char*)stash); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, 1, 8, false, true>), grid, dim3(512), stream, r, r, g, wk, part, colpart, header, ks, ks, (unsigned char*)stash);  \
+        if (ks) CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, true, true>), grid, dim3(256), stream, r, g, wk, part, colpart, header, ks, (unsigned char*)stash); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, false, true>), grid, dim3(256), stream, r, g, wk, part, colpart, header, ks, (unsigned char*)stash);  \
     } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LFS(8); break;

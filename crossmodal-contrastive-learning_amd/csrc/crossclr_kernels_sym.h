@@ -1,0 +1,350 @@
+// crossclr_kernels_sym.h -- the symmetric forward of the single-device step / local block (Dpad <= 512), software-pipelined.
+//
+// Same mathematics and the same workspace layout as fast_fwd_kernel<DK, 1, 8, SW> (upper triangle of the stacked 2b x 2b matrix of
+// exponentials, mirrored half recovered from column sums; reference trainer/loss.py:83-100, 59-60), built differently:
+//   * 4 waves x 64 rows per 256-row block, ONE wave per SIMD (512 registers): both 32-row halves' fragments stay resident
+//     (2 x Dpad/4 registers), so one ds_read_b128 of the column tile feeds TWO MFMAs (half the LDS reads of the 8-wave kernel);
+//   * the epilogue of tile t-1 (scale, exp2, row sums, bf16 pack + stash stores, 64-row column sums) is cut into chores that
+//     are pinned between the 64 MFMAs of tile t (sched_fence per k-step): with one wave per SIMD nothing else would hide them;
+//   * every LDS read is asm with hand-counted lgkmcnt, the barrier does not drain VMEM, the column tiles arrive by
+//     buffer-addressed LDS-DMA (NST-deep ring) -- hipcc puts no wait of its own into the MFMA stream;
+//   * tiles that need a mask (the 256x256 diagonal blocks, ragged columns, padding rows) and the sample-weight variant take the
+//     plain, un-overlapped epilogue: 8 of ~65 tiles per row block.
+// ST: the bf16 exponentials of every evaluated tile are saved for fast_bwd_saved_kernel (layout: stash_tile_index).
+#pragma once
+
+namespace crossclr {
+
+template <int DK, bool SW, bool ST>
+__global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, Geo g, FwdWork wk, float* part, float* colpart,
+                                                              int* header, const float* ks, unsigned char* stash) {
+    constexpr int RB = DK * 32;            // bytes per operand row
+    constexpr int QT = 32;
+    constexpr int TILE = QT * RB;
+    constexpr int TPR = 8;                 // 32-row groups per row block (the workspace / stash layout of the 8-wave kernel)
+    constexpr int NST = (4 * TILE + 4096 <= 160 * 1024) ? 4 : 3;
+    constexpr int NXO = DK / 4;            // DMA pieces per wave and tile
+    constexpr int PF = 4;                  // A-fragment reads in flight ahead of their MFMA pair
+    constexpr int CS0 = NST * TILE;        // two column-sum slots [4 waves][32] floats
+    constexpr int KQ0 = CS0 + 2 * 4 * QT * 4;
+    static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512}");
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[KQ0 + (SW ? NST * 256 : 0)];   // k_q ring: 64 lanes x 4 B per stage (32 used)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    if (blockIdx.x == 0 && tid == 0) { header[0] = 1; header[1] = TPR; header[2] = wk.NT; header[3] = wk.per; }
+    const int NT = wk.NT;
+
+    int w = blockIdx.x * wk.per;
+    int w_end = w + wk.per;
+    if (w_end > wk.total) w_end = wk.total;
+    struct Cursor { int rb, j; };          // item = (row block, index inside its tile list): tile t = TPR*rb + j
+    auto advance = [&](Cursor& c) { if (++c.j == NT - TPR * c.rb) { c.j = 0; ++c.rb; } };
+    Cursor cq[NST];
+    {
+        int rb = 0;
+        while (fwd_prefix(wk, rb + 1) <= w) ++rb;
+        cq[0].rb = rb;
+        cq[0].j = w - fwd_prefix(wk, rb);
+    }
+#pragma unroll
+    for (int k = 1; k < NST; ++k) { cq[k] = cq[k - 1]; advance(cq[k]); }
+
+    // column-tile DMA: piece k of this wave fills LDS bytes [(wave + 4k) KiB, +1 KiB) of the stage
+    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * RB));
+    const BufRsrc rs_k = make_rsrc(SW ? (const void*)ks : (const void*)x, (unsigned)(2 * g.bpad * 4));
+    unsigned voffx[NXO];
+#pragma unroll
+    for (int k = 0; k < NXO; ++k) {
+        const int L = (wave + 4 * k) * 1024 + lane * 16;
+        const int row = L / RB, slot = (L - row * RB) >> 4;
+        voffx[k] = (unsigned)(row * RB + (swz_slot(slot, row) << 4));
+    }
+    // (tiles past the end of the work list are clamped to the last column tile: a harmless re-fetch into a free stage that
+    // keeps the VMEM count per iteration constant and the k-step chain free of branches)
+    auto tile_of = [&](const Cursor& c) { const int t = TPR * c.rb + c.j; return t < NT ? t : NT - 1; };
+    auto issue_piece = [&](const Cursor& c, int stage, int k) {
+        lds_dma16_buf(rs_x, voffx[k], (unsigned)tile_of(c) * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
+    };
+    auto issue_stat = [&](const Cursor& c, int stage) {     // SW: the tile's 32 k_q (every wave issues it: equal VMEM counts)
+        if (SW) lds_dma4_buf(rs_k, (unsigned)((lane & 31) * 4), (unsigned)(tile_of(c) * QT * 4), lds + KQ0 + stage * 256);
+    };
+    constexpr int NOPS = NXO + (SW ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k) {
+#pragma unroll
+        for (int p = 0; p < NXO; ++p) issue_piece(cq[k], k, p);
+        issue_stat(cq[k], k);
+    }
+
+    int off8[8];  // byte offset of logical chunk (2j + half) of this lane's tile row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
+
+    float* cs = reinterpret_cast<float*>(lds + CS0);
+    // ---- per-row-block state ----
+    int my_rb = -1, row0w = 0, rmod = 0;
+    float rowacc[2] = {0.f, 0.f}, kp[2] = {1.f, 1.f};
+    size_t st0[2] = {0, 0};                // ST: stash index of tile j = 0 of the current row block, per 32-row half
+    bf16x8 pf[2][DK];
+    auto store_rows = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v = rowacc[s] + wave_xor_f32(rowacc[s], 32);
+            if (half == 0) part[(size_t)(blockIdx.x - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + 32 * s + l31] = v;
+        }
+    };
+    // ---- the tile whose epilogue is still owed ----
+    struct Prev { bool valid, fast; int t, rb; };
+    Prev prev = {false, false, 0, 0};
+    f32x16 pacc[2];
+    // ---- column sums waiting for the next barrier ----
+    bool pending = false;
+    int ptile = 0, pbuf = 0, prb = 0;
+    auto flush = [&]() {
+        if (tid < QT) {
+            const float* c = cs + pbuf * (4 * QT);
+            colpart[(size_t)prb * NT * QT + QT * ptile + tid] = (c[tid] + c[QT + tid]) + (c[2 * QT + tid] + c[3 * QT + tid]);
+        }
+    };
+    struct Bits8 { bf16_t v[8]; };
+    auto stash_store = [&](int t, int s, const float (&e)[16]) {     // (my_rb is the row block of the tile being finished)
+        const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)(t - TPR * my_rb)) * 2048, 2048u);
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            Bits8 pk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[8 * th + j]);
+            buf_store16(rs_st, (unsigned)(lane * 16 + 1024 * th), 0u, __builtin_bit_cast(u32x4, pk));
+        }
+    };
+    auto colsum_publish = [&](const float (&es)[16], int t) {
+        const float colsum = halving_sum16(es, l31);
+        pbuf ^= 1;
+        if (l31 < 16) cs[pbuf * (4 * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
+        pending = true;
+        ptile = t;
+        prb = my_rb;
+    };
+    // general (masked / weighted) epilogue of one tile, not overlapped with anything
+    auto epilogue_plain = [&](f32x16 (&acc)[2], int t, int stage_of_t) {
+        const int tmod = (QT * t >= g.bpad) ? 1 : 0;
+        const int in_mod0 = QT * t - tmod * g.bpad;
+        const bool same_mod = tmod == rmod;
+        const float c2s = same_mod ? g.c_intra : g.c_inter;
+        const bool upper = t >= TPR * (my_rb + 1);
+        const float ninf = -__builtin_inff();
+        float es[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) es[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r32 = TPR * my_rb + 2 * wave + s;
+            const int r_in_mod = row0w + 32 * s - rmod * g.bpad + l31;
+            float xx[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xx[r] = acc[s][r] * c2s - g.m2;
+            if (in_mod0 + QT > g.b) {                       // ragged tile: columns beyond the valid batch
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (in_mod0 + frag_row(r, half) >= g.b) xx[r] = ninf;
+            }
+            if (t == r32) {                                  // the tile that holds this half's diagonal
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (frag_row(r, half) == l31) xx[r] = ninf;
+            }
+            if (upper && r_in_mod >= g.b) {                  // padding ROWS must not reach the column sums
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xx[r] = ninf;
+            }
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = fast_exp2(xx[r]);
+            if (ST) stash_store(t, s, e);
+            if (SW && same_mod) {
+                const float* kq = reinterpret_cast<const float*>(lds + KQ0 + stage_of_t * 256);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(kq + 8 * r4 + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        rowacc[s] += e[4 * r4 + j] * k4[j];
+                        es[4 * r4 + j] += e[4 * r4 + j] * kp[s];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { rowacc[s] += e[r]; es[r] += e[r]; }
+            }
+        }
+        if (upper) colsum_publish(es, t);
+    };
+
+    int stage = 0;
+    while (w < w_end) {
+        const int t = TPR * cq[0].rb + cq[0].j;
+        if (cq[0].rb != my_rb) {   // (re)load this wave's 64 rows as MFMA B fragments; first settle what is owed to the old rows
+            if (prev.valid) {   // (SW tiles never stay owed: see below)
+                // the owed tile may publish column sums while an earlier publication still waits for its barrier: flush that first
+                __syncthreads();
+                if (pending) { flush(); pending = false; }
+                epilogue_plain(pacc, prev.t, 0);
+                prev.valid = false;
+            }
+            if (my_rb >= 0) store_rows();
+            my_rb = cq[0].rb;
+            rowacc[0] = rowacc[1] = 0.f;
+            row0w = my_rb * 256 + 64 * wave;
+            rmod = row0w / g.bpad;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (SW) kp[s] = ks[row0w + 32 * s + l31];
+                if (ST) st0[s] = stash_tile_index(TPR, NT, TPR * my_rb + 2 * wave + s, TPR * my_rb);
+                const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * 16) + 8 * half;
+#pragma unroll
+                for (int k = 0; k < DK; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
+            }
+            wait_loads_visible();   // here, once per row block -- not as vmcnt countdowns inside every tile's MFMA stream
+        }
+        wait_dma_keep<(NST - 2) * NOPS>();   // tile w has landed (the NST-2 tiles issued after it may still be in flight) ...
+        barrier_keep_dma();                  // ... everywhere; and every wave is done with tile w-1's stage
+        if (pending) { flush(); pending = false; }
+        const int rstage = (stage + NST - 1) % NST;
+        const auto xa = lds_addr(lds + stage * TILE);
+        decltype(lds_addr(lds)) abase[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) abase[j] = xa + off8[j];
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+        u32x4 ring[PF];
+        auto fetch = [&](auto ic) {
+            constexpr int k = decltype(ic)::value;
+            ring[k % PF] = lds_read_b128_async<(k >> 3) * 256>(abase[k & 7]);
+        };
+        // one k-step: wait for its A fragment, two MFMAs (both row halves), the read PF k-steps ahead, then the step's chores
+        auto kstep = [&](auto ic) {
+            constexpr int k = decltype(ic)::value;
+            constexpr int later = (DK - 1 - k) < (PF - 1) ? (DK - 1 - k) : (PF - 1);
+            wait_lgkm<later>(ring[k % PF]);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, ring[k % PF]);
+            acc[0] = mfma_32x32x16_bf16(a, pf[0][k], acc[0]);
+            acc[1] = mfma_32x32x16_bf16(a, pf[1][k], acc[1]);
+            if constexpr (k + PF < DK) fetch(IdxC<k + PF>{});
+            if constexpr (k < NXO) issue_piece(cq[NST - 1], rstage, k);
+            if constexpr (k == NXO) issue_stat(cq[NST - 1], rstage);
+        };
+        // NOTE: the reads that prime the ring must sit in the SAME basic block as the k-step chain: an asm load's registers
+        // count as written when the asm statement ends, so a register copy at a control-flow merge would read them early.
+
+        if (prev.valid && prev.fast) {
+            // ---- pipelined: the owed tile is unmasked, unweighted and strictly right of the diagonal block ----
+            const int ptmod = (QT * prev.t >= g.bpad) ? 1 : 0;
+            const float c2s = (ptmod == rmod) ? g.c_intra : g.c_inter;
+            float e[2][16], es[16], k8[8], k4[4], k2[2];
+            // chore plan over the DK k-steps (C = DK / 8 elements of work per step and stage):
+            //   steps [0, DK/2): scale + exp2 + row sum of elements (s = step / (DK/4), r = ...)   -- 32 elements
+            //   steps [DK/2, 3DK/4): es = e0 + e1 (16), bf16 pack + stash stores (4 fragments)
+            //   steps [3DK/4, DK): recursive-halving butterfly (8 + 4 + 2 + 1 + final) and the LDS slot write
+            constexpr int S1 = DK / 2, S2 = 3 * DK / 4;
+            static_for<PF>([&](auto ic) { fetch(ic); });
+            static_for<DK>([&](auto ic) {
+                constexpr int k = decltype(ic)::value;
+                kstep(ic);
+                if constexpr (k < S1) {
+#pragma unroll
+                    for (int idx = (32 * k) / S1; idx < (32 * (k + 1)) / S1; ++idx) {
+                        const int s = idx >> 4, r = idx & 15;
+                        const float v = fast_exp2(pacc[s][r] * c2s - g.m2);
+                        e[s][r] = v;
+                        rowacc[s] += v;
+                    }
+                } else if constexpr (k < S2) {
+                    constexpr int n = S2 - S1, i = k - S1;         // n steps: 16 sums and 4 fragments
+#pragma unroll
+                    for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = e[0][r] + e[1][r];
+                    if (ST) {
+#pragma unroll
+                        for (int f = (4 * i) / n; f < (4 * (i + 1)) / n; ++f) {
+                            const int s = f >> 1, th = f & 1;
+                            const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)(prev.t - TPR * my_rb)) * 2048, 2048u);
+                            Bits8 pk;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[s][8 * th + j]);
+                            buf_store16(rs_st, (unsigned)(lane * 16 + 1024 * th), 0u, __builtin_bit_cast(u32x4, pk));
+                        }
+                    }
+                } else {
+                    constexpr int n = DK - S2, i = k - S2;         // n >= 2 steps for the butterfly
+                    constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;   // work units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: publish
+#pragma unroll
+                    for (int u = lo; u < hi; ++u) {
+                        if (u < 8) {
+                            const bool up = (l31 >> 3) & 1;
+                            k8[u] = (up ? es[8 + u] : es[u]) + lane_xor<15>(up ? es[u] : es[8 + u]);
+                        } else if (u < 12) {
+                            const int q = u - 8;
+                            const bool up = (l31 >> 2) & 1;
+                            k4[q] = (up ? k8[4 + q] : k8[q]) + lane_xor<7>(up ? k8[q] : k8[4 + q]);
+                        } else if (u < 14) {
+                            const int q = u - 12;
+                            const bool up = (l31 >> 1) & 1;
+                            k2[q] = (up ? k4[2 + q] : k4[q]) + lane_xor<2>(up ? k4[q] : k4[2 + q]);
+                        } else if (u == 14) {
+                            const bool up = l31 & 1;
+                            const float k1 = (up ? k2[1] : k2[0]) + lane_xor<1>(up ? k2[0] : k2[1]);
+                            k2[0] = k1 + lane_xor<16>(k1);
+                        } else {
+                            pbuf ^= 1;
+                            if (l31 < 16) cs[pbuf * (4 * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = k2[0];
+                            pending = true;
+                            ptile = prev.t;
+                            prb = my_rb;
+                        }
+                    }
+                }
+                sched_fence();
+            });
+        } else {
+            if (prev.valid) epilogue_plain(pacc, prev.t, (stage + NST - 1) % NST);   // the owed tile's k_q stage = the stage of tile w-1
+            static_for<PF>([&](auto ic) { fetch(ic); });
+            static_for<DK>([&](auto ic) { kstep(ic); sched_fence(); });
+        }
+        // this tile's epilogue is owed to the next iteration
+        {
+            const int tmod = (QT * t >= g.bpad) ? 1 : 0;
+            const int in_mod0 = QT * t - tmod * g.bpad;
+            const bool upper = t >= TPR * (my_rb + 1);
+            const bool ragged = in_mod0 + QT > g.b;
+            const bool padrows = (row0w - rmod * g.bpad) + 64 > g.b;
+            prev.valid = true;
+            prev.fast = !SW && upper && !ragged && !padrows;
+            prev.t = t;
+            prev.rb = my_rb;
+            pacc[0] = acc[0];
+            pacc[1] = acc[1];
+        }
+        if (SW) {   // weighted tiles read their k_q from the tile's ring stage: finish them before the stage is refilled
+            epilogue_plain(pacc, t, stage);
+            prev.valid = false;
+        }
+        stage = (stage + 1) % NST;
+        ++w;
+#pragma unroll
+        for (int k = 0; k < NST - 1; ++k) cq[k] = cq[k + 1];
+        advance(cq[NST - 1]);
+    }
+    wait_dma();      // (the clamped re-fetches past the end of the work list)
+    __syncthreads();
+    if (pending) { flush(); pending = false; }
+    if (prev.valid) epilogue_plain(pacc, prev.t, 0);
+    __syncthreads();
+    if (pending) flush();
+    if (my_rb >= 0) store_rows();
+}
+
+}  // namespace crossclr
