@@ -17,8 +17,15 @@ batch is scored once per step); samples/s = B_global / t_step is reported next t
 Rank 0 prints ONE JSON line.
 
 Timing: `--prewarm` (default 40) untimed settle steps, then `--warmup` untimed steps, then exactly `--steps` timed steps
-between barrier + synchronize fences, max over ranks.  The settle steps exist because an MI355X that has just been
-handed to the process runs its first ~20-50 steps ~9 % slower (clock ramp); they are reported as `prewarm_steps`.
+between barrier + synchronize fences, max over ranks -> `ms_per_step` / `value` (wall clock, the contract's number).  Every
+timed step is also bracketed by HIP events on the compute stream: `ms_per_step_event_median` is the median of those
+(SURVEY.md 8(d)).  The settle steps exist because an MI355X that has just been handed to the process runs its first
+~20-50 steps ~9 % slower (clock ramp); they are reported as `prewarm_steps` and named in `config.workload`.
+
+`--gpus N` without a torch.distributed launcher (WORLD_SIZE unset) re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, so both
+`python bench.py --gpus 8` and the driver's explicit torchrun command work.
+`--fwd-only` (BASELINE configs[1] with `--mode fp32 --rows 4096`): forward under no_grad, metric "(fwd)".
 """
 import argparse
 import json
@@ -38,6 +45,7 @@ NEG_W = 0.8
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 GOLDEN_LOSS_B8192_SEED1234 = 10.627098744839678  # tests/golden/index.json: g7_b8192_d512_s1234
+GOLDEN_LOSS_B4096_SEED1234 = 9.919463972018582   # tests/golden/index.json: g7_b4096_d512_s1234
 
 
 def measured_traffic(b, d, mode, kernel_substr):
@@ -60,7 +68,17 @@ def measured_traffic(b, d, mode, kernel_substr):
     return best
 
 
-def cpu_baseline(b, d):
+def make_inputs(b, d, seed):
+    """The synthetic workload (BASELINE.md section 3 / SURVEY.md 8(d)): v, t ~ N(0,1) fp32, v drawn first, then t, from one
+    CPU generator.  Same stream as oracle.make_inputs("randn", ...) (checked by tests/test_bench_cpu.py) -- kept here so that
+    the timed path does not import the oracle."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(b, d, generator=g)
+    t = torch.randn(b, d, generator=g)
+    return v, t
+
+
+def cpu_baseline(b, d, fwd_only=False):
     """The oracle's op-for-op restatement of the reference (bit-identical to it, see
     tests/golden/make_golden.py) timed on this box's host cores: bounded sample."""
     from oracle import crossclr_oracle as orc
@@ -70,13 +88,17 @@ def cpu_baseline(b, d):
     except Exception:
         avail_gb = 0.0
     bb = b if avail_gb >= 24 else min(b, 4096)
-    v, t = orc.make_inputs("randn", bb, d, 1234)
+    v, t = make_inputs(bb, d, 1234)
     orc.eager_loss_and_grads(v[:512], t[:512], TAU, NEG_W)  # warm the allocator / thread pool
     times = []
     budget_t0 = time.perf_counter()
     for i in range(3):
         t0 = time.perf_counter()
-        loss, _, _ = orc.eager_loss_and_grads(v, t, TAU, NEG_W)
+        if fwd_only:
+            with torch.no_grad():
+                loss = orc.eager_loss(v, t, TAU, NEG_W)
+        else:
+            loss, _, _ = orc.eager_loss_and_grads(v, t, TAU, NEG_W)
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - budget_t0 > 25 and i >= 1:
             break
@@ -91,7 +113,8 @@ def cpu_baseline(b, d):
             "cpu_model": cpu_model,
             "samples_per_s": bb / best, "seconds_per_step": best, "host_cpus": os.cpu_count(),
             "loss": float(loss),
-            "sample": f"oracle.eager_loss_and_grads (op-for-op reference restatement) fwd+bwd, fp32 inputs, "
+            "sample": f"oracle.eager_loss{'' if fwd_only else '_and_grads'} (op-for-op reference restatement) "
+                      f"{'fwd' if fwd_only else 'fwd+bwd'}, fp32 inputs, "
                       f"B={bb} D={d}, {len(times)} steps (first = warm-up), median of the rest"}
 
 
@@ -107,6 +130,10 @@ def main():
                     help="untimed device settle steps BEFORE the --warmup steps (GPU clocks / allocator reach steady state "
                          "only after ~20-50 steps: 0.79 -> 0.72 ms/step); reported in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="forward under no_grad only (BASELINE configs[1])")
+    ap.add_argument("--selftest-emu", action="store_true",
+                    help="TESTS ONLY (tests/test_bench_cpu.py): CPU tensors, gloo, the host-emulation build of the kernels -- "
+                         "exercises the multi-rank plumbing, the timing fences and the JSON line without a GPU")
     ap.add_argument("--influential", action="store_true",
                     help="BASELINE config 5: influential-sample pruning + loss weighting from synthetic input-space "
                          "features (crossclr_amd.CrossCLR); not the default workload")
@@ -115,6 +142,16 @@ def main():
     # RCCL prints a version banner on the C-level stdout of every rank.  Keep this process's stdout to
     # exactly ONE JSON line: everything else that lands on fd 1 is sent to stderr; the result goes to
     # the saved descriptor.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (one rank per GPU, rendezvous on the loopback address)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
@@ -123,36 +160,50 @@ def main():
     import crossclr_amd
     from crossclr_amd import _native as nat
     from crossclr_amd import _profile
-    from oracle import crossclr_oracle as orc
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    assert nat.backend() == "hip-gfx950", "bench needs the HIP library"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    emu = args.selftest_emu
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu import build_emu
+        nat.use_library_for_testing(build_emu.build())
+        dev = torch.device("cpu")
+    else:
+        assert nat.backend() == "hip-gfx950", "bench needs the HIP library"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         group = dist.group.WORLD
 
     b, d = args.rows, args.dim
-    v, t = orc.make_inputs("randn", b, d, 1234 + rank)
-    v = v.to(dev).requires_grad_(True)
-    t = t.to(dev).requires_grad_(True)
+    v, t = make_inputs(b, d, 1234 + rank)
+    v = v.to(dev).requires_grad_(not args.fwd_only)
+    t = t.to(dev).requires_grad_(not args.fwd_only)
     if args.influential:
         # input-space features: 16 clusters + noise (so that connectivities differ and the threshold prunes a part)
-        xv, xt = orc.make_inputs("cluster", b, 256, 4321 + rank)
-        xv, xt = xv.to(dev), xt.to(dev)
+        g = torch.Generator().manual_seed(4321 + rank)
+        c = torch.randn(16, 256, generator=g)
+        lab = torch.randint(0, 16, (b,), generator=g)
+        xv = (c[lab] + 0.1 * torch.randn(b, 256, generator=g)).to(dev)
+        xt = (c[lab] + 0.1 * torch.randn(b, 256, generator=g)).to(dev)
         crit = crossclr_amd.CrossCLR(TAU, 0.0035, NEG_W, 0.9, compute_mode=args.mode, process_group=group).to(dev)
     else:
         crit = crossclr_amd.CrossCLR_onlyIntraModality(TAU, NEG_W, compute_mode=args.mode, process_group=group).to(dev)
 
     def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                return crit(v, t, xv, xt) if args.influential else crit(v, t)
         v.grad = None
         t.grad = None
         loss = crit(v, t, xv, xt) if args.influential else crit(v, t)   # the O(B D) weight recipe is inside the step
@@ -162,16 +213,23 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not emu:
+            torch.cuda.synchronize(dev)
 
     for _ in range(max(0, args.prewarm)):
         step()
     for _ in range(args.warmup):
         loss = step()
+    # HIP events on the compute stream around every timed step (they cost ~1 us each and do not synchronise)
+    ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if ev:
+            ev[i][0].record()
         loss = step()
+        if ev:
+            ev[i][1].record()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -181,8 +239,22 @@ def main():
     t_step = elapsed / args.steps
     B = b * world
     loss_val = float(loss.item())
+    ev_ms = sorted(a.elapsed_time(z) for a, z in ev) if ev else []
 
     if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    what = "fwd" if args.fwd_only else "fwd+bwd"
+    if emu:   # tests only: the plumbing, not a measurement
+        out = {"metric": f"contrastive-pairs/sec ({what})", "value": B * B / t_step, "unit": "pairs/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
+               "config": {"workload": "SELFTEST on the host emulation of the kernels (not a measurement)", "global_batch": B},
+               "loss": loss_val}
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -194,37 +266,50 @@ def main():
                               negative_scale=sw[0], loss_weight=sw[1])
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
     # algorithmic flops per launch: forward 6*b*b*D, backward 8*b*b*D for the local block
-    alg = {"forward": 6.0 * b * b * d, "backward": 8.0 * b * b * d}
+    # forward_save / backward_saved are what a training step launches when the plan has the save-for-backward pair
+    # (forward / backward are the recomputing entry points, timed for comparison)
+    alg = {"forward": 6.0 * b * b * d, "backward": 8.0 * b * b * d, "forward_save": 6.0 * b * b * d, "backward_saved": 8.0 * b * b * d}
     kernels = {}
-    for k in ("normalize", "forward", "forward_finish", "backward", "backward_finish"):
+    for k in ("normalize", "forward", "forward_save", "forward_finish", "backward", "backward_saved", "backward_finish"):
+        if k not in st:
+            continue
         kernels[k] = {"ms": round(st[k], 4)}
         if k in alg:
             tf = alg[k] / (st[k] * 1e-3) / 1e12
             kernels[k].update(algorithmic_tflops=round(tf, 2), frac=round(tf / peak, 4))
-    dom = "backward"
+    saved = bool(st.get("saved_path"))
+    if args.fwd_only:
+        dom, dom_kernel = "forward", ("fast_fwd_sym_kernel" if st["fast_path"] else "fwd_sums_kernel")
+    else:
+        dom = "backward_saved" if saved else "backward"
+        dom_kernel = "fast_bwd_saved_kernel" if saved else ("fast_bwd" if st["fast_path"] else "bwd_kernel")
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
-    traffic = (measured_traffic(b, d, args.mode, "fast_bwd_kernel" if st["fast_path"] else "bwd_kernel")
-               if world == 1 and not args.influential else None)
-    step_tf = 14.0 * b * B * d / t_step / 1e12  # per-GPU algorithmic fwd+bwd flops over the whole step
+    traffic = measured_traffic(b, d, args.mode, dom_kernel) if world == 1 and not args.influential else None
+    step_tf = (6.0 if args.fwd_only else 14.0) * b * B * d / t_step / 1e12  # per-GPU algorithmic flops over the whole step
     out = {
-        "metric": "contrastive-pairs/sec (fwd+bwd)", "value": B * B / t_step, "unit": "pairs/s",
+        "metric": f"contrastive-pairs/sec ({what})", "value": B * B / t_step, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm),
         "ms_per_step": t_step * 1e3,
+        "ms_per_step_event_median": ev_ms[len(ev_ms) // 2] if ev_ms else None,
+        "ms_per_step_event_min_max": [ev_ms[0], ev_ms[-1]] if ev_ms else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
         "samples_per_s": B / t_step,
         "config": {"workload": ("CrossCLR (influential-sample pruning + weighting) " if args.influential else "CrossCLR_onlyIntraModality ") +
-                               f"fwd+bwd, b={b} rows/GPU, global B={B}, D={d}, "
+                               f"{what}, b={b} rows/GPU, global B={B}, D={d}, "
                                f"tau={TAU}, negative_weight={NEG_W}, {args.mode} operands / fp32 accumulate, "
-                               "randn features seed 1234+rank",
+                               f"randn features seed 1234+rank, {max(0, args.prewarm)} untimed settle steps before the warm-up",
                    "global_batch": B, "rows_per_gpu": b, "dim": d,
                    "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather of packed operands" if world > 1 else ""),
-                   "fast_path": bool(st["fast_path"])},
+                   "fast_path": bool(st["fast_path"]), "save_for_backward": saved and not args.fwd_only},
         "loss": loss_val,
-        "roofline": {"bound": "mfma", "kernel": "crossclr_backward (dominant kernel)",
+        "roofline": {"bound": "mfma", "kernel": f"{dom_kernel} (crossclr_{dom}; dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
+                     "source": "HIP events in this process (torch's current stream = the launch stream), average of 10 launches "
+                               "after the timed region; the rocprofv3 figure of the same command is under profiles/",
                      "traffic": traffic["bytes"] if traffic else None,
-                     "traffic_source": traffic["source"] if traffic else None,
+                     "traffic_source": (traffic["source"] + " (rocprofv3 --pmc passes of tools/kbench.py, read from the committed "
+                                        "summary -- bench.py cannot profile itself)") if traffic else None,
                      "hbm_gbps_at_that_traffic": round(traffic["bytes"] / (st[dom] * 1e-3) / 1e9, 1) if traffic else None,
                      "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
                      "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
@@ -236,8 +321,10 @@ def main():
         out["config"]["pruned_fraction"] = [round(1.0 - float(k.mean()), 4) for k in sw[0]]
     if world == 1 and b == B_PER_GPU and d == DIM and not args.influential:
         out["loss_delta_vs_reference"] = abs(loss_val - GOLDEN_LOSS_B8192_SEED1234)
+    if world == 1 and b == 4096 and d == DIM and not args.influential:
+        out["loss_delta_vs_reference"] = abs(loss_val - GOLDEN_LOSS_B4096_SEED1234)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(b, d)
+        out["cpu_baseline"] = cpu_baseline(b, d, args.fwd_only)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -93,11 +93,18 @@ _lib_path: Optional[str] = None
 
 def _bind(path: str) -> ctypes.CDLL:
     lib = ctypes.CDLL(path)
+    # CROSSCLR_AB_OLD_ABI=1 (kernel A/B timing against a build of an older commit, tools/ only): bind what the library has
+    tolerant = os.environ.get("CROSSCLR_AB_OLD_ABI") == "1"
     for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI
+        try:
+            fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI
+        except AttributeError:
+            if tolerant:
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
-    if lib.crossclr_abi_version() != ABI_VERSION:
+    if lib.crossclr_abi_version() != ABI_VERSION and not tolerant:
         raise CrossCLRNativeError(f"{path}: ABI version {lib.crossclr_abi_version()} != {ABI_VERSION}")
     return lib
 

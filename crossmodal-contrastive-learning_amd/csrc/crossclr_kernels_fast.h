@@ -63,6 +63,13 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128_async(unsigned
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
     return r;
 }
+// counted LDS wait + the MFMA that consumes the fragment, ONE asm statement: no compiler pad (s_nop) between an asm wait and
+// a builtin MFMA, and the fragment registers are only ever read after the wait.  acc lives in AGPRs ("+a"); A comes from
+// VALU results written many instructions earlier, B from the LDS reads being waited for; D -> next reader is another MFMA
+// on the same accumulator or the epilogue far behind the loop, so no software wait states are needed inside the string.
+template <int N> __device__ __forceinline__ void mfma_after_lgkm(f32x16& acc, bf16x8 a, bf16x8 b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
+}
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 // workgroup barrier that does NOT drain VMEM (an LDS-DMA ring stays in flight across it): LDS operations only
@@ -100,6 +107,7 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128_async(unsigned
 }
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4&) {}
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4&, u32x4&) {}
+template <int N> __device__ __forceinline__ void mfma_after_lgkm(f32x16& acc, bf16x8 a, bf16x8 b) { acc = mfma_32x32x16_bf16(a, b, acc); }
 __device__ __forceinline__ void barrier_keep_dma() { __syncthreads(); }
 struct BufRsrc { const unsigned char* base; unsigned bytes; };
 __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) { return BufRsrc{static_cast<const unsigned char*>(base), bytes}; }
@@ -119,6 +127,15 @@ __device__ __forceinline__ void buf_store16(const BufRsrc& b, unsigned voff, uns
 __device__ __forceinline__ void sched_fence() {}
 __device__ __forceinline__ void wait_loads_visible() {}
 #endif
+
+// compile-time loops whose index is a constant inside the body (asm immediates, register-array indices)
+template <int I> struct IdxC { static constexpr int value = I; };
+template <int... Is, typename F> __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F&& f) {
+    (f(IdxC<Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 // Tuning switches (compile-time; defaults = best measured on MI355X, see profiles/):
 //   CROSSCLR_PF     LDS fragment reads kept in flight ahead of the MFMA that consumes them
@@ -157,6 +174,12 @@ __device__ __forceinline__ void wait_loads_visible() {}
     } while (0)
 #endif
 
+#ifndef CROSSCLR_TUNE
+#define CROSSCLR_TUNE 0   // A/B switches: bit0 draining barrier in fast_fwd_kernel, bit1 no per-MFMA fence in fast_bwd16_kernel, bit2 draining barrier there
+#endif
+#ifndef CROSSCLR_FUSED_WAIT
+#define CROSSCLR_FUSED_WAIT 1   // counted LDS wait and MFMA in one asm statement (0: asm wait + builtin MFMA, with hipcc's pad in between)
+#endif
 #ifndef CROSSCLR_SABL
 #define CROSSCLR_SABL 0   // fast_bwd_saved_kernel timing ablations (WRONG results): bit0 no E DMA, bit1 no X DMA, bit2 no weight VALU, bit3 no MFMA, bit4 no X transpose reads, bit5 no barrier
 #endif
@@ -449,7 +472,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t*
 #pragma unroll
             for (int k = 1; k < NST - 1; ++k) inflight += (w + k < w_end);
             wait_keep(inflight);
+#if CROSSCLR_TUNE & 1
+            __syncthreads();
+#else
             barrier_keep_dma();  // item w landed everywhere; every wave is done with item w-1's stage (LDS ops only: the ring stays in flight)
+#endif
             if (w + NST - 1 < w_end) issue(cq[NST - 1], (stage + NST - 1) % NST);
         }
         if (SYM && pending) { flush(); pending = false; }
@@ -736,7 +763,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         const int t3 = next(t2 + 1);
         if (!(CROSSCLR_ABL & 8)) {
             wait_keep((t1 < t_end) + (t2 < t_end));   // tile t landed (its DMA was issued before t1's and t2's)
-            __syncthreads();                            // ... everywhere; and every wave finished tile t-1
+            barrier_keep_dma();                         // ... everywhere; and every wave finished tile t-1
             if (t3 < t_end) issue(t3, (stage + 3) & (NST - 1));
         }
         const unsigned char* bt = lds + stage * TILE;
@@ -745,25 +772,34 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 
         bf16x8 af[2];
         weights(acc, ct, reinterpret_cast<const float*>(stat + stage * 128), reinterpret_cast<const float*>(statk + stage * 128), af);
-        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows), PF-deep fragment ring ----
+        // ---- G[p][:] += W[p][q] . Xq[q][:]  (contraction over the tile's 32 rows).  Item i = (k-step i / DT, output fragment
+        // i % DT); B fragments by asm transpose reads PF items ahead of the fused {counted wait, MFMA} that consumes them
+        // (the ds_read_tr BUILTIN drew a vmcnt(0) in front of every tile's second product: the whole DMA ring drained there)
+        if (!(CROSSCLR_ABL & 1)) {
+            constexpr int NI = 2 * DT;
+            constexpr int PF2 = PF < NI / 2 ? PF : NI / 2;
+            const auto xa = lds_addr(bt);
+            decltype(lds_addr(bt)) base[4][2];
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
-            if (CROSSCLR_ABL & 1) {
-#ifndef CROSSCLR_EMU
-                asm volatile("" ::"v"(af[tp]));
-#endif
-                continue;
-            }
-            Pair ring[PF];
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int i = 0; i < PF; ++i) ring[i] = trpair(bt, tp, i);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const Pair curp = ring[dt % PF];
-                if (dt + PF < DT) ring[dt % PF] = trpair(bt, tp, dt + PF);
-                acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, curp), acc2[dt]);
-            }
-            if (!(CROSSCLR_ABL & 16)) SCHED_PIPELINE(DT, 2, PF);
+                for (int u = 0; u < 2; ++u) base[k][u] = xa + comb[k][u];
+            Pair ring[PF2];
+            auto fetch = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int tp = i / DT, dt = i % DT;
+                ring[i % PF2].lo = lds_read_tr16_b64_async<(16 * tp) * RB + 256 * (dt >> 2)>(base[dt & 3][0]);
+                ring[i % PF2].hi = lds_read_tr16_b64_async<(16 * tp + 8) * RB + 256 * (dt >> 2)>(base[dt & 3][1]);
+            };
+            static_for<PF2>([&](auto ic) { fetch(ic); });
+            static_for<NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int tp = i / DT, dt = i % DT;
+                constexpr int later = (NI - 1 - i) < (PF2 - 1) ? (NI - 1 - i) : (PF2 - 1);
+                mfma_after_lgkm<2 * later>(acc2[dt], af[tp], __builtin_bit_cast(bf16x8, ring[i % PF2]));
+                if constexpr (i + PF2 < NI) fetch(IdxC<i + PF2>{});
+                sched_fence();
+            });
         }
         stage = (stage + 1) & (NST - 1);
         t = t1;
@@ -771,13 +807,21 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
         t2 = t3;
     }
     float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (DK * 16);
+    if (accumulate) {   // (hoisted: a per-element select made every store wait for its own load)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float* dst = gslice + (size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31;
-            *dst = accumulate ? (*dst + acc2[dt][r]) : acc2[dt][r];
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31] += acc2[dt][r];
+            sched_fence();
         }
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31] = acc2[dt][r];
+            sched_fence();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -799,14 +843,6 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 // HBM per launch: the stash is read once directly and once transposed (2 x 0.27 GB at B = 8192) -- O(B^2) bytes, which is
 // the price of not recomputing; the kernel stays MFMA-bound.
 // ---------------------------------------------------------------------------------------------
-template <int I> struct IdxC { static constexpr int value = I; };
-template <int... Is, typename F> __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F&& f) {
-    (f(IdxC<Is>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
-
 template <int DK, bool SW>
 __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
                                                                 const float* rz, const float* wrz, float* gbuf,
@@ -1021,10 +1057,14 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
             constexpr int i = decltype(ic)::value;
             constexpr int tp = i / DT, dt = i % DT;
             constexpr int later = (NI - 1 - i) < (PF - 1) ? (NI - 1 - i) : (PF - 1);   // pairs issued after this one
+#if CROSSCLR_FUSED_WAIT
+            mfma_after_lgkm<2 * later>(acc2[dt], af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]));
+#else
             wait_lgkm<2 * later>(ring[i % PF].lo, ring[i % PF].hi);
             if (CROSSCLR_SABL & 8) acc2[dt][i & 15] += __builtin_bit_cast(float, ring[i % PF].lo[0] | (ring[i % PF].hi[1] << 16));
             else
             acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]), acc2[dt]);
+#endif
             if constexpr (i + PF < NI) fetch(IdxC<i + PF>{});
             if constexpr (i < NXO) issue_x_piece(t + NSX - 1, sx_free, i);
             if constexpr (i == C_E) issue_e(t + NSE - 1, se_free);
@@ -1157,7 +1197,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 #pragma unroll
         for (int k = 1; k < NST - 1; ++k) inflight += (tl[k] < t_end);
         wait_keep(inflight);
+#if CROSSCLR_TUNE & 4
         __syncthreads();
+#else
+        barrier_keep_dma();
+#endif
         if (tl[NST - 1] < t_end) issue(tl[NST - 1], (stage + NST - 1) % NST);
         const unsigned char* bt = lds + stage * TILE;
         const ColTile ct = col_tile(g, tile_of(tl[0]), QT);
@@ -1219,26 +1263,29 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
             }
         }
         const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
-        // ---- G[p][:] += W[p][q] . Xq[q][:] : one k-step (32 columns) per 16-wide output fragment ----
+        // ---- G[p][:] += W[p][q] . Xq[q][:] : one k-step (32 columns) per 16-wide output fragment; B fragments by asm
+        // transpose reads PF2 fragments ahead of their MFMA (the builtin form drained the DMA ring: see fast_bwd_kernel) ----
         {
-            auto trpair = [&](int ds) {
-                Pair p;
-                const unsigned char* a = bt + comb[ds & 7] + 256 * (ds >> 3);
-                p.lo = lds_read_tr16_b64(a);
-                p.hi = lds_read_tr16_b64(a + 16 * RB);
-                return p;
-            };
             constexpr int PF2 = CROSSCLR_PF < DS / 2 ? CROSSCLR_PF : DS / 2;
+            const auto xa = lds_addr(bt);
+            decltype(lds_addr(bt)) base[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) base[k] = xa + comb[k];
             Pair ring[PF2];
-#pragma unroll
-            for (int i = 0; i < PF2; ++i) ring[i] = trpair(i);
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                const Pair curp = ring[ds % PF2];
-                if (ds + PF2 < DS) ring[ds % PF2] = trpair(ds + PF2);
-                acc2[ds] = mfma_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, curp), acc2[ds]);
-            }
-            SCHED_PIPELINE(DS, 2, PF2);
+            auto fetch = [&](auto ic) {
+                constexpr int ds = decltype(ic)::value;
+                ring[ds % PF2].lo = lds_read_tr16_b64_async<256 * (ds >> 3)>(base[ds & 7]);
+                ring[ds % PF2].hi = lds_read_tr16_b64_async<256 * (ds >> 3) + 16 * RB>(base[ds & 7]);
+            };
+            static_for<PF2>([&](auto ic) { fetch(ic); });
+            static_for<DS>([&](auto ic) {
+                constexpr int ds = decltype(ic)::value;
+                constexpr int later = (DS - 1 - ds) < (PF2 - 1) ? (DS - 1 - ds) : (PF2 - 1);
+                wait_lgkm<2 * later>(ring[ds % PF2].lo, ring[ds % PF2].hi);
+                acc2[ds] = mfma_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, ring[ds % PF2]), acc2[ds]);
+                if constexpr (ds + PF2 < DS) fetch(IdxC<ds + PF2>{});
+                if (!(CROSSCLR_TUNE & 2)) sched_fence();
+            });
         }
 #pragma unroll
         for (int k = 0; k < NST - 1; ++k) tl[k] = tl[k + 1];
@@ -1246,13 +1293,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
         stage = (stage + 1) % NST;
     }
     float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * DP;
+    if (accumulate) {
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds)
+        for (int ds = 0; ds < DS; ++ds) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* dst = gslice + (size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16;
-            *dst = accumulate ? (*dst + acc2[ds][r]) : acc2[ds][r];
+            for (int r = 0; r < 4; ++r) gslice[(size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16] += acc2[ds][r];
+            if ((ds & 3) == 3) sched_fence();
         }
+    } else {
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gslice[(size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16] = acc2[ds][r];
+            if ((ds & 3) == 3) sched_fence();
+        }
+    }
 }
 
 }  // namespace crossclr

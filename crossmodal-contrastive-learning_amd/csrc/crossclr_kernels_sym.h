@@ -62,8 +62,13 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
     }
     // (tiles past the end of the work list are clamped to the last column tile: a harmless re-fetch into a free stage that
     // keeps the VMEM count per iteration constant and the k-step chain free of branches)
-    auto tile_of = [&](const Cursor& c) { const int t = TPR * c.rb + c.j; return t < NT ? t : NT - 1; };
+#ifndef CROSSCLR_YABL
+#define CROSSCLR_YABL 0   // timing ablations of this kernel (WRONG results): bit0 every block streams the same 64 column tiles (L2-resident),
+                          // bit1 no stash stores, bit2 no column-sum butterfly, bit3 plain epilogue for every tile (no overlap), bit4 no DMA
+#endif
+    auto tile_of = [&](const Cursor& c) { const int t = TPR * c.rb + c.j; return (CROSSCLR_YABL & 1) ? (t & 63) : (t < NT ? t : NT - 1); };
     auto issue_piece = [&](const Cursor& c, int stage, int k) {
+        if (CROSSCLR_YABL & 16) return;
         lds_dma16_buf(rs_x, voffx[k], (unsigned)tile_of(c) * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
     };
     auto issue_stat = [&](const Cursor& c, int stage) {     // SW: the tile's 32 k_q (every wave issues it: equal VMEM counts)
@@ -267,7 +272,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
                     constexpr int n = S2 - S1, i = k - S1;         // n steps: 16 sums and 4 fragments
 #pragma unroll
                     for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = e[0][r] + e[1][r];
-                    if (ST) {
+                    if (ST && !(CROSSCLR_YABL & 2)) {
 #pragma unroll
                         for (int f = (4 * i) / n; f < (4 * (i + 1)) / n; ++f) {
                             const int s = f >> 1, th = f & 1;
@@ -283,6 +288,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
                     constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;   // work units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: publish
 #pragma unroll
                     for (int u = lo; u < hi; ++u) {
+                        if (CROSSCLR_YABL & 4) { if (u == 15) { k2[0] = es[l31 & 15]; } else continue; }
                         if (u < 8) {
                             const bool up = (l31 >> 3) & 1;
                             k8[u] = (up ? es[8 + u] : es[u]) + lane_xor<15>(up ? es[u] : es[8 + u]);
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
             const bool ragged = in_mod0 + QT > g.b;
             const bool padrows = (row0w - rmod * g.bpad) + 64 > g.b;
             prev.valid = true;
-            prev.fast = !SW && upper && !ragged && !padrows;
+            prev.fast = !SW && upper && !ragged && !padrows && !(CROSSCLR_YABL & 8);
             prev.t = t;
             prev.rb = my_rb;
             pacc[0] = acc[0];

@@ -4,7 +4,7 @@ JSON summary for profiles/.  usage: make_pmc_json.py <prefix> <out.json> B D mod
 import collections, csv, glob, json, re, sys
 prefix, out, B, D, mode = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 agg = collections.defaultdict(dict)
-for path in glob.glob(f"gpurun_out/{prefix}_*/*/*_counter_collection.csv"):
+for path in glob.glob(f"gpurun_out/{prefix}*/*/*_counter_collection.csv"):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void crossclr::", "").replace("crossclr::", "")
