@@ -55,6 +55,8 @@ extern "C" const char* crossclr_backend(void) {
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
+                           const float* kcols, const float* shift, int mode, void* stream);
 
 // forward workspace ("part") layout, in floats:
 //   [4 launch groups][fwd_slots][2*bpad] | colpart (symmetric launch) [<= 2*bpad/128 row blocks][2*bpad]
@@ -193,8 +195,13 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     return CROSSCLR_OK;
 }
 
+static bool needs_row_shift(float temperature, float negative_weight) {
+    const double it = 1.0 / (double)temperature, aw = fabs((double)negative_weight);
+    return it * (aw > 1.0 ? aw : 1.0) > 128.0;   // |logit| <= this bound because the rows are unit vectors
+}
+
 static int make_geo(const crossclr_plan* p, int col_ranks, int col_rank0, int skip_rank, float temperature,
-                    float negative_weight, Geo* g) {
+                    float negative_weight, Geo* g, bool allow_row_shift = false) {
     if (!p) return fail(CROSSCLR_E_ARG, "plan is NULL");
     if (!(temperature > 0.f) || !isfinite(temperature)) return fail(CROSSCLR_E_ARG, "temperature must be > 0");
     if (!isfinite(negative_weight)) return fail(CROSSCLR_E_ARG, "negative_weight must be finite");
@@ -208,9 +215,14 @@ static int make_geo(const crossclr_plan* p, int col_ranks, int col_rank0, int sk
     // fixed soft-max shift: exp(logit - shift) must neither overflow (<= e^64 per term) nor push the
     // always-present exp(0 - shift) self term out of fp32 range (shift <= 64)
     double shift = bound > 64.0 ? bound - 64.0 : 0.0;
-    if (shift > 64.0)
-        return fail(CROSSCLR_E_RANGE, "temperature %g too small for the fixed-shift soft-max (max |logit| %g > 128)",
-                    (double)temperature, bound);
+    g->row_shift = 0;
+    if (shift > 64.0) {
+        if (!allow_row_shift)
+            return fail(CROSSCLR_E_RANGE, "temperature %g too small for the fixed-shift soft-max (max |logit| %g > 128): use the "
+                        "two-pass entry points (crossclr_forward_rowmax + crossclr_*_s)", (double)temperature, bound);
+        g->row_shift = 1;   // per-row shifts (the row maxima of crossclr_forward_rowmax) replace the common one
+        shift = 0.0;
+    }
     g->c_inter = (float)(it * (double)kLog2e);
     g->c_intra = (float)(it * (double)negative_weight * (double)kLog2e);
     g->m2 = (float)(shift * (double)kLog2e);
@@ -257,6 +269,27 @@ static int unpack_k(const crossclr_sample_weights* sw, const float** krows, cons
     return CROSSCLR_OK;
 }
 
+// generic tiled forward: MODE 0 sums with the common shift, 1 row maxima, 2 sums with per-row shifts
+template <typename T>
+static void forward_generic_t(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
+                              const float* kcols, const float* shift, int mode, int tps, dim3 grid, void* stream) {
+    dim3 block(256);
+#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift)
+    if (kcols) { if (mode == 0) CROSSCLR_LFG(true, 0); else if (mode == 1) CROSSCLR_LFG(true, 1); else CROSSCLR_LFG(true, 2); }
+    else { if (mode == 0) CROSSCLR_LFG(false, 0); else if (mode == 1) CROSSCLR_LFG(false, 1); else CROSSCLR_LFG(false, 2); }
+#undef CROSSCLR_LFG
+}
+static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
+                           const float* kcols, const float* shift, int mode, void* stream) {
+    const int ntiles = g.col_ranks * 2 * plan->bpad / 128;
+    const int nsplit = plan->fwd_slots;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    dim3 grid(2 * plan->bpad / 128, nsplit);
+    if (plan->mode == CROSSCLR_MODE_FP32) forward_generic_t<float>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
+    else forward_generic_t<bf16_t>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
+    return launch_status("fwd_sums_kernel");
+}
+
 extern "C" int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
                                 int col_ranks, int col_rank0, int skip_rank, float temperature,
                                 float negative_weight, float* part, int slot0, void* stream) {
@@ -297,18 +330,7 @@ extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_ro
 #endif
     rc = device_zero_header(header, stream);
     if (rc) return rc;
-    const int ntiles = col_ranks * 2 * plan->bpad / 128;
-    const int nsplit = plan->fwd_slots;
-    const int tps = (ntiles + nsplit - 1) / nsplit;
-    dim3 grid(2 * plan->bpad / 128, nsplit), block(256);
-    if (plan->mode == CROSSCLR_MODE_FP32) {
-        if (kcols) LAUNCH((fwd_sums_kernel<float, true>), grid, block, stream, (const float*)xhat_rows, (const float*)xhat_cols, g, tps, out, kcols);
-        else LAUNCH((fwd_sums_kernel<float, false>), grid, block, stream, (const float*)xhat_rows, (const float*)xhat_cols, g, tps, out, kcols);
-    } else {
-        if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out, kcols);
-        else LAUNCH((fwd_sums_kernel<bf16_t, false>), grid, block, stream, (const bf16_t*)xhat_rows, (const bf16_t*)xhat_cols, g, tps, out, kcols);
-    }
-    return launch_status("fwd_sums_kernel");
+    return forward_generic(plan, g, xhat_rows, xhat_cols, out, kcols, nullptr, 0, stream);
 }
 
 extern "C" int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
@@ -414,12 +436,77 @@ extern "C" int crossclr_forward_finish_w(const crossclr_plan* plan, const float*
     if (rc) return rc;
     const int nb = plan->loss_ws_doubles - 1;
     const int nlaunch = nslots / plan->fwd_slots;
+    return crossclr_forward_finish_s(plan, part, nslots, diag_cos, temperature, negative_weight, sw, nullptr, logz, rz, wrz, loss_sum,
+                                     stream);
+}
+
+extern "C" int crossclr_forward_finish_s(const crossclr_plan* plan, const float* part, int nslots,
+                                         const float* diag_cos, float temperature, float negative_weight,
+                                         const crossclr_sample_weights* sw, const float* shift_rows, float* logz, float* rz,
+                                         float* wrz, double* loss_sum, void* stream) {
+    if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum || plan->fwd_slots <= 0 || nslots <= 0 ||
+        nslots % plan->fwd_slots != 0 || nslots / plan->fwd_slots > kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "NULL argument / nslots must be fwd_slots times the number of launch groups (1..%d)", kLaunchGroups);
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g, shift_rows != nullptr);
+    if (rc) return rc;
+    if ((g.row_shift != 0) != (shift_rows != nullptr))
+        return fail(CROSSCLR_E_ARG, "shift_rows must be given exactly when crossclr_needs_row_shift(temperature, negative_weight)");
+    const int nb = plan->loss_ws_doubles - 1;
+    const int nlaunch = nslots / plan->fwd_slots;
     LAUNCH(fwd_finish_kernel, dim3(nb), dim3(256), stream, part, nlaunch, plan->fwd_slots, g, diag_cos, 1.0f / temperature,
            negative_weight, logz, rz, wrz, loss_sum, part + ws_colpart_off(plan),
            reinterpret_cast<const int*>(part + ws_flag_off(plan)), sw ? sw->neg_scale_rows : nullptr,
-           sw ? sw->loss_weight : nullptr);
+           sw ? sw->loss_weight : nullptr, shift_rows);
     LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb);
     return launch_status("fwd_finish_kernel");
+}
+
+// ---- two-pass soft-max for small temperatures (max |logit| > 128) ------------------------------------------------------
+extern "C" int crossclr_needs_row_shift(float temperature, float negative_weight) {
+    return (temperature > 0.f && isfinite(temperature) && isfinite(negative_weight) && needs_row_shift(temperature, negative_weight)) ? 1 : 0;
+}
+
+extern "C" int crossclr_forward_rowmax(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols, int col_ranks,
+                                       int col_rank0, int skip_rank, float temperature, float negative_weight,
+                                       const crossclr_sample_weights* sw, float* part, float* shift_rows, int accumulate,
+                                       void* stream) {
+    if (!plan || !xhat_rows || !xhat_cols || !part || !shift_rows) return fail(CROSSCLR_E_ARG, "NULL argument");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    const bool skipping = skip_rank >= col_rank0 && skip_rank < col_rank0 + col_ranks;
+    const int n = 2 * plan->bpad;
+    int nslots = plan->fwd_slots;
+    if (col_ranks - (skipping ? 1 : 0) <= 0) nslots = 0;   // nothing to look at: only the self pair / the previous value
+    else if ((rc = forward_generic(plan, g, xhat_rows, xhat_cols, part, kcols, nullptr, 1, stream))) return rc;
+    LAUNCH(rowmax_combine_kernel, dim3((n + 255) / 256), dim3(256), stream, (const float*)part, nslots, n, krows, accumulate, shift_rows);
+    return launch_status("rowmax_combine_kernel");
+}
+
+extern "C" int crossclr_forward_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols, int col_ranks,
+                                  int col_rank0, int skip_rank, float temperature, float negative_weight,
+                                  const crossclr_sample_weights* sw, const float* shift_rows, float* part, int slot0, void* stream) {
+    if (!shift_rows)
+        return crossclr_forward_w(plan, xhat_rows, xhat_cols, col_ranks, col_rank0, skip_rank, temperature, negative_weight, sw, part,
+                                  slot0, stream);
+    if (!plan || !xhat_rows || !xhat_cols || !part || slot0 < 0) return fail(CROSSCLR_E_ARG, "NULL/negative argument");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    if (plan->fwd_slots <= 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    float* out = part + (size_t)slot0 * 2 * plan->bpad;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    rc = device_zero_header(header, stream);
+    if (rc) return rc;
+    const bool skipping = skip_rank >= col_rank0 && skip_rank < col_rank0 + col_ranks;
+    if (col_ranks - (skipping ? 1 : 0) <= 0) return device_zero(out, (size_t)plan->fwd_slots * 2 * plan->bpad * sizeof(float), stream);
+    return forward_generic(plan, g, xhat_rows, xhat_cols, out, kcols, shift_rows, 2, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,24 +514,27 @@ template <typename T>
 static int backward_generic(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                             const float* rz_rows, const float* wrz_rows, const float* rz_cols,
                             const float* wrz_cols, float* gbuf, int accumulate, const float* krows, const float* kcols,
-                            void* stream) {
+                            const float* shift_rows, const float* shift_cols, void* stream) {
     dim3 block(256);
     const int rb = 2 * p->bpad / 64;
     const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
     const int ntiles = (g.col_ranks - (skipping ? 1 : 0)) * 2 * p->bpad / 64;   // usable column tiles
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     const unsigned nz = (unsigned)p->bwd_slices;
-#define CROSSCLR_LB(DC)                                                                                                       \
-    do {                                                                                                                       \
-        if (krows) LAUNCH((bwd_kernel<T, DC, true>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows, \
-                          wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols);                                  \
-        else LAUNCH((bwd_kernel<T, DC, false>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)rows, (const T*)cols, g, rz_rows,     \
-                    wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols);                                        \
+    // the generic backward slices D by DC and gbuf by plan->bwd_slices column slices; a plan made for the register-resident
+    // kernels has the slice count of THEIR tiling, which is a valid (just not tuned) slice count here too
+#define CROSSCLR_LB2(DC, SW, RM) LAUNCH((bwd_kernel<T, DC, SW, RM>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)rows, (const T*)cols, g, \
+                                        rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, tps, krows, kcols, shift_rows, shift_cols)
+#define CROSSCLR_LB(DC)                                          \
+    do {                                                          \
+        if (shift_rows) { if (krows) CROSSCLR_LB2(DC, true, true); else CROSSCLR_LB2(DC, false, true); }   \
+        else { if (krows) CROSSCLR_LB2(DC, true, false); else CROSSCLR_LB2(DC, false, false); }            \
     } while (0)
     if (p->Dpad % 256 == 0) CROSSCLR_LB(256);
     else if (p->Dpad % 128 == 0) CROSSCLR_LB(128);
     else CROSSCLR_LB(64);
 #undef CROSSCLR_LB
+#undef CROSSCLR_LB2
     return launch_status("bwd_kernel");
 }
 
@@ -478,9 +568,30 @@ extern "C" int crossclr_backward_w(const crossclr_plan* plan, const void* xhat_r
     }
 #endif
     if (plan->mode == CROSSCLR_MODE_FP32)
-        return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, stream);
-    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, stream);
+        return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, nullptr, nullptr, stream);
+    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, nullptr, nullptr, stream);
 }
+
+extern "C" int crossclr_backward_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols, int col_ranks,
+                                   int col_rank0, int skip_rank, float temperature, float negative_weight,
+                                   const float* rz_rows, const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
+                                   const crossclr_sample_weights* sw, const float* shift_rows, const float* shift_cols,
+                                   float* gbuf, int accumulate, void* stream) {
+    if (!shift_rows && !shift_cols)
+        return crossclr_backward_w(plan, xhat_rows, xhat_cols, col_ranks, col_rank0, skip_rank, temperature, negative_weight, rz_rows,
+                                   wrz_rows, rz_cols, wrz_cols, sw, gbuf, accumulate, stream);
+    if (!plan || !xhat_rows || !xhat_cols || !rz_rows || !wrz_rows || !rz_cols || !wrz_cols || !gbuf || !shift_rows || !shift_cols)
+        return fail(CROSSCLR_E_ARG, "NULL argument");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = make_geo(plan, col_ranks, col_rank0, skip_rank, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    if (plan->mode == CROSSCLR_MODE_FP32)
+        return backward_generic<float>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, shift_rows, shift_cols, stream);
+    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, shift_rows, shift_cols, stream);
+}
+
 
 template <typename TIN>
 static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const void* v, const void* t, long ldv, long ldt,

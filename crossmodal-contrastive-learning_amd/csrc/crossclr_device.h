@@ -45,7 +45,9 @@ struct Geo {
                     // array of W ranks and segment i is rank (col_rank0+i) mod W at offset of that rank
     float c_inter;  // log2(e)/tau
     float c_intra;  // negative_weight*log2(e)/tau
-    float m2;       // soft-max shift, log2 domain
+    float m2;       // soft-max shift, log2 domain (0 when row_shift is set)
+    int row_shift;  // 1: max |logit| is beyond any fixed shift in fp32 (temperature < ~0.008): the generic kernels take a per-row
+                    // shift (the row maximum, found by a first pass) like the reference's float64 soft-max does (loss.py:60)
 };
 
 // ---------------------------------------------------------------------------------------------

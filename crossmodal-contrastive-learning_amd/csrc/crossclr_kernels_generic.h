@@ -170,9 +170,12 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 //   slot -> no atomics, deterministic.
 // ---------------------------------------------------------------------------------------------
 //   SW (sample weights): the exponential of an INTRA-modal column q is multiplied by kcols[q] (include/crossclr.h).
-template <typename T, bool SW>
+//   MODE 0: sums of exp2(x - g.m2) (one shift for everything).  Small temperatures (Geo::row_shift) take two passes:
+//   MODE 1: the slot receives the row MAXIMUM of the scaled logits x over the slot's unmasked columns (columns with k_q = 0 do
+//           not count: they are not in the soft-max), MODE 2: sums of exp2(x - shift[p]) with the per-row shift of pass 1.
+template <typename T, bool SW, int MODE>
 __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
-                                                       float* part, const float* kcols) {
+                                                       float* part, const float* kcols, const float* shift) {
     typedef Operand<T> Op;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
@@ -195,7 +198,10 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
     int t_end = t_begin + tiles_per_split;
     if (t_end > ntiles) t_end = ntiles;
 
-    float rowacc[2] = {0.f, 0.f};
+    const float kNone = -3.0e38f;   // "no unmasked column yet" (MODE 1)
+    float rowacc[2] = {MODE == 1 ? kNone : 0.f, MODE == 1 ? kNone : 0.f};
+    float myshift[2] = {0.f, 0.f};
+    if (MODE == 2) { myshift[0] = shift[row0 + 64 * wr + l31]; myshift[1] = shift[row0 + 64 * wr + 32 + l31]; }
     KTileStage<128, 256> sp, sq;
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -253,24 +259,45 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * r4 + j;
                         const int q_t = 64 * wc + 32 * qi + frag_row(r, half);
-                        float e = fast_exp2(acc[qi][pi][r] * c2 - g.m2);
-                        if (SW) e *= kq[j];
-                        if (ragged && ct.in_mod0 + q_t >= g.b) e = 0.f;
-                        if (diag_tile && q_t == p_t) e = 0.f;
-                        rowacc[pi] += e;
+                        const bool masked = (ragged && ct.in_mod0 + q_t >= g.b) || (diag_tile && q_t == p_t);
+                        if (MODE == 1) {
+                            const float x = acc[qi][pi][r] * c2;
+                            if (!masked && !(SW && kq[j] == 0.f)) rowacc[pi] = fmaxf(rowacc[pi], x);
+                        } else {
+                            float e = fast_exp2(acc[qi][pi][r] * c2 - (MODE == 2 ? myshift[pi] : g.m2));
+                            if (SW) e *= kq[j];
+                            if (masked) e = 0.f;
+                            rowacc[pi] += e;
+                        }
                     }
                 }
             }
     }
     // combine the two lane halves, then the two column waves
-    rowacc[0] += wave_xor_f32(rowacc[0], 32);
-    rowacc[1] += wave_xor_f32(rowacc[1], 32);
+    if (MODE == 1) {
+        rowacc[0] = fmaxf(rowacc[0], wave_xor_f32(rowacc[0], 32));
+        rowacc[1] = fmaxf(rowacc[1], wave_xor_f32(rowacc[1], 32));
+    } else {
+        rowacc[0] += wave_xor_f32(rowacc[0], 32);
+        rowacc[1] += wave_xor_f32(rowacc[1], 32);
+    }
     if (half == 0) {
         red[wc * 128 + 64 * wr + l31] = rowacc[0];
         red[wc * 128 + 64 * wr + 32 + l31] = rowacc[1];
     }
     __syncthreads();
-    if (tid < 128) part[(size_t)blockIdx.y * 2 * g.bpad + row0 + tid] = red[tid] + red[128 + tid];
+    if (tid < 128)
+        part[(size_t)blockIdx.y * 2 * g.bpad + row0 + tid] = MODE == 1 ? fmaxf(red[tid], red[128 + tid]) : red[tid] + red[128 + tid];
+}
+// pass 1 of the two-pass soft-max, second half: shift[p] = max(slot maxima, own previous value if `accumulate`, and the masked
+// self pair's logit 0 when it is part of the row's soft-max: k_p != 0)
+__global__ void __launch_bounds__(256) rowmax_combine_kernel(const float* part, int nslots, int n, const float* krows, int accumulate,
+                                                             float* shift) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    float m = accumulate ? shift[p] : ((krows && krows[p] == 0.f) ? -3.0e38f : 0.f);
+    for (int k = 0; k < nslots; ++k) m = fmaxf(m, part[(size_t)k * n + p]);
+    shift[p] = m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -292,14 +319,16 @@ __device__ __forceinline__ int fin_prefix(int kind, int tpr, int NT, int rb) {
 __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nlaunch, int slots_per_launch, Geo g,
                                                          const float* diag_cos, float inv_tau, float neg_w, float* logz,
                                                          float* rz, float* wrz, double* loss_ws, const float* colpart,
-                                                         const int* header, const float* krows, const float* lw) {
+                                                         const int* header, const float* krows, const float* lw,
+                                                         const float* row_shift) {
     CROSSCLR_SHARED double red[4];
     const int n = 2 * g.bpad;
-    const double shift = (double)g.m2 * (double)kLn2;
-    const double self_term = exp(-shift);
     double acc = 0.0;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         const int mod = p / g.bpad, i = p - mod * g.bpad;
+        // shift of this row's sums (natural log): one value for the whole launch, or the row's own maximum (two-pass mode)
+        const double shift = (row_shift ? (double)row_shift[p] : (double)g.m2) * (double)kLn2;
+        const double self_term = exp(-shift);
         double s = krows ? self_term * (double)krows[p] : self_term;   // the masked self pair travels with its column
         for (int L = 0; L < nlaunch; ++L) {
             const int kind = header[4 * L], tpr = header[4 * L + 1], NT = header[4 * L + 2], per = header[4 * L + 3];
@@ -447,11 +476,14 @@ __device__ __forceinline__ void bwd_gemm2(const unsigned char* wt, const unsigne
 }
 
 // SW (sample weights): the intra-modal weight is s E (wrz_p k_q + wrz_q k_p) instead of s E (wrz_p + wrz_q).
-template <typename T, int DC, bool SW>
+// RM (two-pass soft-max, small temperatures): rz = omega / (row sum relative to the ROW's shift), so the weight is
+//    s (exp2(x - shift_p) wrz_p k_q + exp2(x - shift_q) wrz_q k_p)  -- two exponentials, both <= 1: nothing can overflow.
+template <typename T, int DC, bool SW, bool RM>
 __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, Geo g, const float* rz_rows,
                                                   const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
                                                   float* gbuf, int accumulate, int tiles_per_slice,
-                                                  const float* krows, const float* kcols) {
+                                                  const float* krows, const float* kcols,
+                                                  const float* shift_rows, const float* shift_cols) {
     typedef Operand<T> Op;
     typedef BwdLds<T, DC> L;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[L::kTotal];
@@ -486,6 +518,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
     const float rzp_inter = rz_rows[row0 + p_t];
     const float rzp_intra = wrz_rows[row0 + p_t];
     const float kp = SW ? krows[row0 + p_t] : 1.f;
+    const float shp = RM ? shift_rows[row0 + p_t] : 0.f;
 
     // column slice z walks its share of the USABLE tiles (the skipped rank's segment is cut out of the numbering,
     // so the slices stay balanced) ...
@@ -545,11 +578,20 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
             f32x4 kq = {1.f, 1.f, 1.f, 1.f};
             if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + q0);
             const float kpe = (SW && same_mod) ? kp : 1.f;
+            f32x4 shq = {0.f, 0.f, 0.f, 0.f};
+            if (RM) shq = *reinterpret_cast<const f32x4*>(shift_cols + ct.stat0 + q0);
             f32x4 w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float e = fast_exp2(acc[4 * r4 + j] * c2 - g.m2);
-                float v = SW ? e * (rzp * kq[j] + rq[j] * kpe) : e * (rzp + rq[j]);
+                float v;
+                if (RM) {
+                    const float x = acc[4 * r4 + j] * c2;
+                    const float ep = fast_exp2(x - shp), eq = fast_exp2(x - shq[j]);
+                    v = SW ? (ep * rzp * kq[j] + eq * rq[j] * kpe) : (ep * rzp + eq * rq[j]);
+                } else {
+                    const float e = fast_exp2(acc[4 * r4 + j] * c2 - g.m2);
+                    v = SW ? e * (rzp * kq[j] + rq[j] * kpe) : e * (rzp + rq[j]);
+                }
                 if (diag_tile && q0 + j == p_t) v = 0.f;
                 w[j] = v;
             }
@@ -559,16 +601,21 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
         // ---------------- phase C ----------------
         bwd_gemm2<DC>(wt, xq, wr, wc * (DC / 2), lane, acc2, (T*)nullptr);
     }
-    // G[row][d]: lane holds column d = l31 of each fragment, 16 rows
+    // G[row][d]: lane holds column d = l31 of each fragment, 16 rows ... into its own slice
+    float* gslice = gbuf + (size_t)blockIdx.z * 2 * g.bpad * g.Dpad;
+    if (accumulate) {
 #pragma unroll
-    for (int dt = 0; dt < DC / 64; ++dt)
+        for (int dt = 0; dt < DC / 64; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + 32 * wr + frag_row(r, half);
-            const int d = d0 + wc * (DC / 2) + 32 * dt + l31;
-            float* dst = gbuf + (size_t)blockIdx.z * 2 * g.bpad * g.Dpad + (size_t)row * g.Dpad + d;  // ... into its own slice
-            *dst = accumulate ? (*dst + acc2[dt][r]) : acc2[dt][r];
-        }
+            for (int r = 0; r < 16; ++r)
+                gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] += acc2[dt][r];
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DC / 64; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] = acc2[dt][r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -596,7 +643,7 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
     // positive pair: -(omega_v,i + omega_t,i)/(2 B tau) * partner  (= -1/(B tau) without sample weights)
     const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
-    const bool clamped = io >= 1e12;  // ||x|| < eps: x/eps, no projection term
+    const bool clamped = io >= 9.99e11;  // ||x|| < eps: x/eps, no projection term (inv_norm is stored as float: (float)1e12 = 999999995904)
     const double go = grad_out[0];
     if (g.D <= 256 * kRowCache) {
         double gh[kRowCache][4], xh[kRowCache][4];

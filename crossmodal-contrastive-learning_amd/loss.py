@@ -15,7 +15,9 @@ C-ABI in include/crossclr.h; no B x B tensor is ever materialised.
 Keyword-only additions (defaults reproduce the reference's single-process behaviour):
   compute_mode   "auto" | "fp32" | "bf16".  fp32 = exact-fp32 MFMA; bf16 = bf16 operands with
                  fp32 accumulation (the BASELINE headline mode).  auto = bf16 when the global
-                 batch is >= 1024 rows (where its error is ~1e-4 on the loss), fp32 below that.
+                 batch is >= 1024 rows (where its error is ~1e-5 on the loss; a one-time warning says so
+                 for fp32/fp64 inputs), fp32 below that and whenever max(1,|w|)/temperature > 128
+                 (small temperatures: the two-pass soft-max regime, where bf16 cosines are too coarse).
   process_group  a torch.distributed group: the batch is the concatenation of every rank's rows
                  (equal count per rank); the returned loss is the GLOBAL loss on every rank and the
                  gradients are exactly d(global loss)/d(local rows).
@@ -57,13 +59,28 @@ def _row_major(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
 
 
-def _resolve_mode(compute_mode: str, global_batch: int) -> int:
+_warned_auto_bf16 = False
+
+
+def _resolve_mode(compute_mode: str, global_batch: int, in_dtype=None, small_temperature: bool = False) -> int:
+    global _warned_auto_bf16
     if compute_mode == "fp32":
         return nat.MODE_FP32
     if compute_mode == "bf16":
         return nat.MODE_BF16
     if compute_mode == "auto":
-        return nat.MODE_BF16 if global_batch >= AUTO_BF16_MIN_GLOBAL_BATCH else nat.MODE_FP32
+        # bf16 rounds a cosine to 2^-9; the logit carries that times 1/tau: at small temperatures (the two-pass regime) only
+        # exact-fp32 products keep the 1e-3 loss bar, and the generic kernels run there in either mode anyway
+        if global_batch < AUTO_BF16_MIN_GLOBAL_BATCH or small_temperature:
+            return nat.MODE_FP32
+        if in_dtype in (torch.float32, torch.float64) and not _warned_auto_bf16:
+            _warned_auto_bf16 = True
+            import warnings
+            warnings.warn("CrossCLR compute_mode='auto': global batch >= %d, using bf16 operands with fp32 accumulation for the "
+                          "similarity products of these %s inputs (loss within ~1e-5, gradients within ~5e-3 of the fp32 "
+                          "reference); pass compute_mode='fp32' for exact-fp32 products. This message is shown once."
+                          % (AUTO_BF16_MIN_GLOBAL_BATCH, str(in_dtype).replace("torch.", "")), stacklevel=3)
+        return nat.MODE_BF16
     raise ValueError(f"compute_mode must be 'auto', 'fp32' or 'bf16', got {compute_mode!r}")
 
 
@@ -71,7 +88,7 @@ class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
-                 "k_rows", "k_cols", "lw", "stats_work", "stash")
+                 "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols")
 
 
 def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor]:
@@ -114,7 +131,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # with skip_rank, statistics gather, loss all-reduce) even for a 1-rank group, so the collectives and the
     # skip logic can be exercised on a single GPU
     sharded = world > 1 or (group is not None and os.environ.get("CROSSCLR_FORCE_SHARDED_PATH") == "1")
-    mode = _resolve_mode(compute_mode, b * world)
+    small_tau = bool(lib.crossclr_needs_row_shift(float(temperature), float(negative_w)))
+    mode = _resolve_mode(compute_mode, b * world, video.dtype, small_tau)
     plan = nat.make_plan(b, D, world, rank, mode)
     stream = _stream_for(video)
     f32 = dict(dtype=torch.float32, device=dev)
@@ -150,6 +168,12 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
             dist.all_gather_into_tensor(ws.k_cols, ws.k_rows, group=group)
     else:
         ws.xcols = ws.xhat
+    # Small temperatures (max |logit| = max(1,|w|)/tau > 128): no single soft-max shift fits fp32.  Like the reference's
+    # float64 soft-max (loss.py:60) the rows then get their own shift -- the row maximum, found by a first pass -- and the
+    # generic tiled kernels do the rest (no symmetric evaluation, no pair scheme, no save-for-backward in this regime).
+    ws.shift = ws.shift_cols = None
+    if lib.crossclr_needs_row_shift(ws.temperature, ws.negative_w):
+        return _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev)
     # Local (symmetric) block.  When a backward will follow and the plan offers it, the forward also saves its bf16
     # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
     # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
@@ -214,6 +238,46 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     return loss, ws
 
 
+def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev):
+    """Two-pass forward (include/crossclr.h, "two-pass soft-max"): row maxima, then sums relative to them."""
+    import torch.distributed as dist
+    plan = ws.plan
+    pp = ctypes.byref(plan)
+    f32 = dict(dtype=torch.float32, device=dev)
+    ws.stash = None
+    ws.shift = torch.empty(2 * plan.bpad, **f32)
+    sw_loc, sw_all = _sw(ws.k_rows, ws.k_rows, None), _sw(ws.k_rows, ws.k_cols, None)
+    T, w = ws.temperature, ws.negative_w
+    nat.check(lib.crossclr_forward_rowmax(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, T, w, sw_loc, _ptr(part), _ptr(ws.shift), 0,
+                                          stream))
+    if ws.sharded:
+        gather.wait()
+        nat.check(lib.crossclr_forward_rowmax(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(part),
+                                              _ptr(ws.shift), 1, stream))
+    nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, stream))
+    nlaunch = 1
+    if ws.sharded:
+        nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(ws.shift), _ptr(part),
+                                         plan.fwd_slots, stream))
+        nlaunch = 2
+    nat.check(lib.crossclr_forward_finish_s(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), T, w,
+                                            _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.shift), _ptr(ws.logz), _ptr(ws.rz), _ptr(ws.wrz),
+                                            _ptr(ws.loss_sum), stream))
+    if ws.sharded:
+        # the remote backward needs every rank's omega/Z' AND the shifts they are relative to: one gather of both
+        both = torch.cat([ws.rz, ws.shift])
+        gathered = torch.empty(world * both.numel(), **f32)
+        ws.stats_work = dist.all_gather_into_tensor(gathered, both, group=group, async_op=True)
+        ws.rz_cols, ws.wrz_cols, ws.shift_cols = gathered, None, None   # split after the wait, in the backward
+        total = ws.loss_sum[:1].clone()
+        dist.all_reduce(total, group=group)
+    else:
+        ws.rz_cols, ws.wrz_cols, ws.shift_cols, ws.stats_work = ws.rz, ws.wrz, ws.shift, None
+        total = ws.loss_sum[:1]
+    loss = (total / (2.0 * b * world)).reshape(())
+    return loss, ws
+
+
 def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad_out: torch.Tensor):
     lib = nat.library()
     plan = ws.plan
@@ -223,7 +287,22 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
     rank, world = ws.rank, ws.world
     rz_loc, wrz_loc = ws.rz, ws.wrz   # column statistics of the local block = this rank's row statistics
-    if ws.stash is not None:
+    if ws.shift is not None:   # two-pass (small temperature) regime: generic kernels with per-row shifts
+        nat.check(lib.crossclr_backward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                          _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None),
+                                          _ptr(ws.shift), _ptr(ws.shift), _ptr(gbuf), 0, stream))
+        if ws.sharded:
+            if ws.wrz_cols is None:
+                ws.stats_work.wait()
+                n2 = ws.rz.numel()
+                both = ws.rz_cols.view(world, 2, n2)
+                ws.rz_cols = both[:, 0].contiguous().view(-1)
+                ws.shift_cols = both[:, 1].contiguous().view(-1)
+                ws.wrz_cols = ws.rz_cols * ws.negative_w
+            nat.check(lib.crossclr_backward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature, ws.negative_w,
+                                              _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols),
+                                              _sw(ws.k_rows, ws.k_cols, None), _ptr(ws.shift), _ptr(ws.shift_cols), _ptr(gbuf), 1, stream))
+    elif ws.stash is not None:
         nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
                                               _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
                                               stream))
@@ -232,7 +311,7 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                           _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
                                           _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
-    if ws.sharded:
+    if ws.sharded and ws.shift is None:
         if ws.wrz_cols is None:
             ws.stats_work.wait()
             ws.wrz_cols = ws.rz_cols * ws.negative_w

@@ -49,7 +49,7 @@ extern "C" {
 /* error codes */
 #define CROSSCLR_OK 0
 #define CROSSCLR_E_ARG (-1)      /* bad shape / pointer / enum                       */
-#define CROSSCLR_E_RANGE (-2)    /* temperature too small for the fixed-shift softmax */
+#define CROSSCLR_E_RANGE (-2)    /* temperature too small for the fixed-shift softmax: use the two-pass entry points */
 #define CROSSCLR_E_HIP (-3)      /* a HIP call failed (text in crossclr_last_error)   */
 #define CROSSCLR_E_WORKSPACE (-4)/* workspace too small                               */
 
@@ -200,6 +200,37 @@ int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float tem
 int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash,
                             float temperature, float negative_weight, const float* rz, const float* wrz,
                             const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+
+/* ---- two-pass soft-max for small temperatures (ABI version 3) ------------------------------------------------------
+ * The reference's soft-max runs in float64 with a per-row maximum (loss.py:60 after the promotion at :96-100), so it is
+ * finite for any temperature; the single common shift of the entry points above covers max |logit| =
+ * max(1, |negative_weight|) / temperature <= 128 (they return CROSSCLR_E_RANGE beyond it).  crossclr_needs_row_shift says when
+ * that limit is exceeded; then
+ *   1. crossclr_forward_rowmax: shift_rows[2][bpad] = the rows' maxima of the scaled logits (log2 domain) over the given
+ *      columns and -- unless k_p = 0 -- the masked self pair's logit 0; `accumulate` = 1 folds a further column operand into an
+ *      existing result (remote ranks' columns); `part` is scratch (the slots of one launch group);
+ *   2. crossclr_forward_s / crossclr_forward_finish_s: the sums relative to the row's own shift; rz / wrz come out relative to
+ *      that shift too (values in [1/(2B), 1]);
+ *   3. crossclr_backward_s with the shifts of the rows and of the columns (the statistics layout): the weight becomes
+ *      s (exp2(x - shift_p) rz_p k_q + exp2(x - shift_q) rz_q k_p), two exponentials <= 1.
+ * These run on the generic tiled kernels in both compute modes (the register-resident kernels and the save-for-backward
+ * pair assume the common shift).  With shift pointers NULL the _s entry points are the _w ones.                         */
+int crossclr_needs_row_shift(float temperature, float negative_weight);
+int crossclr_forward_rowmax(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                            int col_ranks, int col_rank0, int skip_rank, float temperature, float negative_weight,
+                            const crossclr_sample_weights* sw, float* part, float* shift_rows, int accumulate, void* stream);
+int crossclr_forward_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                       int col_ranks, int col_rank0, int skip_rank, float temperature, float negative_weight,
+                       const crossclr_sample_weights* sw, const float* shift_rows, float* part, int slot0, void* stream);
+int crossclr_forward_finish_s(const crossclr_plan* plan, const float* part, int nslots,
+                              const float* diag_cos, float temperature, float negative_weight,
+                              const crossclr_sample_weights* sw, const float* shift_rows,
+                              float* logz, float* rz, float* wrz, double* loss_sum, void* stream);
+int crossclr_backward_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_cols,
+                        int col_ranks, int col_rank0, int skip_rank, float temperature, float negative_weight,
+                        const float* rz_rows, const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
+                        const crossclr_sample_weights* sw, const float* shift_rows, const float* shift_cols,
+                        float* gbuf, int accumulate, void* stream);
 
 /* ---- influential-sample statistics (ABI version 2; SURVEY.md 8(f) rank 1, not in the reference @ v1) ----
  * From INPUT-space features x[b][Din] of both modalities (any float dtype, row stride ld):

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, B, D, mode, q):
+def _worker(rank, world, port, B, D, mode, q, tau=0.05):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -31,10 +31,10 @@ def _worker(rank, world, port, B, D, mode, q):
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
         tl = t[rank * b:(rank + 1) * b].clone().requires_grad_(True)
-        crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.7, compute_mode=mode, process_group=dist.group.WORLD)
+        crit = crossclr_amd.CrossCLR_onlyIntraModality(tau, 0.7, compute_mode=mode, process_group=dist.group.WORLD)
         loss = crit(vl, tl)
         loss.backward()
-        ref = orc.sharded_loss_and_grads(v, t, world, rank, 0.05, 0.7)
+        ref = orc.sharded_loss_and_grads(v, t, world, rank, tau, 0.7)
         scale = ref["grad_v"].abs().max().item()
         q.put((rank, float(loss), float(ref["loss"]),
                (vl.grad.double() - ref["grad_v"]).abs().max().item() / scale,
@@ -48,6 +48,10 @@ def _worker(rank, world, port, B, D, mode, q):
 # bf16 with >= 3 ranks takes the pair scheme (crossclr_forward_pairs + column-sum exchange): 3 ranks = one pair each,
 # 4 ranks = one pair + the antipodal rank, 5 ranks = two pairs with rank wrap-around
 @pytest.mark.parametrize("world,B,D,mode,ltol,gtol", [(2, 24, 20, "fp32", 1e-5, 2e-4),
+                                                       # tau = 0.004: the two-pass soft-max (row maxima over local + remote columns,
+                                                       # shifts gathered for the remote backward); "fp32/0.004" encodes the temperature
+                                                       (2, 24, 20, "fp32/0.004", 1e-4, 1e-3),
+                                                       (3, 18, 16, "fp32/0.002", 1e-4, 1e-3),
                                                        (2, 40, 48, "bf16", 5e-3, 2e-2),
                                                        (3, 18, 16, "fp32", 1e-5, 2e-4),
                                                        (3, 24, 16, "bf16", 5e-3, 2e-2),
@@ -62,7 +66,10 @@ def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, D, mode, q)) for r in range(world)]
+    tau = 0.05
+    if "/" in mode:
+        mode, tau = mode.split("/")[0], float(mode.split("/")[1])
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, D, mode, q, tau)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]

@@ -54,7 +54,9 @@ def test_fp32_mode_matches_golden_loss_and_grads(name):
     scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
     # + fp32 cancellation floor: the positive-pair term (p_ii - 1)/(B tau) is formed in fp32 here and in
     # fp64 by the reference's softmax; it matters only where the gradient itself is ~1e-14 (aligned regime)
-    gtol = (2e-2 if half_in else 2e-4) * scale + 1e-7 / (m["B"] * m["temperature"])
+    # the reference forms its logits from an fp32 GEMM (loss.py:83-93): a 6e-8 rounding of a cosine is a 6e-8/tau error of
+    # the logit, i.e. of the relative size of a soft-max weight -- at tau = 0.002 the reference's own noise is ~1e-4
+    gtol = (2e-2 if half_in else max(2e-4, 4e-7 / m["temperature"])) * scale + 1e-7 / (m["B"] * m["temperature"])
     assert np.abs(gv.double().cpu().numpy() - arr["grad_v"].astype(np.float64)).max() <= gtol
     assert np.abs(gt.double().cpu().numpy() - arr["grad_t"].astype(np.float64)).max() <= gtol
 
@@ -68,7 +70,9 @@ def test_bf16_mode_matches_bf16_operand_model(name):
     assert abs(loss.item() - model) <= 5e-5 * max(1.0, abs(model))
     arr = golden_arrays(name)
     scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
-    if m["loss"] > 1e-3:  # (the aligned regime has gradients ~1e-11: below what bf16 operands resolve)
+    # (the aligned regime has gradients ~1e-11: below what bf16 operands resolve; and a bf16 cosine (2^-9) times 1/tau is a
+    # logit error of 0.1-1 at tau <= 0.005: the gradient bar is stated, and held, at the reference's default temperature range)
+    if m["loss"] > 1e-3 and m["temperature"] >= 0.02:
         assert np.abs(gv.double().cpu().numpy() - arr["grad_v"].astype(np.float64)).max() <= 2e-2 * scale
         assert np.abs(gt.double().cpu().numpy() - arr["grad_t"].astype(np.float64)).max() <= 2e-2 * scale
 
@@ -93,13 +97,18 @@ def test_large_cases_sampled_rows(name, mode):
         pytest.skip("fp32 at B=8192 is covered by the forward-only test; keep the GPU suite short")
     v, t = golden_inputs(m)
     loss, gv, gt = run_module(v, t, m, mode)
-    ltol = 2e-5 * max(1.0, abs(m["loss"])) if mode == "fp32" else 1e-3
+    small_tau = max(1.0, abs(m["negative_weight"])) / m["temperature"] > 128      # two-pass regime: "auto" computes in fp32 there
+    exact = mode == "fp32" or (mode == "auto" and small_tau)
+    # explicit bf16 at small temperatures: a bf16 cosine (2^-9) times 1/tau -- the bars are stated at tau = 0.03
+    coarse = (0.03 / m["temperature"]) ** 2 if (small_tau and not exact) else 1.0
+    ltol = 2e-5 * max(1.0, abs(m["loss"])) if exact else 1e-3 * coarse
     assert abs(loss.item() - m["loss"]) <= ltol, (loss.item(), m["loss"])
     arr = golden_arrays(name)
     rows = arr["rows"]
     scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
-    if m["loss"] > 1e-3:
-        gtol = (2e-4 if mode == "fp32" else 1e-2) * scale
+    if m["loss"] > 1e-3 and coarse == 1.0:
+        mode = "fp32" if exact else mode
+        gtol = (max(2e-4, 4e-7 / m["temperature"]) if mode == "fp32" else 1e-2) * scale
         assert np.abs(gv[rows].cpu().numpy() - arr["grad_v_rows"]).max() <= gtol
         assert np.abs(gt[rows].cpu().numpy() - arr["grad_t_rows"]).max() <= gtol
         # norms of the whole gradient (catches errors outside the sampled rows)
@@ -261,8 +270,10 @@ def test_module_device_behaviour():
         crit(vd[None], td[None])
     with pytest.raises(RuntimeError):
         crit(v, t)  # CPU tensors: no CPU fallback
-    with pytest.raises(nat.CrossCLRNativeError):
-        crossclr_amd.crossclr_loss(vd, td, temperature=0.001)  # outside the fixed-shift range: loud, not inf
+    # outside the fixed-shift range the module takes the two-pass soft-max (like the reference's float64 one): finite, right
+    tiny = crossclr_amd.crossclr_loss(vd, td, temperature=0.001)
+    ref = orc.streaming_stats(v, t, 0.001, 0.8)
+    assert torch.isfinite(tiny) and abs(tiny.item() - float(ref["loss"])) <= 1e-4 * float(ref["loss"])
 
 
 def test_sharded_host_path_with_real_collectives_on_one_gpu(monkeypatch):

@@ -34,7 +34,7 @@ def run(v, t, tau, w, mode, scale=1.0):
 
 TINY = ["g2_b8_d16_s1", "g4_b16_d32_s3_float32", "g4_b16_d32_s3_float64", "g4_b16_d32_s3_float16",
         "g4_b16_d32_s3_bfloat16", "g5_zero_row_b16_d32", "g5_b1_d32", "g5_w0_tau01_b16_d32", "g5_tau01_b16_d32",
-        "g5_tau002_b32_d64"]
+        "g5_tau002_b32_d64", "g5_tau0005_b32_d64", "g5_tau0002_b64_d128", "g5_tau0005_w4_b48_d40", "g5_tiny_row_b16_d32"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -150,14 +150,44 @@ def test_grad_output_scaling_and_noncontiguous_rows():
     assert lp.item() == l0.item()
 
 
-def test_temperature_outside_fixed_shift_range_fails_loudly():
+def test_small_temperatures_take_the_two_pass_soft_max():
+    """max |logit| > 128 (tau < 0.0078 at |w| <= 1): the reference still works (float64 soft-max with a row maximum,
+    loss.py:60); so does the module, through crossclr_forward_rowmax + the _s entry points.  The plain C-ABI entry points
+    keep refusing that range loudly (they have one common shift)."""
+    import ctypes
     v, t = orc.make_inputs("randn", 8, 16, 1)
-    with pytest.raises(nat.CrossCLRNativeError, match="too small"):
-        crossclr_amd.crossclr_loss(v, t, temperature=0.005, negative_weight=0.8, compute_mode="fp32")
-    # small but inside the range: shift is active (1/tau = 100 > 64), result must still be right
+    plan = nat.make_plan(8, 16, 1, 0, nat.MODE_FP32)
+    lib = nat.library()
+    assert lib.crossclr_needs_row_shift(0.005, 0.8) == 1 and lib.crossclr_needs_row_shift(0.03, 0.8) == 0
+    assert lib.crossclr_needs_row_shift(0.03, 4.0) == 1          # the bound is max(1, |w|) / tau
+    x = torch.zeros(plan.operand_bytes, dtype=torch.uint8)
+    part = torch.zeros(plan.fwd_ws_floats)
+    rc = lib.crossclr_forward(ctypes.byref(plan), x.data_ptr(), x.data_ptr(), 1, 0, -1, 0.005, 0.8, part.data_ptr(), 0, None)
+    assert rc == nat.E_RANGE and b"two-pass" in lib.crossclr_last_error()
+    for tau in (0.005, 0.002, 0.0005):
+        ref = orc.streaming_loss_and_grads(v, t, tau, 0.8)
+        for mode, ltol in (("fp32", 1e-4), ("bf16", 2e-2)):
+            loss, gv, gt = run(v, t, tau, 0.8, mode)
+            assert abs(loss.item() - float(ref["loss"])) <= ltol * max(1.0, float(ref["loss"])), (tau, mode)
+            if mode == "fp32":
+                scale = max(ref["grad_v"].abs().max().item(), ref["grad_t"].abs().max().item())
+                assert (gv.double() - ref["grad_v"]).abs().max().item() <= 1e-3 * scale
+                assert (gt.double() - ref["grad_t"]).abs().max().item() <= 1e-3 * scale
+    # small but inside the range: the common shift is active (1/tau = 100 > 64), result must still be right
     ref = orc.streaming_stats(v, t, 0.01, 0.8)
     out = crossclr_amd.crossclr_loss(v, t, temperature=0.01, negative_weight=0.8, compute_mode="fp32")
     assert abs(out.item() - float(ref["loss"])) <= 1e-4 * float(ref["loss"])
+
+
+def test_small_temperature_aligned_pairs_give_the_reference_zero():
+    # the positive pair dominates completely: the reference's float64 loss is exactly 0.0 with zero gradients
+    m = IDX["g5_tau0002_aligned_b128_d96"]
+    v, t = golden_inputs(m)
+    loss, gv, gt = run(v, t, m["temperature"], m["negative_weight"], "fp32")
+    # (logZ ~ 480 is carried in fp32 and the positive-pair logit is formed from an fp32 cosine: a 1e-5 cancellation floor,
+    # a hundred times under the 1e-3 bar)
+    assert m["loss"] == 0.0 and abs(loss.item()) <= 1e-4
+    assert gv.abs().max().item() <= 1e-3 and gt.abs().max().item() <= 1e-3
 
 
 def test_plan_geometry():
