@@ -8,8 +8,8 @@ through the `crossclr_amd` alias module at the repository root:
     criterion = crossclr_amd.CrossCLR_onlyIntraModality(temperature=0.03, negative_weight=0.8)
 """
 from . import _native
-from .loss import AUTO_BF16_MIN_GLOBAL_BATCH, CrossCLR_onlyIntraModality, crossclr_loss
+from .loss import AUTO_BF16_MIN_GLOBAL_BATCH, CrossCLR_onlyIntraModality, all_gather_with_grad, crossclr_loss
 from .influence import CrossCLR, influential_sample_weights
 
-__all__ = ["CrossCLR_onlyIntraModality", "CrossCLR", "crossclr_loss", "influential_sample_weights",
+__all__ = ["CrossCLR_onlyIntraModality", "CrossCLR", "crossclr_loss", "all_gather_with_grad", "influential_sample_weights",
            "AUTO_BF16_MIN_GLOBAL_BATCH", "_native"]

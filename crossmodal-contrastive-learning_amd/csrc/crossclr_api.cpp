@@ -55,6 +55,33 @@ extern "C" const char* crossclr_backend(void) {
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// tuning knobs from the environment, read ONCE per process (not per call: crossclr_make_plan sits on the step's host path)
+struct EnvKnobs {
+    bool disable_fast, disable_symmetric, disable_save;
+    int bwd_kernel, fwd_blocks, bwd_slices;
+    EnvKnobs() {
+        disable_fast = getenv("CROSSCLR_DISABLE_FAST") != nullptr;
+        disable_symmetric = getenv("CROSSCLR_DISABLE_SYMMETRIC") != nullptr;
+        disable_save = getenv("CROSSCLR_DISABLE_SAVE") != nullptr;
+        const char* e = getenv("CROSSCLR_BWD_KERNEL");
+        bwd_kernel = e ? atoi(e) : 0;
+        e = getenv("CROSSCLR_FWD_BLOCKS");
+        fwd_blocks = e ? atoi(e) : 0;
+        e = getenv("CROSSCLR_BWD_SLICES");
+        bwd_slices = e ? atoi(e) : 0;
+    }
+};
+static const EnvKnobs& env_knobs() {
+#ifdef CROSSCLR_EMU
+    static thread_local EnvKnobs k;   // the CPU tests flip these variables between calls (monkeypatch): re-read there
+    k = EnvKnobs();
+    return k;
+#else
+    static const EnvKnobs k;
+    return k;
+#endif
+}
 static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
                            const float* kcols, const float* shift, int mode, void* stream);
 
@@ -99,15 +126,22 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     if (b < 1 || D < 1) return fail(CROSSCLR_E_ARG, "need b >= 1 and D >= 1 (got b=%d D=%d)", b, D);
     if (world < 1 || rank < 0 || rank >= world) return fail(CROSSCLR_E_ARG, "bad world/rank %d/%d", world, rank);
     if (mode != CROSSCLR_MODE_FP32 && mode != CROSSCLR_MODE_BF16) return fail(CROSSCLR_E_ARG, "bad mode %d", mode);
-    // the forward's flat work list is indexed with 32-bit integers: (2b/256 row blocks) x (2B/32 column tiles) < 2^31
-    if ((long long)b * world > (1 << 21)) return fail(CROSSCLR_E_ARG, "global batch %lld too large (limit 2^21 rows)", (long long)b * world);
+    // the forward's flat work list, the stash and the column-sum workspace are indexed with 32-bit integers:
+    // (2b/128 row blocks) x (2B/32 column tiles) must stay below 2^31 (whichever kernel the plan ends up with)
+    {
+        const long long bp = ((long long)b + kRowPad - 1) / kRowPad * kRowPad;
+        const long long items = (2 * bp / 128) * (2 * bp * world / 32);
+        if ((long long)b * world > (1 << 21) || items >= (1LL << 31))
+            return fail(CROSSCLR_E_ARG, "batch too large: b=%d x world=%d gives %lld work items (limit 2^31; global rows limit 2^21)", b, world, items);
+    }
     memset(plan, 0, sizeof(*plan));
     plan->b = b; plan->D = D; plan->world = world; plan->rank = rank; plan->mode = mode;
     plan->bpad = round_up(b, kRowPad);
     plan->fast_path = 0;
     int dpad = round_up(D, 64);
 #ifndef CROSSCLR_NO_FAST
-    if (mode == CROSSCLR_MODE_BF16 && !getenv("CROSSCLR_DISABLE_FAST")) {  // env knob: A/B against the generic path
+    const EnvKnobs& env = env_knobs();
+    if (mode == CROSSCLR_MODE_BF16 && !env.disable_fast) {  // env knob: A/B against the generic path
         int fp = fast_dpad(D);
         if (fp > 0) { dpad = fp; plan->fast_path = 1; }
     }
@@ -117,12 +151,10 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     // backward kernel: 0 generic tiled, 1 register-resident 32-row waves (Dpad <= 512), 2 16-row waves (Dpad <= 1024)
     plan->fast_bwd = 0;
 #ifndef CROSSCLR_NO_FAST
-    if (mode == CROSSCLR_MODE_BF16 && !getenv("CROSSCLR_DISABLE_FAST")) {
+    if (mode == CROSSCLR_MODE_BF16 && !env.disable_fast) {
         if (plan->fast_path) plan->fast_bwd = dpad <= 512 ? CROSSCLR_DEFAULT_BWD_KERNEL : 2;
-        if (const char* e = getenv("CROSSCLR_BWD_KERNEL")) {  // tuning knob: 16 or 32
-            if (atoi(e) == 16 && plan->fast_path) plan->fast_bwd = 2;
-            if (atoi(e) == 32 && plan->fast_path && dpad <= 512) plan->fast_bwd = 1;
-        }
+        if (env.bwd_kernel == 16 && plan->fast_path) plan->fast_bwd = 2;              // tuning knob: 16 or 32
+        if (env.bwd_kernel == 32 && plan->fast_path && dpad <= 512) plan->fast_bwd = 1;
     }
 #endif
     // forward partial-sum slots.  generic kernels: (row block x column split) grid, enough work items to
@@ -137,10 +169,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
 #ifndef CROSSCLR_NO_FAST
     if (plan->fast_path) {
         plan->fwd_blocks = 256;  // one persistent block per MI355X CU (LDS-limited to one block per CU)
-        if (const char* e = getenv("CROSSCLR_FWD_BLOCKS")) {  // tuning knob
-            int v = atoi(e);
-            if (v >= 1 && v <= 4096) plan->fwd_blocks = v;
-        }
+        if (env.fwd_blocks >= 1 && env.fwd_blocks <= 4096) plan->fwd_blocks = env.fwd_blocks;   // tuning knob
         int slots = fwd_max_slots(fast_forward_work(plan, 1, -1, true));
         int s2 = fwd_max_slots(fast_forward_work(plan, 1, -1, false));
         if (s2 > slots) slots = s2;
@@ -173,10 +202,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         if (sl > tiles / 2) sl = tiles / 2;
         if (sl > 16) sl = 16;
         if (sl < 1) sl = 1;
-        if (const char* e = getenv("CROSSCLR_BWD_SLICES")) {  // tuning knob
-            int v = atoi(e);
-            if (v >= 1 && v <= tiles / 2 && v <= 64) sl = v;
-        }
+        if (env.bwd_slices >= 1 && env.bwd_slices <= tiles / 2 && env.bwd_slices <= 64) sl = env.bwd_slices;   // tuning knob
         plan->bwd_slices = sl;
     }
     {
@@ -190,7 +216,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     plan->gbuf_bytes = (size_t)plan->bwd_slices * 2 * plan->bpad * plan->Dpad * 4;
     plan->stash_bytes = 0;
 #ifndef CROSSCLR_NO_FAST
-    if (plan->fast_path && plan->fast_bwd && !getenv("CROSSCLR_DISABLE_SAVE")) plan->stash_bytes = fast_stash_bytes(plan->bpad, plan->Dpad);
+    if (plan->fast_path && plan->fast_bwd && !env.disable_save) plan->stash_bytes = fast_stash_bytes(plan->bpad, plan->Dpad);
 #endif
     return CROSSCLR_OK;
 }
@@ -230,33 +256,43 @@ static int make_geo(const crossclr_plan* p, int col_ranks, int col_rank0, int sk
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename TIN>
+template <typename TIN, bool NORM>
 static int normalize_t(const crossclr_plan* p, const void* v, const void* t, long ldv, long ldt, void* xhat,
                        float* inv_norm, float* diag, void* stream) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((p->bpad + 3) / 4), block(256);
     if (p->mode == CROSSCLR_MODE_FP32)
-        LAUNCH((normalize_kernel<TIN, float>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+        LAUNCH((normalize_kernel<TIN, float, NORM>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
                (float*)xhat, inv_norm, diag);
     else
-        LAUNCH((normalize_kernel<TIN, bf16_t>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+        LAUNCH((normalize_kernel<TIN, bf16_t, NORM>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
                (bf16_t*)xhat, inv_norm, diag);
     return launch_status("normalize_kernel");
+}
+template <bool NORM>
+static int normalize_any(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                         void* xhat, float* inv_norm, float* diag_cos, void* stream) {
+    if (!plan || !video || !text || !xhat || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (ld_video < plan->D || ld_text < plan->D) return fail(CROSSCLR_E_ARG, "row stride smaller than D");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return normalize_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F64: return normalize_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F16: return normalize_t<in_f16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_BF16: return normalize_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+extern "C" int crossclr_pack(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video,
+                             long ld_text, int in_dtype, void* xhat, float* inv_norm, float* diag_cos, void* stream) {
+    return normalize_any<false>(plan, video_hat, text_hat, ld_video, ld_text, in_dtype, xhat, inv_norm, diag_cos, stream);
 }
 
 extern "C" int crossclr_normalize(const crossclr_plan* plan, const void* video, const void* text, long ld_video,
                                   long ld_text, int in_dtype, void* xhat, float* inv_norm, float* diag_cos,
                                   void* stream) {
-    if (!plan || !video || !text || !xhat || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
-    if (ld_video < plan->D || ld_text < plan->D) return fail(CROSSCLR_E_ARG, "row stride smaller than D");
-    switch (in_dtype) {
-        case CROSSCLR_IN_F32: return normalize_t<float>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F64: return normalize_t<double>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F16: return normalize_t<in_f16>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_BF16: return normalize_t<in_bf16>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-    }
-    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+    return normalize_any<true>(plan, video, text, ld_video, ld_text, in_dtype, xhat, inv_norm, diag_cos, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,7 +352,7 @@ extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_ro
         // rows and columns are the same packed operand (the single-GPU case and the local block of a
         // sharded run): evaluate only the upper triangle of the symmetric matrix
         const bool symmetric = xhat_rows == xhat_cols && col_ranks == 1 && col_rank0 == plan->rank && skip_rank < 0 &&
-                               !getenv("CROSSCLR_DISABLE_SYMMETRIC");
+                               !env_knobs().disable_symmetric;
         const bool skipping = skip_rank >= col_rank0 && skip_rank < col_rank0 + col_ranks;
         if (col_ranks - (skipping ? 1 : 0) <= 0) {
             // nothing to do (every column rank is skipped): leave a dense, all-zero launch behind
@@ -596,12 +632,12 @@ extern "C" int crossclr_backward_s(const crossclr_plan* plan, const void* xhat_r
 template <typename TIN>
 static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const void* v, const void* t, long ldv, long ldt,
                              const float* inv_norm, float temperature, const double* grad_out, void* gv, void* gt,
-                             long ldgv, long ldgt, const float* lw, void* stream) {
+                             long ldgv, long ldgt, const float* lw, void* stream, int prenormalized = 0) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((2 * p->b + 3) / 4), block(256);
     LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,
-           1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw);
+           1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw, prenormalized);
     return launch_status("bwd_finish_kernel");
 }
 
@@ -619,15 +655,24 @@ extern "C" int crossclr_backward_finish_w(const crossclr_plan* plan, const float
                                           const float* inv_norm, float temperature, const crossclr_sample_weights* sw,
                                           const double* grad_out, void* grad_video, void* grad_text, long ld_gvideo,
                                           long ld_gtext, void* stream) {
+    return crossclr_backward_finish_p(plan, gbuf, video, text, ld_video, ld_text, in_dtype, inv_norm, temperature, sw, grad_out,
+                                      grad_video, grad_text, ld_gvideo, ld_gtext, 0, stream);
+}
+
+extern "C" int crossclr_backward_finish_p(const crossclr_plan* plan, const float* gbuf, const void* video,
+                                          const void* text, long ld_video, long ld_text, int in_dtype,
+                                          const float* inv_norm, float temperature, const crossclr_sample_weights* sw,
+                                          const double* grad_out, void* grad_video, void* grad_text, long ld_gvideo,
+                                          long ld_gtext, int prenormalized, void* stream) {
     const float* lw = sw ? sw->loss_weight : nullptr;
     if (!plan || !gbuf || !video || !text || !inv_norm || !grad_out || !grad_video || !grad_text)
         return fail(CROSSCLR_E_ARG, "NULL argument");
     if (!(temperature > 0.f)) return fail(CROSSCLR_E_ARG, "temperature must be > 0");
     switch (in_dtype) {
-        case CROSSCLR_IN_F32: return backward_finish_t<float>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
-        case CROSSCLR_IN_F64: return backward_finish_t<double>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
-        case CROSSCLR_IN_F16: return backward_finish_t<in_f16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
-        case CROSSCLR_IN_BF16: return backward_finish_t<in_bf16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream);
+        case CROSSCLR_IN_F32: return backward_finish_t<float>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream, prenormalized);
+        case CROSSCLR_IN_F64: return backward_finish_t<double>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream, prenormalized);
+        case CROSSCLR_IN_F16: return backward_finish_t<in_f16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream, prenormalized);
+        case CROSSCLR_IN_BF16: return backward_finish_t<in_bf16>(plan, gbuf, video, text, ld_video, ld_text, inv_norm, temperature, grad_out, grad_video, grad_text, ld_gvideo, ld_gtext, lw, stream, prenormalized);
     }
     return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
 }

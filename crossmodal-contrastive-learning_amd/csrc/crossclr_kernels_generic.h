@@ -93,7 +93,9 @@ __device__ __forceinline__ void op_store4(bf16_t* row, int d, const float (&v)[4
 // vhat_i . that_i (the positive-pair logit of loss.py:83 before /tau) comes out in fp32 for free.
 // HBM-bound: reads 2*B*D inputs once, writes the packed operand once.
 // ---------------------------------------------------------------------------------------------
-template <typename TIN, typename T>
+// NORM = false ("pack"): the rows are already unit vectors (the producer's projection head normalised them): they are only
+// cast / laid out into the packed operand, inv_norm = 1, and the positive-pair cosine is still formed in fp32 here.
+template <typename TIN, typename T, bool NORM = true>
 __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const TIN* text, long ldv, long ldt,
                                                         Geo g, T* X, float* inv_norm, float* diag_cos) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -133,6 +135,7 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
     // x / max(||x||, eps), eps = 1e-12 (F.normalize default)
     double nv = sqrt(ssv), nt = sqrt(sst);
     double iv = 1.0 / (nv > 1e-12 ? nv : 1e-12), it = 1.0 / (nt > 1e-12 ? nt : 1e-12);
+    if (!NORM) iv = it = 1.0;
     if (cached) {
 #pragma unroll
         for (int k = 0; k < kRowCache; ++k) {
@@ -628,7 +631,7 @@ template <typename TIN>
 __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int nslices, const TIN* video, const TIN* text, long ldv,
                                                          long ldt, Geo g, const float* inv_norm, float inv_tau,
                                                          int Bglobal, const double* grad_out, TIN* gvideo,
-                                                         TIN* gtext, long ldgv, long ldgt, const float* lw) {
+                                                         TIN* gtext, long ldgv, long ldgt, const float* lw, int prenormalized) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + wave;  // 0 .. 2*b-1
     if (idx >= 2 * g.b) return;
@@ -643,7 +646,9 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
     // positive pair: -(omega_v,i + omega_t,i)/(2 B tau) * partner  (= -1/(B tau) without sample weights)
     const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
-    const bool clamped = io >= 9.99e11;  // ||x|| < eps: x/eps, no projection term (inv_norm is stored as float: (float)1e12 = 999999995904)
+    // ||x|| < eps: x/eps, no projection term (inv_norm is stored as float: (float)1e12 = 999999995904); prenormalized rows:
+    // the gradient is the one w.r.t. the unit vectors as given (inv_norm = 1, no projection)
+    const bool clamped = io >= 9.99e11 || prenormalized != 0;
     const double go = grad_out[0];
     if (g.D <= 256 * kRowCache) {
         double gh[kRowCache][4], xh[kRowCache][4];

@@ -88,7 +88,42 @@ class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
-                 "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols")
+                 "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized")
+
+
+_plan_cache: dict = {}
+_checked_shapes: set = set()
+
+
+def _plan_for(b: int, D: int, world: int, rank: int, mode: int):
+    """crossclr_make_plan is pure in its arguments (and in tuning variables the library reads once): cache it."""
+    key = (b, D, world, rank, mode, nat.library_path())
+    plan = _plan_cache.get(key)
+    if plan is None:
+        if len(_plan_cache) > 256:
+            _plan_cache.clear()
+        plan = _plan_cache[key] = nat.make_plan(b, D, world, rank, mode)
+    return plan
+
+
+def _check_equal_rows_per_rank(b: int, D: int, group, dev) -> None:
+    """Every rank must bring the same [b, D] (the gathered operand is world x one rank's packed operand).  A mismatch would
+    otherwise surface as a hang or an opaque error inside all_gather_into_tensor; checked once per (group, shape)."""
+    import torch.distributed as dist
+    key = (id(group), b, D)
+    if key in _checked_shapes:
+        return
+    t = torch.tensor([b, -b, D, -D], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    lo_b, hi_b, lo_d, hi_d = -int(t[1]), int(t[0]), -int(t[3]), int(t[2])
+    if lo_b != hi_b or lo_d != hi_d:
+        raise RuntimeError(f"CrossCLR (sharded): every rank must pass the same number of rows and columns; this rank has "
+                           f"[{b}, {D}] but the group spans [{lo_b}..{hi_b}, {lo_d}..{hi_d}]")
+    _checked_shapes.add(key)
+
+
+def _carve(total: torch.Tensor, offset: int, nbytes: int, dtype):
+    return total[offset:offset + nbytes].view(dtype)
 
 
 def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor]:
@@ -120,7 +155,7 @@ def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
 
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
                   compute_mode: str, group, negative_scale=None, loss_weight=None,
-                  save_for_backward: bool = False) -> "tuple[torch.Tensor, _Workspace]":
+                  save_for_backward: bool = False, prenormalized: bool = False) -> "tuple[torch.Tensor, _Workspace]":
     import torch.distributed as dist
     lib = nat.library()
     dev = video.device
@@ -133,7 +168,9 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     sharded = world > 1 or (group is not None and os.environ.get("CROSSCLR_FORCE_SHARDED_PATH") == "1")
     small_tau = bool(lib.crossclr_needs_row_shift(float(temperature), float(negative_w)))
     mode = _resolve_mode(compute_mode, b * world, video.dtype, small_tau)
-    plan = nat.make_plan(b, D, world, rank, mode)
+    plan = _plan_for(b, D, world, rank, mode)
+    if world > 1:
+        _check_equal_rows_per_rank(b, D, group, dev)
     stream = _stream_for(video)
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -141,22 +178,33 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.plan, ws.world, ws.rank, ws.sharded = plan, world, rank, sharded
     ws.temperature, ws.negative_w = float(temperature), float(negative_w)
     ws.in_dtype = _IN_DTYPE[video.dtype]
-    ws.xhat = torch.empty(plan.operand_bytes, dtype=torch.uint8, device=dev)
-    ws.inv_norm = torch.empty(2 * plan.bpad, **f32)
-    ws.diag = torch.empty(plan.bpad, **f32)
+    # one allocation for everything the step keeps (a dozen torch.empty calls were a third of the host time at small batches):
+    # [xhat | loss_sum (doubles) | inv_norm | diag | logz | rz | wrz | part], every piece 256-byte aligned
+    n2 = 2 * plan.bpad
+    sizes = [plan.operand_bytes, 8 * plan.loss_ws_doubles, 4 * n2, 4 * plan.bpad, 4 * n2, 4 * n2, 4 * n2, 4 * plan.fwd_ws_floats]
+    offs, tot = [], 0
+    for sz in sizes:
+        offs.append(tot)
+        tot += (sz + 255) // 256 * 256
+    slab = torch.empty(tot, dtype=torch.uint8, device=dev)
+    ws.xhat = slab[offs[0]:offs[0] + sizes[0]]
+    ws.loss_sum = _carve(slab, offs[1], sizes[1], torch.float64)
+    ws.inv_norm = _carve(slab, offs[2], sizes[2], torch.float32)
+    ws.diag = _carve(slab, offs[3], sizes[3], torch.float32)
+    ws.logz = _carve(slab, offs[4], sizes[4], torch.float32)
+    ws.rz = _carve(slab, offs[5], sizes[5], torch.float32)
+    ws.wrz = _carve(slab, offs[6], sizes[6], torch.float32)
+    part = _carve(slab, offs[7], sizes[7], torch.float32)
     nlaunch = 2 if sharded else 1
-    part = torch.empty(plan.fwd_ws_floats, **f32)
-    ws.logz = torch.empty(2 * plan.bpad, **f32)
-    ws.rz = torch.empty(2 * plan.bpad, **f32)
-    ws.wrz = torch.empty(2 * plan.bpad, **f32)
-    ws.loss_sum = torch.empty(plan.loss_ws_doubles, dtype=torch.float64, device=dev)
     pp = ctypes.byref(plan)
     ws.k_rows = _pack_pair(negative_scale, b, plan.bpad, dev, "negative_scale")
     ws.lw = _pack_pair(loss_weight, b, plan.bpad, dev, "loss_weight")
     ws.k_cols = ws.k_rows
 
-    nat.check(lib.crossclr_normalize(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
-                                     _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+    ws.prenormalized = bool(prenormalized)
+    entry = lib.crossclr_pack if prenormalized else lib.crossclr_normalize    # unit rows are only laid out, not re-normalised
+    nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                    _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
     gather = None
     if sharded:
         # all-gather of the packed operands runs on the collective's own stream (RCCL over xGMI)
@@ -173,7 +221,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # generic tiled kernels do the rest (no symmetric evaluation, no pair scheme, no save-for-backward in this regime).
     ws.shift = ws.shift_cols = None
     if lib.crossclr_needs_row_shift(ws.temperature, ws.negative_w):
-        return _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev)
+        return _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev, save_for_backward)
     # Local (symmetric) block.  When a backward will follow and the plan offers it, the forward also saves its bf16
     # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
     # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
@@ -225,10 +273,12 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                                             _ptr(ws.wrz), _ptr(ws.loss_sum), stream))
     if sharded:
         # the backward's remote launch needs every rank's omega/Z: gathered asynchronously, waited for in the backward
-        # (w * omega/Z of the columns is recomputed there: the same fp32 product the finish kernel forms)
-        ws.rz_cols = torch.empty(world * ws.rz.numel(), **f32)
-        ws.stats_work = dist.all_gather_into_tensor(ws.rz_cols, ws.rz, group=group, async_op=True)
-        ws.wrz_cols = None
+        # (w * omega/Z of the columns is recomputed there: the same fp32 product the finish kernel forms).  Only when a
+        # backward will follow: under no_grad nobody would ever wait for the collective or keep its buffer alive.
+        ws.rz_cols, ws.wrz_cols, ws.stats_work = None, None, None
+        if save_for_backward:
+            ws.rz_cols = torch.empty(world * ws.rz.numel(), **f32)
+            ws.stats_work = dist.all_gather_into_tensor(ws.rz_cols, ws.rz, group=group, async_op=True)
         total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
     else:
@@ -238,7 +288,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     return loss, ws
 
 
-def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev):
+def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev, needs_backward):
     """Two-pass forward (include/crossclr.h, "two-pass soft-max"): row maxima, then sums relative to them."""
     import torch.distributed as dist
     plan = ws.plan
@@ -265,10 +315,12 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
                                             _ptr(ws.loss_sum), stream))
     if ws.sharded:
         # the remote backward needs every rank's omega/Z' AND the shifts they are relative to: one gather of both
-        both = torch.cat([ws.rz, ws.shift])
-        gathered = torch.empty(world * both.numel(), **f32)
-        ws.stats_work = dist.all_gather_into_tensor(gathered, both, group=group, async_op=True)
-        ws.rz_cols, ws.wrz_cols, ws.shift_cols = gathered, None, None   # split after the wait, in the backward
+        ws.rz_cols, ws.wrz_cols, ws.shift_cols, ws.stats_work = None, None, None, None
+        if needs_backward:
+            both = torch.cat([ws.rz, ws.shift])
+            gathered = torch.empty(world * both.numel(), **f32)
+            ws.stats_work = dist.all_gather_into_tensor(gathered, both, group=group, async_op=True)
+            ws.rz_cols = gathered   # split after the wait, in the backward
         total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
     else:
@@ -321,9 +373,10 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
     gv = torch.empty(video.shape, dtype=video.dtype, device=dev)
     gt = torch.empty(text.shape, dtype=text.dtype, device=dev)
-    nat.check(lib.crossclr_backward_finish_w(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
+    nat.check(lib.crossclr_backward_finish_p(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
                                              ws.in_dtype, _ptr(ws.inv_norm), ws.temperature, _sw(None, None, ws.lw),
-                                             _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0), stream))
+                                             _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0),
+                                             1 if ws.prenormalized else 0, stream))
     return gv, gt
 
 
@@ -344,12 +397,12 @@ class _device_of:
 
 class _CrossCLRFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, video, text, temperature, negative_w, compute_mode, group, negative_scale, loss_weight):
+    def forward(ctx, video, text, temperature, negative_w, compute_mode, group, negative_scale, loss_weight, prenormalized):
         video_c, text_c = _row_major(video.detach()), _row_major(text.detach())
         needs_grad = any(ctx.needs_input_grad[:2])
         with _device_of(video_c):
             loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight,
-                                     save_for_backward=needs_grad)
+                                     save_for_backward=needs_grad, prenormalized=prenormalized)
         ctx.ws = ws
         ctx.save_for_backward(video_c, text_c)
         return loss
@@ -360,7 +413,7 @@ class _CrossCLRFunction(torch.autograd.Function):
         with _device_of(video_c):
             gv, gt = _backward_impl(ctx.ws, video_c, text_c, grad_out)
         return (gv if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def _validate(video: torch.Tensor, text: torch.Tensor) -> None:
@@ -385,8 +438,12 @@ def _validate(video: torch.Tensor, text: torch.Tensor) -> None:
 
 def crossclr_loss(video_features: torch.Tensor, text_features: torch.Tensor, temperature: float = 0.03,
                   negative_weight: float = 0.8, *, compute_mode: str = "auto", process_group=None,
-                  negative_scale=None, loss_weight=None) -> torch.Tensor:
-    """Functional form of `CrossCLR_onlyIntraModality.forward` (+ the optional per-sample weights, see module doc)."""
+                  negative_scale=None, loss_weight=None, prenormalized: bool = False) -> torch.Tensor:
+    """Functional form of `CrossCLR_onlyIntraModality.forward` (+ the optional per-sample weights, see module doc).
+
+    prenormalized=True: the rows ARE unit vectors already (a projection head with a fused L2-norm, or `F.normalize` upstream):
+    the normalisation pass of loss.py:79-80 is skipped, and the returned gradients are those w.r.t. the unit rows as given, so
+    that the upstream normalise-backward (autograd) applies."""
     _validate(video_features, text_features)
     if not video_features.is_cuda and nat.backend() != "emu-host":
         # the reference hard-codes .cuda() (trainer/loss.py:66,103,104); so does this path
@@ -394,7 +451,47 @@ def crossclr_loss(video_features: torch.Tensor, text_features: torch.Tensor, tem
     if video_features.shape[0] == 0:
         return torch.full((), float("nan"), dtype=torch.float64, device=video_features.device)
     return _CrossCLRFunction.apply(video_features, text_features, float(temperature), float(negative_weight),
-                                   compute_mode, process_group, negative_scale, loss_weight)
+                                   compute_mode, process_group, negative_scale, loss_weight, bool(prenormalized))
+
+
+class _AllGatherWithGrad(torch.autograd.Function):
+    """all_gather whose backward returns to each rank the SUM over ranks of the gradient of its own slice."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        ctx.group = group
+        x = x.contiguous()
+        out = torch.empty((dist.get_world_size(group) * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        import torch.distributed as dist
+        grad = grad.contiguous()
+        world = dist.get_world_size(ctx.group)
+        out = torch.empty((grad.shape[0] // world,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
+        dist.reduce_scatter_tensor(out, grad, op=dist.ReduceOp.SUM, group=ctx.group)
+        return out, None
+
+
+def all_gather_with_grad(x: torch.Tensor, process_group=None) -> torch.Tensor:
+    """[b, ...] on every rank -> [world * b, ...] (rank order), differentiable: the backward reduce-scatters (sums) the
+    gradient of the gathered tensor back to the rank that owns the rows.
+
+    Two ways to train with a global batch under DistributedDataParallel (DDP averages parameter gradients over ranks):
+      * gather + replicate (what open-source CLIP trainers do): `loss = criterion(all_gather_with_grad(v), all_gather_with_grad(t))`
+        -- every rank evaluates the whole B x B problem (world x the work), the summed slice gradient is world x the true one
+        and DDP's averaging restores it: no extra scaling;
+      * sharded (preferred, world x cheaper): `criterion = CrossCLR_onlyIntraModality(..., process_group=group)` on the LOCAL
+        rows -- the returned loss is the global loss, the gradients are exactly d(global loss)/d(local rows); because DDP
+        averages, call `(loss * world).backward()` (or scale the learning rate) to get the gradient of the global loss.
+    """
+    import torch.distributed as dist
+    if process_group is None:
+        process_group = dist.group.WORLD
+    return _AllGatherWithGrad.apply(x, process_group)
 
 
 class CrossCLR_onlyIntraModality(nn.Module):
@@ -404,7 +501,7 @@ class CrossCLR_onlyIntraModality(nn.Module):
     """
 
     def __init__(self, temperature=0.03, negative_weight=0.8, logger=None, *, compute_mode: str = "auto",
-                 process_group=None):
+                 process_group=None, prenormalized: bool = False):
         super().__init__()
         # members the reference registers but never reads in forward (loss.py:52-53); kept so that
         # state_dict()/parameters()/named_children() of an existing checkpoint or optimiser match
@@ -416,6 +513,7 @@ class CrossCLR_onlyIntraModality(nn.Module):
         _resolve_mode(compute_mode, 0)  # validate early
         self.compute_mode = compute_mode
         self.process_group = process_group
+        self.prenormalized = prenormalized
 
     # cheap torch one-liners kept for API completeness (loss.py:59-66)
     def compute_loss(self, logits, mask):
@@ -435,7 +533,7 @@ class CrossCLR_onlyIntraModality(nn.Module):
         """
         # temperature / negative_w are read here, at call time, like the reference (loss.py:90-100)
         return crossclr_loss(video_features, text_features, self.temperature, self.negative_w,
-                             compute_mode=self.compute_mode, process_group=self.process_group)
+                             compute_mode=self.compute_mode, process_group=self.process_group, prenormalized=self.prenormalized)
 
     def extra_repr(self):
         return f"temperature={self.temperature}, negative_weight={self.negative_w}, compute_mode={self.compute_mode!r}"

@@ -201,6 +201,22 @@ int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const v
                             float temperature, float negative_weight, const float* rz, const float* wrz,
                             const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
 
+/* ---- caller-side fusion: embeddings that are already unit vectors (ABI version 3) --------------
+ * When the producer (a projection head with a fused L2-norm epilogue) hands over unit rows, the normalisation of
+ * loss.py:79-80 is not repeated: crossclr_pack only casts / lays the rows out as the packed operand (inv_norm := 1) and forms
+ * the fp32 positive-pair cosine; crossclr_backward_finish_p with prenormalized = 1 returns d(loss)/d(the unit rows as given)
+ * -- no projection, no 1/||x|| -- so that the producer's own normalise-backward (autograd of F.normalize upstream) applies.
+ * A producer that writes X[2][bpad][Dpad] itself in the plan's element type skips crossclr_pack's copy and only needs
+ * diag_cos[i] = vhat_i . that_i.                                                                                       */
+int crossclr_pack(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video, long ld_text,
+                  int in_dtype, void* xhat, float* inv_norm, float* diag_cos, void* stream);
+int crossclr_backward_finish_p(const crossclr_plan* plan, const float* gbuf,
+                               const void* video, const void* text, long ld_video, long ld_text,
+                               int in_dtype, const float* inv_norm, float temperature,
+                               const crossclr_sample_weights* sw,
+                               const double* grad_out, void* grad_video, void* grad_text,
+                               long ld_gvideo, long ld_gtext, int prenormalized, void* stream);
+
 /* ---- two-pass soft-max for small temperatures (ABI version 3) ------------------------------------------------------
  * The reference's soft-max runs in float64 with a per-row maximum (loss.py:60 after the promotion at :96-100), so it is
  * finite for any temperature; the single common shift of the entry points above covers max |logit| =

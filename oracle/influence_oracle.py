@@ -60,6 +60,24 @@ def influence_weights(input_vid: torch.Tensor, input_txt: torch.Tensor, score_th
     return out
 
 
+def influence_weights_streaming(input_vid: torch.Tensor, input_txt: torch.Tensor, score_threshold: float = 0.7,
+                                temperature_weights: float = 0.0035) -> Dict[str, torch.Tensor]:
+    """The same recipe without the B x B matrix (usable at B = 65536):
+    mean_j s[i,j] with the diagonal masked = (xhat_i . sum_j xhat_j - xhat_i . xhat_i) / B.  Checked against
+    `influence_weights` in tests/test_sample_weights_cpu.py."""
+    out = {}
+    for name, x in (("v", input_vid), ("t", input_txt)):
+        xh = F.normalize(x.double(), dim=1)
+        n = xh.shape[0]
+        conn = (xh @ xh.sum(0) - (xh * xh).sum(1)) / n
+        keep = (conn / conn.max() < score_threshold).double()
+        rho = torch.exp((conn / conn.sum()) / temperature_weights)
+        out["conn_" + name] = conn
+        out["keep_" + name] = keep
+        out["omega_" + name] = n * rho / rho.sum()
+    return out
+
+
 # --------------------------------------------------------------------------- #
 # literal dense form (column selection + masked softmax), binary keep only       #
 # --------------------------------------------------------------------------- #
@@ -109,7 +127,8 @@ def dense_weighted_loss_and_grads(video, text, temperature, negative_weight, k_v
 # closed form, streaming float64 (nothing O(B^2) resident; row_range for the sharded semantics)      #
 # --------------------------------------------------------------------------- #
 def streaming_weighted_loss_and_grads(video, text, temperature, negative_weight, k_v, k_t, omega_v, omega_t,
-                                      block: int = 1024, row_range: Optional[Tuple[int, int]] = None
+                                      block: int = 1024, row_range: Optional[Tuple[int, int]] = None,
+                                      logz_all: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
                                       ) -> Dict[str, torch.Tensor]:
     """W for the gradient:  inter  E (ov_i/Zv_i + ot_j/Zt_j);  intra  w E (o_i k_j / Z_i + o_j k_i / Z_j), diag 0;
     positive-pair term  -(ov_i + ot_i)/(2 B tau) * partner."""
@@ -122,7 +141,9 @@ def streaming_weighted_loss_and_grads(video, text, temperature, negative_weight,
     lzv = torch.empty(B, dtype=torch.float64)
     lzt = torch.empty(B, dtype=torch.float64)
     neg_inf = float("-inf")
-    for r0 in range(0, B, block):
+    if logz_all is not None:      # (the full-batch denominators of an earlier call: the O(B^2 D) part)
+        lzv, lzt = logz_all[0].double().clone(), logz_all[1].double().clone()
+    for r0 in range(0, B if logz_all is None else 0, block):
         r1 = min(B, r0 + block)
         idx, rows = torch.arange(r0, r1), torch.arange(r1 - r0)
         for own, other, k, out in ((vhat, that, kv, lzv), (that, vhat, kt, lzt)):
@@ -157,6 +178,6 @@ def streaming_weighted_loss_and_grads(video, text, temperature, negative_weight,
         tiny = (x.double().norm(dim=1) < base.NORM_EPS)[:, None]
         return torch.where(tiny, g, proj) / nrm[:, None]
 
-    return {"loss": loss, "logZv": lzv[lo:hi], "logZt": lzt[lo:hi],
+    return {"loss": loss, "logZv": lzv[lo:hi], "logZt": lzt[lo:hi], "logZv_all": lzv, "logZt_all": lzt,
             "grad_v": through_normalize(gv, vhat[lo:hi], video[lo:hi], vnorm[lo:hi]),
             "grad_t": through_normalize(gt, that[lo:hi], text[lo:hi], tnorm[lo:hi])}

@@ -82,3 +82,94 @@ def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
         assert ev <= gtol and et <= gtol, (rank, ev, et)
         losses.append(loss)
     assert max(losses) - min(losses) <= 1e-12, "every rank must see the same global loss"
+
+
+def _gather_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import crossclr_amd
+        from crossclr_amd import _native as nat
+        from emu import build_emu
+        from oracle import crossclr_oracle as orc
+        nat.use_library_for_testing(build_emu.OUT)
+        B, D = 24, 20
+        v, t = orc.make_inputs("randn", B, D, 55)
+        b = B // world
+        vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        tl = t[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        # gather + replicate: every rank evaluates the whole problem on the gathered (differentiable) batch
+        loss = crossclr_amd.crossclr_loss(crossclr_amd.all_gather_with_grad(vl), crossclr_amd.all_gather_with_grad(tl), 0.05, 0.7,
+                                          compute_mode="fp32")
+        loss.backward()
+        ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.7)
+        scale = ref["grad_v"].abs().max().item()
+        # the reduce-scatter SUMS the world identical copies: world x the true slice gradient (DDP's averaging undoes it)
+        ev = (vl.grad.double() / world - ref["grad_v"][rank * b:(rank + 1) * b]).abs().max().item() / scale
+        et = (tl.grad.double() / world - ref["grad_t"][rank * b:(rank + 1) * b]).abs().max().item() / scale
+        q.put((rank, float(loss), float(ref["loss"]), ev, et))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), 0, 0))
+
+
+def test_all_gather_with_grad_over_gloo():
+    from emu import build_emu
+    build_emu.build()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 17
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, loss, ref, ev, et in sorted(results):
+        assert loss != "error", ref
+        assert abs(loss - ref) <= 1e-5 * max(1.0, abs(ref))
+        assert ev <= 2e-4 and et <= 2e-4, (rank, ev, et)
+
+
+def _mismatch_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import crossclr_amd
+        from crossclr_amd import _native as nat
+        from emu import build_emu
+        nat.use_library_for_testing(build_emu.OUT)
+        rows = 8 + 4 * rank      # a different row count on every rank
+        try:
+            crossclr_amd.crossclr_loss(torch.randn(rows, 16), torch.randn(rows, 16), compute_mode="fp32", process_group=dist.group.WORLD)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "crash: " + traceback.format_exc()))
+
+
+def test_mismatched_rows_per_rank_raise_a_clear_error():
+    from emu import build_emu
+    build_emu.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 23
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert "same number of rows" in msg, msg

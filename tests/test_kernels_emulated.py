@@ -205,3 +205,22 @@ def test_plan_geometry():
         nat.make_plan(0, 16, 1, 0, nat.MODE_FP32)
     with pytest.raises(nat.CrossCLRNativeError):
         nat.make_plan(8, 16, 2, 2, nat.MODE_FP32)
+
+
+def test_prenormalized_inputs_skip_the_normalisation_and_chain_through_autograd():
+    """a producer that already emits unit rows calls the loss with prenormalized=True; F.normalize
+    upstream (autograd) then supplies the normalise-backward, and values and gradients equal the plain path's."""
+    v, t = orc.make_inputs("randn", 24, 40, 9)
+    for mode, tol in (("fp32", 2e-6), ("bf16", 2e-6)):
+        l0, gv0, gt0 = run(v, t, 0.05, 0.8, mode)
+        vv = v.clone().requires_grad_(True)
+        tt = t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(torch.nn.functional.normalize(vv, dim=1), torch.nn.functional.normalize(tt, dim=1),
+                                          0.05, 0.8, compute_mode=mode, prenormalized=True)
+        loss.backward()
+        assert abs(loss.item() - l0.item()) <= tol * max(1.0, abs(l0.item()))
+        scale = gv0.abs().max().item()
+        assert (vv.grad - gv0).abs().max().item() <= 2e-5 * scale and (tt.grad - gt0).abs().max().item() <= 2e-5 * scale
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.8, compute_mode="fp32", prenormalized=True)
+    assert abs(crit(torch.nn.functional.normalize(v, dim=1), torch.nn.functional.normalize(t, dim=1)).item() -
+               float(orc.streaming_stats(v, t, 0.05, 0.8)["loss"])) <= 1e-5

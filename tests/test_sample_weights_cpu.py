@@ -221,3 +221,16 @@ def test_sharded_weighted_loss_over_gloo(mode, world, B, ltol, gtol):
         assert ev <= gtol and et <= gtol, (rank, ev, et)
         losses.append(loss)
     assert max(losses) - min(losses) <= 1e-12
+
+
+def test_streaming_influence_recipe_equals_the_dense_one():
+    # the O(B D) form used for the B = 65536 goldens (tests/golden/make_g8.py) against the literal B x B statement
+    g = torch.Generator().manual_seed(5)
+    c = torch.randn(6, 24, generator=g)
+    lab = torch.randint(0, 6, (90,), generator=g)
+    xv = c[lab] + 0.2 * torch.randn(90, 24, generator=g)
+    xt = c[lab] + 0.2 * torch.randn(90, 24, generator=g)
+    a = inf.influence_weights(xv, xt, 0.9, 0.0035)
+    s = inf.influence_weights_streaming(xv, xt, 0.9, 0.0035)
+    for k in a:
+        assert torch.allclose(a[k], s[k], rtol=1e-10, atol=1e-12), k
