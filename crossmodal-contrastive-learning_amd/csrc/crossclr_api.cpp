@@ -494,7 +494,7 @@ extern "C" int crossclr_forward_finish_s(const crossclr_plan* plan, const float*
            negative_weight, logz, rz, wrz, loss_sum, part + ws_colpart_off(plan),
            reinterpret_cast<const int*>(part + ws_flag_off(plan)), sw ? sw->neg_scale_rows : nullptr,
            sw ? sw->loss_weight : nullptr, shift_rows);
-    LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb);
+    LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb, 1.0 / (2.0 * (double)plan->b * (double)plan->world));
     return launch_status("fwd_finish_kernel");
 }
 

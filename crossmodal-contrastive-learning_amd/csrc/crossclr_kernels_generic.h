@@ -381,11 +381,13 @@ __global__ void __launch_bounds__(256) fwd_add_kernel(const float* vec, int n, f
     if (i == 0) { header[0] = 0; header[1] = vec ? 1 : -1; header[2] = 0; header[3] = 0; }
     if (vec && i < n) slot[i] = vec[i];
 }
-__global__ void __launch_bounds__(64) fwd_finish_reduce_kernel(double* loss_ws, int nblocks) {
+// loss_ws[0] = the sum; the block partials are dead after this read, so loss_ws[1] receives sum * scale: the rank's
+// contribution to the mean loss, ready to be returned without another kernel (scale = 1 / (2 B_global))
+__global__ void __launch_bounds__(64) fwd_finish_reduce_kernel(double* loss_ws, int nblocks, double scale) {
     double acc = 0.0;
     for (int k = threadIdx.x; k < nblocks; k += 64) acc += loss_ws[1 + k];
-    acc = wave_sum_f64(acc);
-    if (threadIdx.x == 0) loss_ws[0] = acc;
+    acc = wave_sum_f64(acc);   // (every lane has read its partials before lane 0 overwrites loss_ws[1])
+    if (threadIdx.x == 0) { loss_ws[0] = acc; if (nblocks >= 1) loss_ws[1] = acc * scale; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -46,13 +46,14 @@ AUTO_BF16_MIN_GLOBAL_BATCH = 1024
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+    """Device address as a plain int (ctypes converts it to void* itself; building a c_void_p per argument cost ~10 us per step)."""
+    return 0 if t is None else t.data_ptr()
 
 
 def _stream_for(t: torch.Tensor):
     if t.is_cuda:
-        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    return ctypes.c_void_p(0)
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
 
 
 def _row_major(t: torch.Tensor) -> torch.Tensor:
@@ -181,14 +182,15 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # one allocation for everything the step keeps (a dozen torch.empty calls were a third of the host time at small batches):
     # [xhat | loss_sum (doubles) | inv_norm | diag | logz | rz | wrz | part], every piece 256-byte aligned
     n2 = 2 * plan.bpad
-    sizes = [plan.operand_bytes, 8 * plan.loss_ws_doubles, 4 * n2, 4 * plan.bpad, 4 * n2, 4 * n2, 4 * n2, 4 * plan.fwd_ws_floats]
+    sizes = [plan.operand_bytes, 0, 4 * n2, 4 * plan.bpad, 4 * n2, 4 * n2, 4 * n2, 4 * plan.fwd_ws_floats]
     offs, tot = [], 0
     for sz in sizes:
         offs.append(tot)
         tot += (sz + 255) // 256 * 256
     slab = torch.empty(tot, dtype=torch.uint8, device=dev)
     ws.xhat = slab[offs[0]:offs[0] + sizes[0]]
-    ws.loss_sum = _carve(slab, offs[1], sizes[1], torch.float64)
+    # (the loss the caller gets back is a 0-dim view of this buffer: its own small allocation, so it never pins the slab)
+    ws.loss_sum = torch.empty(max(2, plan.loss_ws_doubles), dtype=torch.float64, device=dev)
     ws.inv_norm = _carve(slab, offs[2], sizes[2], torch.float32)
     ws.diag = _carve(slab, offs[3], sizes[3], torch.float32)
     ws.logz = _carve(slab, offs[4], sizes[4], torch.float32)
@@ -281,10 +283,10 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
             ws.stats_work = dist.all_gather_into_tensor(ws.rz_cols, ws.rz, group=group, async_op=True)
         total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
+        loss = (total / (2.0 * b * world)).reshape(())
     else:
         ws.rz_cols, ws.wrz_cols, ws.stats_work = ws.rz, ws.wrz, None
-        total = ws.loss_sum[:1]
-    loss = (total / (2.0 * b * world)).reshape(())
+        loss = ws.loss_sum[1]      # = sum / (2 B), written by the finish kernel (a 0-dim view of the 8-byte-per-block loss buffer)
     return loss, ws
 
 
@@ -323,10 +325,10 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
             ws.rz_cols = gathered   # split after the wait, in the backward
         total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
+        loss = (total / (2.0 * b * world)).reshape(())
     else:
         ws.rz_cols, ws.wrz_cols, ws.shift_cols, ws.stats_work = ws.rz, ws.wrz, ws.shift, None
-        total = ws.loss_sum[:1]
-    loss = (total / (2.0 * b * world)).reshape(())
+        loss = ws.loss_sum[1]
     return loss, ws
 
 
@@ -370,7 +372,10 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                           ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols),
                                           _ptr(ws.wrz_cols), _sw(ws.k_rows, ws.k_cols, None), _ptr(gbuf), 1, stream))
-    go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
+    if grad_out.dtype == torch.float64 and grad_out.device == dev and grad_out.numel() == 1:
+        go = grad_out.detach().reshape(1)
+    else:
+        go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
     gv = torch.empty(video.shape, dtype=video.dtype, device=dev)
     gt = torch.empty(text.shape, dtype=text.dtype, device=dev)
     nat.check(lib.crossclr_backward_finish_p(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
@@ -384,7 +389,8 @@ class _device_of:
     """The C-ABI launches on the stream it is given; HIP requires that stream's device to be current (the inputs may
     live on another GPU than the process's current one, and the backward runs on an autograd engine thread)."""
     def __init__(self, t: torch.Tensor):
-        self._guard = torch.cuda.device(t.device) if t.is_cuda else None
+        # (switching devices costs ~5 us per enter/exit: only when the tensor's device is not already current)
+        self._guard = torch.cuda.device(t.device) if t.is_cuda and torch.cuda.current_device() != t.device.index else None
 
     def __enter__(self):
         if self._guard is not None:

@@ -108,7 +108,8 @@ int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const voi
 /* Reduce `nslots` (= fwd_slots times the number of launch groups used, 1..4) partial slots: logz[2][bpad] (natural log of the full denominator),
  * rz = 1/Z_shifted, wrz = negative_weight * rz (both 0 on padding rows) and
  * loss_sum[0] = sum over valid rows of (logZv + logZt - 2 A_ii)  (double); loss_sum must hold
- * plan->loss_ws_doubles doubles ([1..] are per-block partials, added in index order).          */
+ * plan->loss_ws_doubles doubles ([1..] are per-block partials, added in index order; afterwards
+ * loss_sum[1] = loss_sum[0] / (2 * b * world): this rank's share of the mean loss of loss.py:114).  */
 int crossclr_forward_finish(const crossclr_plan* plan, const float* part, int nslots,
                             const float* diag_cos, float temperature, float negative_weight,
                             float* logz, float* rz, float* wrz, double* loss_sum, void* stream);
