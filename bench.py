@@ -279,7 +279,7 @@ def main():
             kernels[k].update(algorithmic_tflops=round(tf, 2), frac=round(tf / peak, 4))
     saved = bool(st.get("saved_path"))
     if args.fwd_only:
-        dom, dom_kernel = "forward", ("fast_fwd_sym_kernel" if st["fast_path"] else "fwd_sums_kernel")
+        dom, dom_kernel = "forward", ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel")
     else:
         dom = "backward_saved" if saved else "backward"
         dom_kernel = "fast_bwd_saved_kernel" if saved else ("fast_bwd" if st["fast_path"] else "bwd_kernel")

@@ -77,6 +77,14 @@ _SIGNATURES = {
                                              ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P]),
     "crossclr_backward_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
                                                ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    # ABI version 3: rectangular blocks with saved exponentials
+    "crossclr_rect_stash_bytes": (ctypes.c_size_t, [ctypes.POINTER(Plan), ctypes.c_int]),
+    "crossclr_forward_rect_save": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                  ctypes.c_float, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P, _P]),
+    "crossclr_backward_rect_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                    ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    "crossclr_backward_ranks": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     # ABI version 3: unit-vector inputs (caller-side fusion)
     "crossclr_pack": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, _P, _P, _P, _P]),
     "crossclr_backward_finish_p": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long,

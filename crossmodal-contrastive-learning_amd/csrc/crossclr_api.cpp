@@ -405,7 +405,7 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
     if (rc) return rc;
-    rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, gbuf, accumulate, krows, stream);
+    rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, false, stream);
     return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_saved_kernel");
 #endif
 }
@@ -628,6 +628,104 @@ extern "C" int crossclr_backward_s(const crossclr_plan* plan, const void* xhat_r
     return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_cols, rz_rows, wrz_rows, rz_cols, wrz_cols, gbuf, accumulate, krows, kcols, shift_rows, shift_cols, stream);
 }
 
+
+// ---- rectangular blocks of the sharded step with saved exponentials ------------------------------------------------------
+// `first_rank`, `nranks`: column ranks first_rank .. first_rank+nranks-1 (mod plan->world) of the WHOLE gathered operand.
+static int rect_geo(const crossclr_plan* plan, int first_rank, int nranks, float temperature, float negative_weight, Geo* g) {
+    if (first_rank < 0 || first_rank >= plan->world || nranks < 1 || nranks >= plan->world)
+        return fail(CROSSCLR_E_ARG, "bad first_rank/nranks %d/%d for world %d", first_rank, nranks, plan->world);
+    for (int i = 0; i < nranks; ++i)
+        if ((first_rank + i) % plan->world == plan->rank) return fail(CROSSCLR_E_ARG, "the rank range must not contain this rank");
+    int rc = make_geo(plan, nranks, first_rank, -1, temperature, negative_weight, g);
+    if (rc) return rc;
+    g->col_wrap = plan->world;
+    return CROSSCLR_OK;
+}
+
+extern "C" size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nranks) {
+#ifdef CROSSCLR_NO_FAST
+    return 0;
+#else
+    if (!plan || !plan->stash_bytes || nranks < 1) return 0;
+    return fast_stash_bytes_rect(plan->bpad, plan->Dpad, nranks);
+#endif
+}
+
+extern "C" int crossclr_forward_rect_save(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank,
+                                          int nranks, int with_colsums, float temperature, float negative_weight,
+                                          const crossclr_sample_weights* sw, float* part, int slot0, float* colsum_out,
+                                          void* stash, void* stream) {
+    if (!plan || !xhat_rows || !xhat_all || !part || !stash || (with_colsums && !colsum_out)) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_forward_rect_save needs the register-resident path");
+#else
+    if (!plan->stash_bytes) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path (stash_bytes == 0)");
+    if (with_colsums && nranks > (plan->world - 1) / 2) return fail(CROSSCLR_E_ARG, "a pair range holds at most (world-1)/2 ranks");
+    if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);
+    if (rc) return rc;
+    float* out = part + (size_t)slot0 * 2 * plan->bpad;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    float* colpart = part + ws_paircol_off(plan);
+    const FwdWork wk = fast_forward_work(plan, nranks, -1, false, with_colsums != 0);
+    rc = fast_forward_pipe(plan, g, wk, xhat_rows, xhat_all, out, colpart, header, with_colsums ? 3 : 2, krows, kcols, stash, stream);
+    if (rc) return fail(rc, "fast_forward_pipe: unsupported Dpad %d", plan->Dpad);
+    if (with_colsums) {
+        const int nrb = 2 * plan->bpad / (32 * fast_fwd_tpr(plan->Dpad));
+        const int ncols = nranks * 2 * plan->bpad;
+        LAUNCH(colsum_reduce_kernel, dim3((ncols + 255) / 256), dim3(256), stream, (const float*)colpart, nrb, ncols, colsum_out);
+    }
+    return launch_status("fast_fwd_pipe_kernel (rect, save)");
+#endif
+}
+
+extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const void* xhat_all, const void* stash, int first_rank,
+                                            int nranks, float temperature, float negative_weight, const float* rz_rows,
+                                            const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                            const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat_all || !stash || !rz_rows || !wrz_rows || !rz_all || !wrz_all || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved needs the register-resident path");
+#else
+    if (!plan->stash_bytes) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path (stash_bytes == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);
+    if (rc) return rc;
+    rc = fast_backward_saved(plan, g, xhat_all, stash, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, true, stream);
+    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_saved_kernel (rect)");
+#endif
+}
+
+// the recomputing backward over a (wrapping) rank range of the whole gathered operand: the blocks OTHER ranks evaluated in the
+// pair scheme, whose exponentials this rank therefore does not hold
+extern "C" int crossclr_backward_ranks(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank,
+                                       int nranks, float temperature, float negative_weight, const float* rz_rows,
+                                       const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                       const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat_rows || !xhat_all || !rz_rows || !wrz_rows || !rz_all || !wrz_all || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);
+    if (rc) return rc;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->fast_bwd) {
+        rc = plan->fast_bwd == 2
+                 ? fast_backward16(plan, g, xhat_rows, xhat_all, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, stream)
+                 : fast_backward(plan, g, xhat_rows, xhat_all, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, stream);
+        return rc ? fail(rc, "fast backward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_kernel (ranks)");
+    }
+#endif
+    if (plan->mode == CROSSCLR_MODE_FP32)
+        return backward_generic<float>(plan, g, xhat_rows, xhat_all, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, nullptr, nullptr, stream);
+    return backward_generic<bf16_t>(plan, g, xhat_rows, xhat_all, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, nullptr, nullptr, stream);
+}
 
 template <typename TIN>
 static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const void* v, const void* t, long ldv, long ldt,

@@ -843,10 +843,17 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 // HBM per launch: the stash is read once directly and once transposed (2 x 0.27 GB at B = 8192) -- O(B^2) bytes, which is
 // the price of not recomputing; the kernel stays MFMA-bound.
 // ---------------------------------------------------------------------------------------------
-template <int DK, bool SW>
+// RECT: the same kernel for a rectangular block of the sharded step (this rank's rows x other ranks' columns: the blocks
+// this rank evaluated itself in the forward -- its pair partners and the antipodal rank): the stash is rectangular
+// (tile (r32, item j) at (r32 * NT + j) * 2 KiB, always "direct"), the columns are the usable tiles of the column operand
+// (one rank skipped, or ranks col_rank0.. modulo col_wrap of the whole gathered operand), their statistics come from the
+// gathered arrays; everything else is shared.
+template <int DK, bool SW, bool RECT>
 __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
-                                                                const float* rz, const float* wrz, float* gbuf,
-                                                                int accumulate, int tiles_per_slice, const float* ks) {
+                                                                const float* rz, const float* wrz,
+                                                                const float* rz_cols, const float* wrz_cols, float* gbuf,
+                                                                int accumulate, int tiles_per_slice, const float* ks,
+                                                                const float* kc) {
     constexpr int RB = DK * 32;
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
@@ -876,8 +883,11 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     const int half = lane >> 5, l31 = lane & 31;
     const int row0w = blockIdx.x * 128 + 32 * wave;
     const int r32 = uniform(row0w >> 5);
-    const int NT = 2 * g.bpad / QT;              // column tiles; the first NT/2 are modality 0
-    const int rmod = (2 * r32 >= NT) ? 1 : 0;
+    const int per_rank = 2 * g.bpad / QT, per_mod = g.bpad / QT;
+    const int skip_seg = (RECT && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
+    // column tiles of this launch: the operand's own (the first NT/2 are modality 0), or the usable tiles of the rank range
+    const int NT = RECT ? (g.col_ranks - (skip_seg >= 0 ? 1 : 0)) * per_rank : per_rank;
+    const int rmod = (2 * r32 >= per_rank) ? 1 : 0;
     const int rb0 = (r32 / TPR) * TPR;           // first tile the forward evaluated for this wave's rows
     unsigned char* ebuf = lds + E0 + wave * 2048;      // + estage * ESTG
     unsigned char* sbuf = lds + S0 + wave * 256;       // + estage * SSTG: omega/Z (or w omega/Z) of the tile's columns
@@ -897,7 +907,8 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
             comb[k][u] = (4 * half + jrow) * RB + 64 * (k ^ jrow) + 16 * ((2 * dsub + (piece >> 1)) ^ (2 * u + half)) +
                          8 * (piece & 1);
     // column-tile DMA: piece k of this wave fills LDS bytes [(wave + 4k) KiB, +1 KiB) of the stage; lane -> (row, swizzled slot)
-    const BufRsrc rs_x = make_rsrc(cols, (unsigned)((size_t)2 * g.bpad * RB));
+    const int col_segs = !RECT ? 1 : (g.col_wrap > 0 ? g.col_wrap : g.col_ranks);   // rank segments the column operand holds
+    const BufRsrc rs_x = make_rsrc(cols, (unsigned)((size_t)col_segs * 2 * g.bpad * RB));
     unsigned voffx[NXO];
 #pragma unroll
     for (int k = 0; k < NXO; ++k) {
@@ -914,8 +925,9 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     // transposed read: lane (half, g1 = grp&1, jj = jrow, c = piece) addresses row rho = 16th + 8u + 4half + jj, chunk
     // (hf = c&1, th_s = g1), 8-byte half c>>1  ->  th*1024 + u*512 + [half*256 + (jj + 4(c&1) + 8 g1)*16 + 8(c>>1)]
     const int etr = half * 256 + (jrow + 4 * (piece & 1) + 8 * dsub) * 16 + 8 * (piece >> 1);
-    const BufRsrc rs_rz = make_rsrc(rz, (unsigned)(2 * g.bpad * 4)), rs_wrz = make_rsrc(wrz, (unsigned)(2 * g.bpad * 4));
-    const BufRsrc rs_k = make_rsrc(SW ? ks : rz, (unsigned)(2 * g.bpad * 4));
+    const unsigned stat_bytes = (unsigned)((size_t)col_segs * 2 * g.bpad * 4);
+    const BufRsrc rs_rz = make_rsrc(rz_cols, stat_bytes), rs_wrz = make_rsrc(wrz_cols, stat_bytes);
+    const BufRsrc rs_k = make_rsrc(SW ? kc : rz_cols, stat_bytes);
 
     f32x16 acc2[DT];
 #pragma unroll
@@ -927,25 +939,53 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     int t_end = t + tiles_per_slice;
     if (t_end > NT) t_end = NT;
     auto clampt = [&](int u) { return u < t_end ? u : t_end - 1; };   // past the end: re-fetch the last tile (fixed VMEM count)
-    auto issue_x_piece = [&](int u, int stage, int k) {
-        if (CROSSCLR_SABL & 2) return;
-        lds_dma16_buf(rs_x, voffx[k], (unsigned)clampt(u) * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
+    // Column cursors (RECT): item u -> tile index inside the column operand (mt) and its modality; the three streams that walk
+    // the items (weights of t+1, column-tile DMA of t+NSX-1, E / statistics DMA of t+NSE-1) advance one item per iteration, so
+    // the mapping is tracked incrementally (one division per block, none per tile).  !RECT: mt = u, modality = (2u >= NT).
+    struct Col { int u, mt, seg, in_seg; };
+    auto col_seg_start = [&](Col& c) {
+        c.in_seg = 0;
+        int r = c.seg;
+        if (g.col_wrap > 0) { r += g.col_rank0; if (r >= g.col_wrap) r -= g.col_wrap; }
+        c.mt = r * per_rank;
     };
-    auto issue_e = [&](int u, int estage) {      // 2 pieces of the saved exponentials + the tile's statistics
+    auto col_at = [&](int u) {
+        Col c;
+        c.u = u = clampt(u);
+        if (!RECT) { c.mt = u; c.seg = 0; c.in_seg = u; return c; }
+        const int su = u / per_rank;
+        c.seg = su + ((skip_seg >= 0 && su >= skip_seg) ? 1 : 0);
+        col_seg_start(c);
+        c.in_seg = u - su * per_rank;
+        c.mt += c.in_seg;
+        return c;
+    };
+    auto col_next = [&](Col& c) {
+        if (c.u + 1 >= t_end) return;                   // stay on the last tile
+        ++c.u; ++c.mt; ++c.in_seg;
+        if (RECT && c.in_seg == per_rank) { ++c.seg; if (c.seg == skip_seg) ++c.seg; col_seg_start(c); }
+    };
+    auto col_mod = [&](const Col& c) { return c.in_seg >= per_mod ? 1 : 0; };
+    auto issue_x_piece = [&](const Col& c, int stage, int k) {
+        if (CROSSCLR_SABL & 2) return;
+        lds_dma16_buf(rs_x, voffx[k], (unsigned)c.mt * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
+    };
+    auto issue_e = [&](const Col& c, int estage) {      // 2 pieces of the saved exponentials + the tile's statistics
         if (CROSSCLR_SABL & 1) return;
-        u = clampt(u);
-        const bool direct = u >= rb0;
+        const int u = c.u;
+        const bool direct = RECT || u >= rb0;
         // stash_tile_index in 32-bit scalar arithmetic (the host refuses plans whose stash has 2^31 tiles or more)
         const unsigned a32 = direct ? (unsigned)r32 : (unsigned)u, b32 = direct ? (unsigned)u : (unsigned)r32;
         const unsigned rbp = a32 / TPR, wp = a32 % TPR;
-        const unsigned idx = TPR * rbp * ((unsigned)NT - (TPR / 2) * rbp + (TPR / 2)) + wp * ((unsigned)NT - TPR * rbp) + (b32 - TPR * rbp);
+        const unsigned idx = RECT ? (unsigned)r32 * (unsigned)NT + (unsigned)u
+                                  : TPR * rbp * ((unsigned)NT - (TPR / 2) * rbp + (TPR / 2)) + wp * ((unsigned)NT - TPR * rbp) + (b32 - TPR * rbp);
         const BufRsrc rs_e = make_rsrc(stash + (size_t)((CROSSCLR_SABL & 64) ? (idx & 1023) : idx) * 2048, 2048u);   // bit6: E from a 2-MiB window (L2)
         const unsigned o0 = direct ? eoff_d0 : eoff_t0;      // second half (LDS chunks 64..127): +1 KiB direct, +16 rows transposed
         lds_dma16_buf(rs_e, o0, 0u, ebuf + estage * ESTG);
         lds_dma16_buf(rs_e, o0 + (direct ? 1024u : 256u), 0u, ebuf + estage * ESTG + 1024);
-        const bool same = ((2 * u >= NT) ? 1 : 0) == rmod;
-        lds_dma4_buf(same ? rs_wrz : rs_rz, (unsigned)(lane * 4), (unsigned)(u * QT * 4), sbuf + estage * SSTG);
-        if (SW) lds_dma4_buf(rs_k, (unsigned)(lane * 4), (unsigned)(u * QT * 4), kbuf + estage * SSTG);
+        const bool same = col_mod(c) == rmod;
+        lds_dma4_buf(same ? rs_wrz : rs_rz, (unsigned)(lane * 4), (unsigned)(c.mt * QT * 4), sbuf + estage * SSTG);
+        if (SW) lds_dma4_buf(rs_k, (unsigned)(lane * 4), (unsigned)(c.mt * QT * 4), kbuf + estage * SSTG);
     };
     struct Pair { s16x4 lo, hi; };
     struct Bits8 { bf16_t e[8]; };
@@ -983,10 +1023,10 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     };
     // W = E (omega_p/Z_p + omega_q/Z_q) for four columns (k-step th, register quad r4), packed to bf16 in place
     // YOUNGER = LDS operations certainly issued after the staged reads (>= that many): the wait is then a no-op in practice
-    auto weigh4 = [&](int u, Staged& st, Bits8 (&pk)[2], int th, int r4, auto younger) {
+    auto weigh4 = [&](const Col& c, Staged& st, Bits8 (&pk)[2], int th, int r4, auto younger) {
         constexpr int YOUNGER = decltype(younger)::value;
-        const bool direct = clampt(u) >= rb0;
-        const bool same_mod = ((2 * clampt(u) >= NT) ? 1 : 0) == rmod;
+        const bool direct = RECT || c.u >= rb0;
+        const bool same_mod = col_mod(c) == rmod;
         const bool weighted = SW && same_mod;
         const float rzp = same_mod ? rzp_intra : rzp_inter;
         wait_lgkm<YOUNGER>(st.e[th], st.rq[2 * th + r4]);
@@ -1007,19 +1047,26 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     };
 
     bf16x8 af[2];      // A fragments of the tile being multiplied
+    Col cw, cx, ce;    // the next tile to weigh (t+1), to fetch (t+NSX-1), to fetch saved exponentials for (t+NSE-1)
     if (t < t_end) {
+        ce = col_at(t);
 #pragma unroll
-        for (int k = 0; k < NSE - 1; ++k) issue_e(t + k, k);
+        for (int k = 0; k < NSE - 1; ++k) { issue_e(ce, k); col_next(ce); }
+        cx = col_at(t);
 #pragma unroll
-        for (int k = 0; k < NSX - 1; ++k)
+        for (int k = 0; k < NSX - 1; ++k) {
 #pragma unroll
-            for (int j = 0; j < NXO; ++j) issue_x_piece(t + k, k, j);
+            for (int j = 0; j < NXO; ++j) issue_x_piece(cx, k, j);
+            col_next(cx);
+        }
         if (!(CROSSCLR_SABL & 3)) wait_dma_keep<(NSX - 1) * NXO>();     // the E / statistics pieces precede the column tiles
         Bits8 pk[2];
         Staged st;
         read_staged(0, st);
+        cw = col_at(t);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) weigh4(t, st, pk, q >> 1, q & 1, IdxC<0>{});
+        for (int q = 0; q < 4; ++q) weigh4(cw, st, pk, q >> 1, q & 1, IdxC<0>{});
+        col_next(cw);
         af[0] = __builtin_bit_cast(bf16x8, pk[0]);
         af[1] = __builtin_bit_cast(bf16x8, pk[1]);
     }
@@ -1066,20 +1113,21 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
             acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]), acc2[dt]);
 #endif
             if constexpr (i + PF < NI) fetch(IdxC<i + PF>{});
-            if constexpr (i < NXO) issue_x_piece(t + NSX - 1, sx_free, i);
-            if constexpr (i == C_E) issue_e(t + NSE - 1, se_free);
+            if constexpr (i < NXO) issue_x_piece(cx, sx_free, i);
+            if constexpr (i == C_E) issue_e(ce, se_free);
             if constexpr (i == C_RD) read_staged(se_next, st);
             if constexpr (i >= C_W0 && (i - C_W0) % WSTEP == 0) {
                 constexpr int q = (i - C_W0) / WSTEP;                      // quad (th = q >> 1, r4 = q & 1)
                 constexpr int last_fetch = NI - PF - 1;                    // last slot that issues transpose reads
                 constexpr int n_after = (i < last_fetch ? i : last_fetch) - C_RD;   // slots C_RD+1 .. i that issued a pair
                 constexpr int younger = n_after <= 0 ? 0 : (2 * n_after < 2 * PF ? 2 * n_after : 2 * PF);
-                weigh4(t + 1, st, pk, q >> 1, q & 1, IdxC<younger>{});
+                weigh4(cw, st, pk, q >> 1, q & 1, IdxC<younger>{});
             }
             sched_fence();
         });
         af[0] = __builtin_bit_cast(bf16x8, pk[0]);
         af[1] = __builtin_bit_cast(bf16x8, pk[1]);
+        col_next(cw); col_next(cx); col_next(ce);
         sx = sx + 1 == NSX ? 0 : sx + 1;
         se = se_next;
     }
@@ -1332,6 +1380,44 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
     return fwd_make_work(symmetric ? 1 : (pairs ? 3 : 2), p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
 }
 
+// the software-pipelined forward (Dpad <= 512), all three kinds, with or without saving the exponentials
+static inline int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols,
+                                    float* part, float* colpart, int* header, int kind, const float* krows, const float* kcols,
+                                    void* stash, void* stream) {
+    if (wk.total <= 0) return CROSSCLR_OK;
+    const bf16_t* r = (const bf16_t*)rows;
+    const bf16_t* c = (const bf16_t*)cols;
+    unsigned char* st = (unsigned char*)stash;
+    dim3 grid(wk.nblk), block(256);
+    const bool sw = krows != nullptr && kcols != nullptr;
+#define CROSSCLR_LP3(DK, KIND, SW, ST) \
+    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st)
+#define CROSSCLR_LP2(DK, KIND)                                   \
+    do {                                                          \
+        if (sw && st) CROSSCLR_LP3(DK, KIND, true, true);         \
+        else if (sw) CROSSCLR_LP3(DK, KIND, true, false);         \
+        else if (st) CROSSCLR_LP3(DK, KIND, false, true);         \
+        else CROSSCLR_LP3(DK, KIND, false, false);                \
+    } while (0)
+#define CROSSCLR_LP(DK)                                 \
+    do {                                                 \
+        if (kind == 1) CROSSCLR_LP2(DK, 1);              \
+        else if (kind == 2) CROSSCLR_LP2(DK, 2);         \
+        else CROSSCLR_LP2(DK, 3);                        \
+    } while (0)
+    switch (p->Dpad) {
+        case 128: CROSSCLR_LP(8); break;
+        case 256: CROSSCLR_LP(16); break;
+        case 384: CROSSCLR_LP(24); break;
+        case 512: CROSSCLR_LP(32); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LP
+#undef CROSSCLR_LP2
+#undef CROSSCLR_LP3
+    return CROSSCLR_OK;
+}
+
 static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
                                float* colpart, int* header, bool symmetric, const float* krows, const float* kcols,
                                void* stream, bool pairs = false) {
@@ -1342,23 +1428,9 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     const bf16_t* c = (const bf16_t*)cols;
     dim3 grid(wk.nblk);
     const bool sw = krows != nullptr && kcols != nullptr;
-    static const bool old_sym = getenv("CROSSCLR_FWD_KERNEL") && !strcmp(getenv("CROSSCLR_FWD_KERNEL"), "8wave");   // A/B knob
-    if (symmetric && !pairs && p->Dpad <= 512 && !old_sym) {   // software-pipelined 4-wave kernel (crossclr_kernels_sym.h)
-#define CROSSCLR_LSY(DK)                                                                                                      \
-    do {                                                                                                                      \
-        if (sw) CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, true, false>), grid, dim3(256), stream, r, g, wk, part, colpart, header, krows, (unsigned char*)nullptr); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, false, false>), grid, dim3(256), stream, r, g, wk, part, colpart, header, krows, (unsigned char*)nullptr);  \
-    } while (0)
-        switch (p->Dpad) {
-            case 128: CROSSCLR_LSY(8); break;
-            case 256: CROSSCLR_LSY(16); break;
-            case 384: CROSSCLR_LSY(24); break;
-            case 512: CROSSCLR_LSY(32); break;
-            default: return CROSSCLR_E_ARG;
-        }
-#undef CROSSCLR_LSY
-        return CROSSCLR_OK;
-    }
+    static const bool old_fwd = getenv("CROSSCLR_FWD_KERNEL") && !strcmp(getenv("CROSSCLR_FWD_KERNEL"), "8wave");   // A/B knob
+    if (p->Dpad <= 512 && !old_fwd)   // software-pipelined 4-wave kernel (crossclr_kernels_sym.h): symmetric, rectangular and pairs
+        return fast_forward_pipe(p, g, wk, rows, cols, part, colpart, header, symmetric ? 1 : (pairs ? 3 : 2), krows, kcols, nullptr, stream);
 #define CROSSCLR_LF2(DK, NW, SYM, SW) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW, false>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols, (unsigned char*)nullptr)
 #define CROSSCLR_LF(DK, NW)                                        \
@@ -1388,38 +1460,33 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
 static inline size_t fast_stash_bytes(int bpad, int Dpad) {
     return Dpad <= 512 ? stash_tiles_total(8, 2 * bpad / 32) * 2048 : 0;
 }
+// bytes of the stash of a rectangular (remote / pairs) launch over `nranks` column ranks
+static inline size_t fast_stash_bytes_rect(int bpad, int Dpad, int nranks) {
+    return Dpad <= 512 ? (size_t)(2 * bpad / 32) * (size_t)(2 * bpad / 32) * (size_t)nranks * 2048 : 0;
+}
 static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const void* x, float* part, float* colpart,
                                     int* header, const float* ks, void* stash, void* stream) {
     const FwdWork wk = fast_forward_work(p, 1, -1, true);
-    if (wk.total <= 0) return CROSSCLR_OK;
-    const bf16_t* r = (const bf16_t*)x;
-    dim3 grid(wk.nblk);
-#define CROSSCLR_LFS(DK)                                                                                                   \
-    do {                                                                                                                    \
-        if (ks) CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, true, true>), grid, dim3(256), stream, r, g, wk, part, colpart, header, ks, (unsigned char*)stash); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_sym_kernel<DK, false, true>), grid, dim3(256), stream, r, g, wk, part, colpart, header, ks, (unsigned char*)stash);  \
-    } while (0)
-    switch (p->Dpad) {
-        case 128: CROSSCLR_LFS(8); break;
-        case 256: CROSSCLR_LFS(16); break;
-        case 384: CROSSCLR_LFS(24); break;
-        case 512: CROSSCLR_LFS(32); break;
-        default: return CROSSCLR_E_ARG;
-    }
-#undef CROSSCLR_LFS
-    return CROSSCLR_OK;
+    return fast_forward_pipe(p, g, wk, x, x, part, colpart, header, 1, ks, ks, stash, stream);
 }
-static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* x, const void* stash, const float* rz,
-                                      const float* wrz, float* gbuf, int accumulate, const float* ks, void* stream) {
-    const int ntiles = 2 * p->bpad / 32;
+// rect = false: the symmetric local block (x is both operands).  rect = true: a rectangular block whose forward saved its
+// exponentials (g describes the column ranks; cols / rz_cols / wrz_cols / kc use the column operand's indexing).
+static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* cols, const void* stash, const float* rz,
+                                      const float* wrz, const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
+                                      const float* ks, const float* kc, bool rect, void* stream) {
+    const bool skipping = rect && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
+    const int ntiles = (rect ? g.col_ranks - (skipping ? 1 : 0) : 1) * (2 * p->bpad / 32);
+    if (ntiles <= 0) return CROSSCLR_OK;
     const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
-    const bf16_t* c = (const bf16_t*)x;
+    const bf16_t* c = (const bf16_t*)cols;
     const unsigned char* st = (const unsigned char*)stash;
-#define CROSSCLR_LBS(DK)                                                                                                            \
-    do {                                                                                                                             \
-        if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, true>), grid, block, stream, c, st, g, rz, wrz, gbuf, accumulate, tps, ks); \
-        else CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, false>), grid, block, stream, c, st, g, rz, wrz, gbuf, accumulate, tps, ks);  \
+#define CROSSCLR_LBS2(DK, SW, RECT) \
+    CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, SW, RECT>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
+#define CROSSCLR_LBS(DK)                                                              \
+    do {                                                                               \
+        if (rect) { if (ks) CROSSCLR_LBS2(DK, true, true); else CROSSCLR_LBS2(DK, false, true); }    \
+        else { if (ks) CROSSCLR_LBS2(DK, true, false); else CROSSCLR_LBS2(DK, false, false); }        \
     } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LBS(8); break;
@@ -1429,9 +1496,9 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_LBS
+#undef CROSSCLR_LBS2
     return CROSSCLR_OK;
 }
-
 // which backward the fast path uses: 16-row wavefronts (rows per block 128 at Dpad <= 512, 64 above) or the
 // 32-row kernel (Dpad <= 512 only)
 static inline int fast_bwd_rows_per_block(int Dpad, int use16) { return use16 ? (Dpad <= 512 ? 128 : 64) : 128; }

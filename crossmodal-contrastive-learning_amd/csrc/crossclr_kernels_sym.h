@@ -1,7 +1,12 @@
-// crossclr_kernels_sym.h -- the symmetric forward of the single-device step / local block (Dpad <= 512), software-pipelined.
+// crossclr_kernels_sym.h -- the software-pipelined forward (Dpad <= 512): symmetric local block, rectangular remote blocks, pairs.
 //
-// Same mathematics and the same workspace layout as fast_fwd_kernel<DK, 1, 8, SW> (upper triangle of the stacked 2b x 2b matrix of
-// exponentials, mirrored half recovered from column sums; reference trainer/loss.py:83-100, 59-60), built differently:
+// Same mathematics and the same workspace layouts as fast_fwd_kernel<DK, SYM, 8, SW> (reference trainer/loss.py:83-100, 59-60):
+//   KIND 1  symmetric: rows and columns are the same operand; upper triangle of the stacked 2b x 2b matrix of exponentials,
+//           the mirrored half recovered from column sums                                  (single device / local block)
+//   KIND 2  rectangular: this rank's rows against other ranks' columns (segments in memory order, one rank skipped)
+//   KIND 3  pairs: rectangular over ranks col_rank0, col_rank0+1, ... (mod col_wrap) of the whole gathered operand, and EVERY
+//           tile also yields its column sums over this rank's rows (what the column ranks would otherwise compute)
+// built differently from that kernel:
 //   * 4 waves x 64 rows per 256-row block, ONE wave per SIMD (512 registers): both 32-row halves' fragments stay resident
 //     (2 x Dpad/4 registers), so one ds_read_b128 of the column tile feeds TWO MFMAs (half the LDS reads of the 8-wave kernel);
 //   * the epilogue of tile t-1 (scale, exp2, row sums, bf16 pack + stash stores, 64-row column sums) is cut into chores that
@@ -10,14 +15,17 @@
 //     buffer-addressed LDS-DMA (NST-deep ring) -- hipcc puts no wait of its own into the MFMA stream;
 //   * tiles that need a mask (the 256x256 diagonal blocks, ragged columns, padding rows) and the sample-weight variant take the
 //     plain, un-overlapped epilogue: 8 of ~65 tiles per row block.
-// ST: the bf16 exponentials of every evaluated tile are saved for fast_bwd_saved_kernel (layout: stash_tile_index).
+// ST: the bf16 exponentials of every evaluated tile are saved for fast_bwd_saved_kernel -- KIND 1: the triangular layout of
+// stash_tile_index; KIND 2/3: rectangular, tile (32-row group r32, item j) at (r32 * NT + j) * 2 KiB.
 #pragma once
 
 namespace crossclr {
 
-template <int DK, bool SW, bool ST>
-__global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, Geo g, FwdWork wk, float* part, float* colpart,
-                                                              int* header, const float* ks, unsigned char* stash) {
+template <int DK, int KIND, bool SW, bool ST>
+__global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, const bf16_t* xc, Geo g, FwdWork wk, float* part,
+                                                               float* colpart, int* header, const float* ks, const float* kc,
+                                                               unsigned char* stash) {
+    static_assert(KIND >= 1 && KIND <= 3, "1 symmetric, 2 rectangular, 3 pairs");
     constexpr int RB = DK * 32;            // bytes per operand row
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
@@ -32,27 +40,60 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    if (blockIdx.x == 0 && tid == 0) { header[0] = 1; header[1] = TPR; header[2] = wk.NT; header[3] = wk.per; }
-    const int NT = wk.NT;
+    if (blockIdx.x == 0 && tid == 0) { header[0] = wk.kind; header[1] = TPR; header[2] = wk.NT; header[3] = wk.per; }
+    const int NT = wk.NT;                      // KIND 1: column tiles of the operand; KIND 2/3: usable column tiles
+    const int per_rank = 2 * g.bpad / QT, per_mod = g.bpad / QT;
+    const int skip_seg = (KIND == 2 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
 
     int w = blockIdx.x * wk.per;
     int w_end = w + wk.per;
     if (w_end > wk.total) w_end = wk.total;
-    struct Cursor { int rb, j; };          // item = (row block, index inside its tile list): tile t = TPR*rb + j
-    auto advance = [&](Cursor& c) { if (++c.j == NT - TPR * c.rb) { c.j = 0; ++c.rb; } };
+    // item = (row block rb, index j inside its tile list); mt = the tile's index inside the column operand (DMA / statistics
+    // address), seg / in_seg = its rank segment and position inside the segment (modality, ragged test) -- tracked
+    // incrementally: no division per tile
+    struct Cursor { int rb, j, mt, seg, in_seg; };
+    auto seg_start = [&](Cursor& c) {          // c.seg is set: first tile of that segment
+        c.in_seg = 0;
+        // col_wrap = 0: the operand holds exactly the launch's segments, in order; col_wrap = W: it is the whole gathered array
+        // and segment i is rank (col_rank0 + i) mod W
+        if (KIND != 1) {
+            int r = c.seg;
+            if (g.col_wrap > 0) { r += g.col_rank0; if (r >= g.col_wrap) r -= g.col_wrap; }
+            c.mt = r * per_rank;
+        }
+    };
+    auto row_start = [&](Cursor& c) {          // c.rb is set: first item of that row block
+        c.j = 0;
+        if (KIND == 1) { c.mt = TPR * c.rb; c.seg = 0; c.in_seg = c.mt; }
+        else { c.seg = (skip_seg == 0) ? 1 : 0; seg_start(c); }
+    };
+    auto advance = [&](Cursor& c) {
+        ++c.j; ++c.mt; ++c.in_seg;
+        if (c.j == (KIND == 1 ? NT - TPR * c.rb : NT)) { ++c.rb; row_start(c); return; }
+        if (KIND != 1 && c.in_seg == per_rank) { ++c.seg; if (c.seg == skip_seg) ++c.seg; seg_start(c); }
+    };
     Cursor cq[NST];
     {
         int rb = 0;
         while (fwd_prefix(wk, rb + 1) <= w) ++rb;
         cq[0].rb = rb;
-        cq[0].j = w - fwd_prefix(wk, rb);
+        row_start(cq[0]);
+        const int j0 = w - fwd_prefix(wk, rb);
+        if (KIND == 1) { cq[0].j = j0; cq[0].mt += j0; cq[0].in_seg = cq[0].mt; }
+        else {
+            int su = j0 / per_rank;                        // usable segments before the item (once per block)
+            cq[0].seg = su + ((skip_seg >= 0 && su >= skip_seg) ? 1 : 0);
+            seg_start(cq[0]);
+            cq[0].j = j0; cq[0].in_seg = j0 - su * per_rank; cq[0].mt += cq[0].in_seg;
+        }
     }
 #pragma unroll
     for (int k = 1; k < NST; ++k) { cq[k] = cq[k - 1]; advance(cq[k]); }
 
     // column-tile DMA: piece k of this wave fills LDS bytes [(wave + 4k) KiB, +1 KiB) of the stage
-    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * RB));
-    const BufRsrc rs_k = make_rsrc(SW ? (const void*)ks : (const void*)x, (unsigned)(2 * g.bpad * 4));
+    const int col_segs = KIND == 1 ? 1 : (g.col_wrap > 0 ? g.col_wrap : g.col_ranks);     // rank segments the column operand holds
+    const BufRsrc rs_x = make_rsrc(xc, (unsigned)((size_t)col_segs * 2 * g.bpad * RB));
+    const BufRsrc rs_k = make_rsrc(SW ? (const void*)kc : (const void*)xc, (unsigned)((size_t)col_segs * 2 * g.bpad * 4));
     unsigned voffx[NXO];
 #pragma unroll
     for (int k = 0; k < NXO; ++k) {
@@ -66,7 +107,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
 #define CROSSCLR_YABL 0   // timing ablations of this kernel (WRONG results): bit0 every block streams the same 64 column tiles (L2-resident),
                           // bit1 no stash stores, bit2 no column-sum butterfly, bit3 plain epilogue for every tile (no overlap), bit4 no DMA
 #endif
-    auto tile_of = [&](const Cursor& c) { const int t = TPR * c.rb + c.j; return (CROSSCLR_YABL & 1) ? (t & 63) : (t < NT ? t : NT - 1); };
+    const int mt_last = col_segs * per_rank - 1;
+    auto tile_of = [&](const Cursor& c) { return (CROSSCLR_YABL & 1) ? (c.mt & 63) : (c.mt < mt_last ? (c.mt < 0 ? 0 : c.mt) : mt_last); };
     auto issue_piece = [&](const Cursor& c, int stage, int k) {
         if (CROSSCLR_YABL & 16) return;
         lds_dma16_buf(rs_x, voffx[k], (unsigned)tile_of(c) * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
@@ -100,8 +142,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
         }
     };
     // ---- the tile whose epilogue is still owed ----
-    struct Prev { bool valid, fast; int t, rb; };
-    Prev prev = {false, false, 0, 0};
+    struct Prev { bool valid, fast; int j, cmod, in_mod0, stage, crank; };   // (the owed tile always belongs to the current row block)
+    Prev prev = {false, false, 0, 0, 0, 0, 0};
     f32x16 pacc[2];
     // ---- column sums waiting for the next barrier ----
     bool pending = false;
@@ -113,48 +155,51 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
         }
     };
     struct Bits8 { bf16_t v[8]; };
-    auto stash_store = [&](int t, int s, const float (&e)[16]) {     // (my_rb is the row block of the tile being finished)
-        const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)(t - TPR * my_rb)) * 2048, 2048u);
+    auto stash_store = [&](int j, int s, const float (&e)[16]) {     // (my_rb is the row block of the tile being finished)
+        const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)j) * 2048, 2048u);
 #pragma unroll
         for (int th = 0; th < 2; ++th) {
             Bits8 pk;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[8 * th + j]);
+            for (int q = 0; q < 8; ++q) pk.v[q] = f32_to_bf16_bits(e[8 * th + q]);
             buf_store16(rs_st, (unsigned)(lane * 16 + 1024 * th), 0u, __builtin_bit_cast(u32x4, pk));
         }
     };
-    auto colsum_publish = [&](const float (&es)[16], int t) {
+    // position of item j's 32 column sums inside a colpart row: KIND 1 the tile's place in the operand, KIND 3 in the pair range
+    auto colpos = [&](int j) { return KIND == 1 ? TPR * my_rb + j : j; };
+    auto wants_colsum = [&](int j) { return KIND == 3 || (KIND == 1 && j >= TPR); };   // KIND 1: strictly right of the diagonal block
+    auto colsum_publish = [&](const float (&es)[16], int j) {
         const float colsum = halving_sum16(es, l31);
         pbuf ^= 1;
         if (l31 < 16) cs[pbuf * (4 * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
         pending = true;
-        ptile = t;
+        ptile = colpos(j);
         prb = my_rb;
     };
     // general (masked / weighted) epilogue of one tile, not overlapped with anything
-    auto epilogue_plain = [&](f32x16 (&acc)[2], int t, int stage_of_t) {
-        const int tmod = (QT * t >= g.bpad) ? 1 : 0;
-        const int in_mod0 = QT * t - tmod * g.bpad;
-        const bool same_mod = tmod == rmod;
+    auto epilogue_plain = [&](f32x16 (&acc)[2], const Prev& pv) {
+        const bool same_mod = pv.cmod == rmod;
         const float c2s = same_mod ? g.c_intra : g.c_inter;
-        const bool upper = t >= TPR * (my_rb + 1);
+        const bool upper = wants_colsum(pv.j);
         const float ninf = -__builtin_inff();
         float es[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) es[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int r32 = TPR * my_rb + 2 * wave + s;
             const int r_in_mod = row0w + 32 * s - rmod * g.bpad + l31;
             float xx[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) xx[r] = acc[s][r] * c2s - g.m2;
-            if (in_mod0 + QT > g.b) {                       // ragged tile: columns beyond the valid batch
+            if (pv.in_mod0 + QT > g.b) {                    // ragged tile: columns beyond the valid batch
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (in_mod0 + frag_row(r, half) >= g.b) xx[r] = ninf;
+                    if (pv.in_mod0 + frag_row(r, half) >= g.b) xx[r] = ninf;
             }
-            if (t == r32) {                                  // the tile that holds this half's diagonal
+            // the tile that holds this half's self pairs: KIND 1 t == r32; a rectangular launch that includes the rows' own rank
+            const bool diag_here = KIND == 1 ? (pv.j == 2 * wave + s)
+                                             : (pv.crank == g.row_rank && same_mod && pv.in_mod0 == row0w + 32 * s - rmod * g.bpad);
+            if (diag_here) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (frag_row(r, half) == l31) xx[r] = ninf;
@@ -166,16 +211,16 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
             float e[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = fast_exp2(xx[r]);
-            if (ST) stash_store(t, s, e);
+            if (ST) stash_store(pv.j, s, e);
             if (SW && same_mod) {
-                const float* kq = reinterpret_cast<const float*>(lds + KQ0 + stage_of_t * 256);
+                const float* kq = reinterpret_cast<const float*>(lds + KQ0 + pv.stage * 256);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const f32x4 k4 = *reinterpret_cast<const f32x4*>(kq + 8 * r4 + 4 * half);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        rowacc[s] += e[4 * r4 + j] * k4[j];
-                        es[4 * r4 + j] += e[4 * r4 + j] * kp[s];
+                    for (int q = 0; q < 4; ++q) {
+                        rowacc[s] += e[4 * r4 + q] * k4[q];
+                        es[4 * r4 + q] += e[4 * r4 + q] * kp[s];
                     }
                 }
             } else {
@@ -183,18 +228,17 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
                 for (int r = 0; r < 16; ++r) { rowacc[s] += e[r]; es[r] += e[r]; }
             }
         }
-        if (upper) colsum_publish(es, t);
+        if (upper) colsum_publish(es, pv.j);
     };
 
     int stage = 0;
     while (w < w_end) {
-        const int t = TPR * cq[0].rb + cq[0].j;
         if (cq[0].rb != my_rb) {   // (re)load this wave's 64 rows as MFMA B fragments; first settle what is owed to the old rows
             if (prev.valid) {   // (SW tiles never stay owed: see below)
                 // the owed tile may publish column sums while an earlier publication still waits for its barrier: flush that first
                 __syncthreads();
                 if (pending) { flush(); pending = false; }
-                epilogue_plain(pacc, prev.t, 0);
+                epilogue_plain(pacc, prev);
                 prev.valid = false;
             }
             if (my_rb >= 0) store_rows();
@@ -205,7 +249,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (SW) kp[s] = ks[row0w + 32 * s + l31];
-                if (ST) st0[s] = stash_tile_index(TPR, NT, TPR * my_rb + 2 * wave + s, TPR * my_rb);
+                if (ST) st0[s] = KIND == 1 ? stash_tile_index(TPR, NT, TPR * my_rb + 2 * wave + s, TPR * my_rb)
+                                           : (size_t)(TPR * my_rb + 2 * wave + s) * (size_t)NT;
                 const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * 16) + 8 * half;
 #pragma unroll
                 for (int k = 0; k < DK; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
@@ -247,14 +292,13 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
         // count as written when the asm statement ends, so a register copy at a control-flow merge would read them early.
 
         if (prev.valid && prev.fast) {
-            // ---- pipelined: the owed tile is unmasked, unweighted and strictly right of the diagonal block ----
-            const int ptmod = (QT * prev.t >= g.bpad) ? 1 : 0;
-            const float c2s = (ptmod == rmod) ? g.c_intra : g.c_inter;
+            // ---- pipelined: the owed tile is unmasked and unweighted (and, KIND 1, strictly right of the diagonal block) ----
+            const float c2s = (prev.cmod == rmod) ? g.c_intra : g.c_inter;
             float e[2][16], es[16], k8[8], k4[4], k2[2];
-            // chore plan over the DK k-steps (C = DK / 8 elements of work per step and stage):
-            //   steps [0, DK/2): scale + exp2 + row sum of elements (s = step / (DK/4), r = ...)   -- 32 elements
+            // chore plan over the DK k-steps:
+            //   steps [0, DK/2): scale + exp2 + row sum of the 32 elements
             //   steps [DK/2, 3DK/4): es = e0 + e1 (16), bf16 pack + stash stores (4 fragments)
-            //   steps [3DK/4, DK): recursive-halving butterfly (8 + 4 + 2 + 1 + final) and the LDS slot write
+            //   steps [3DK/4, DK): recursive-halving butterfly (8 + 4 + 2 + 1 + final) and the LDS slot write (KIND 1 / 3)
             constexpr int S1 = DK / 2, S2 = 3 * DK / 4;
             static_for<PF>([&](auto ic) { fetch(ic); });
             static_for<DK>([&](auto ic) {
@@ -270,20 +314,22 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
                     }
                 } else if constexpr (k < S2) {
                     constexpr int n = S2 - S1, i = k - S1;         // n steps: 16 sums and 4 fragments
+                    if (KIND != 2) {
 #pragma unroll
-                    for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = e[0][r] + e[1][r];
+                        for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = e[0][r] + e[1][r];
+                    }
                     if (ST && !(CROSSCLR_YABL & 2)) {
 #pragma unroll
                         for (int f = (4 * i) / n; f < (4 * (i + 1)) / n; ++f) {
                             const int s = f >> 1, th = f & 1;
-                            const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)(prev.t - TPR * my_rb)) * 2048, 2048u);
+                            const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)prev.j) * 2048, 2048u);
                             Bits8 pk;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[s][8 * th + j]);
+                            for (int q = 0; q < 8; ++q) pk.v[q] = f32_to_bf16_bits(e[s][8 * th + q]);
                             buf_store16(rs_st, (unsigned)(lane * 16 + 1024 * th), 0u, __builtin_bit_cast(u32x4, pk));
                         }
                     }
-                } else {
+                } else if constexpr (KIND != 2) {
                     constexpr int n = DK - S2, i = k - S2;         // n >= 2 steps for the butterfly
                     constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;   // work units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: publish
 #pragma unroll
@@ -308,7 +354,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
                             pbuf ^= 1;
                             if (l31 < 16) cs[pbuf * (4 * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = k2[0];
                             pending = true;
-                            ptile = prev.t;
+                            ptile = colpos(prev.j);
                             prb = my_rb;
                         }
                     }
@@ -316,26 +362,35 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
                 sched_fence();
             });
         } else {
-            if (prev.valid) epilogue_plain(pacc, prev.t, (stage + NST - 1) % NST);   // the owed tile's k_q stage = the stage of tile w-1
+            if (prev.valid) epilogue_plain(pacc, prev);
             static_for<PF>([&](auto ic) { fetch(ic); });
             static_for<DK>([&](auto ic) { kstep(ic); sched_fence(); });
         }
         // this tile's epilogue is owed to the next iteration
         {
-            const int tmod = (QT * t >= g.bpad) ? 1 : 0;
-            const int in_mod0 = QT * t - tmod * g.bpad;
-            const bool upper = t >= TPR * (my_rb + 1);
+            const int cmod = cq[0].in_seg >= per_mod ? 1 : 0;
+            const int in_mod0 = (cq[0].in_seg - cmod * per_mod) * QT;
             const bool ragged = in_mod0 + QT > g.b;
             const bool padrows = (row0w - rmod * g.bpad) + 64 > g.b;
+            const bool colsum = wants_colsum(cq[0].j);
+            int crank = g.row_rank;
+            if (KIND != 1) { crank = g.col_rank0 + cq[0].seg; if (g.col_wrap > 0 && crank >= g.col_wrap) crank -= g.col_wrap; }
+            const int r0 = row0w - rmod * g.bpad;       // the wave's first row inside its modality
+            const bool selfpairs = KIND != 1 && crank == g.row_rank && cmod == rmod && (in_mod0 == r0 || in_mod0 == r0 + 32);
             prev.valid = true;
-            prev.fast = !SW && upper && !ragged && !padrows && !(CROSSCLR_YABL & 8);
-            prev.t = t;
-            prev.rb = my_rb;
+            // fast = nothing to mask: KIND 1 tiles of the diagonal block (j < TPR) hold the self pairs; padding rows only matter
+            // where column sums are formed
+            prev.fast = !SW && !ragged && !(colsum && padrows) && !(KIND == 1 && !colsum) && !selfpairs && !(CROSSCLR_YABL & 8);
+            prev.crank = crank;
+            prev.j = cq[0].j;
+            prev.cmod = cmod;
+            prev.in_mod0 = in_mod0;
+            prev.stage = stage;
             pacc[0] = acc[0];
             pacc[1] = acc[1];
         }
         if (SW) {   // weighted tiles read their k_q from the tile's ring stage: finish them before the stage is refilled
-            epilogue_plain(pacc, t, stage);
+            epilogue_plain(pacc, prev);
             prev.valid = false;
         }
         stage = (stage + 1) % NST;
@@ -347,7 +402,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_sym_kernel(const bf16_t* x, G
     wait_dma();      // (the clamped re-fetches past the end of the work list)
     __syncthreads();
     if (pending) { flush(); pending = false; }
-    if (prev.valid) epilogue_plain(pacc, prev.t, 0);
+    if (prev.valid) epilogue_plain(pacc, prev);
     __syncthreads();
     if (pending) flush();
     if (my_rb >= 0) store_rows();

@@ -89,7 +89,8 @@ class _Workspace:
     """Everything one forward produces and the backward consumes (all caller-owned torch tensors)."""
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
-                 "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized")
+                 "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
+                 "saved_blocks", "recompute_ranges")
 
 
 _plan_cache: dict = {}
@@ -240,7 +241,43 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # 8 ranks (+ the antipodal one, evaluated by both).  CROSSCLR_DISABLE_PAIR_FORWARD=1: every rank evaluates all blocks.
     use_pairs = (sharded and plan.fast_path == 1 and world >= 3 and
                  os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1")
-    if sharded and use_pairs:
+    # With a backward to follow, the remote blocks this rank evaluates itself (pair partners, antipodal rank; at 2 ranks: the
+    # other rank) save their exponentials as well: the backward then recomputes only the blocks the OTHER ranks evaluated.
+    ws.saved_blocks, ws.recompute_ranges = None, None
+    save_remote = (sharded and world >= 2 and ws.stash is not None and (use_pairs or world == 2) and
+                   os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1")
+    if save_remote:
+        gather.wait()
+        n2 = 2 * plan.bpad
+        npairs = (world - 1) // 2 if use_pairs else 0
+        sw_all = _sw(ws.k_rows, ws.k_cols, None)
+        ws.saved_blocks, ws.recompute_ranges = [], []
+        if npairs:
+            colsum = torch.empty(npairs * n2, **f32)
+            st = torch.empty(lib.crossclr_rect_stash_bytes(pp, npairs), dtype=torch.uint8, device=dev)
+            nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), (rank + 1) % world, npairs, 1, ws.temperature,
+                                                     ws.negative_w, sw_all, _ptr(part), plan.fwd_slots, _ptr(colsum), _ptr(st), stream))
+            ws.saved_blocks.append(((rank + 1) % world, npairs, st))
+            ws.recompute_ranges.append(((rank - npairs) % world, npairs))
+        if world % 2 == 0:   # the antipodal rank (at 2 ranks: the other rank): both sides evaluate their own rows
+            opp = (rank + world // 2) % world
+            st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
+            nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), opp, 1, 0, ws.temperature, ws.negative_w,
+                                                     sw_all, _ptr(part), (2 if npairs else 1) * plan.fwd_slots, None, _ptr(st), stream))
+            ws.saved_blocks.append((opp, 1, st))
+        elif npairs:
+            nat.check(lib.crossclr_forward_add(pp, _ptr(part), 2 * plan.fwd_slots, None, stream))
+        if npairs:
+            outbox = torch.zeros(world, n2, **f32)
+            outbox[[(rank + 1 + k) % world for k in range(npairs)]] = colsum.view(npairs, n2)
+            inbox = torch.empty(world, n2, **f32)
+            dist.all_to_all_single(inbox.view(-1), outbox.view(-1), group=group)
+            received = inbox.sum(0)         # fixed order over source ranks: deterministic (kept in a variable: _ptr is a bare address)
+            nat.check(lib.crossclr_forward_add(pp, _ptr(part), 3 * plan.fwd_slots, _ptr(received), stream))
+            nlaunch = 4
+        else:
+            nlaunch = 2
+    elif sharded and use_pairs:
         gather.wait()
         n2 = 2 * plan.bpad
         npairs = (world - 1) // 2
@@ -258,12 +295,13 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                                              2 * plan.fwd_slots, stream))
         else:
             nat.check(lib.crossclr_forward_add(pp, _ptr(part), 2 * plan.fwd_slots, None, stream))
-        # ship colsum[k] to rank+1+k: one all-gather of every rank's [world][2*bpad] outbox (zeros elsewhere)
+        # ship colsum[k] to rank+1+k: one all-to-all of [world][2*bpad] outboxes (row s goes to rank s; zeros where this rank
+        # evaluated nothing for s) -- world x less traffic than gathering every rank's whole outbox
         outbox = torch.zeros(world, n2, **f32)
         outbox[[(rank + 1 + k) % world for k in range(npairs)]] = colsum.view(npairs, n2)
-        inbox = torch.empty(world * world * n2, **f32)
-        dist.all_gather_into_tensor(inbox, outbox.view(-1), group=group)
-        received = inbox.view(world, world, n2)[:, rank].sum(0)
+        inbox = torch.empty(world, n2, **f32)
+        dist.all_to_all_single(inbox.view(-1), outbox.view(-1), group=group)
+        received = inbox.sum(0)         # fixed order over source ranks: deterministic
         nat.check(lib.crossclr_forward_add(pp, _ptr(part), 3 * plan.fwd_slots, _ptr(received), stream))
         nlaunch = 4
     elif sharded:
@@ -365,7 +403,21 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                           _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
                                           _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
-    if ws.sharded and ws.shift is None:
+    if ws.sharded and ws.shift is None and ws.saved_blocks is not None:
+        if ws.wrz_cols is None:
+            ws.stats_work.wait()
+            ws.wrz_cols = ws.rz_cols * ws.negative_w
+        sw_all = _sw(ws.k_rows, ws.k_cols, None)
+        for first, n, st in ws.saved_blocks:        # blocks this rank evaluated in the forward: from their saved exponentials
+            nat.check(lib.crossclr_backward_rect_saved(pp, _ptr(ws.xcols), _ptr(st), first, n, ws.temperature, ws.negative_w,
+                                                       _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
+                                                       _ptr(gbuf), 1, stream))
+        for first, n in ws.recompute_ranges:        # blocks the other side of a pair evaluated: recompute
+            nat.check(lib.crossclr_backward_ranks(pp, _ptr(ws.xhat), _ptr(ws.xcols), first, n, ws.temperature, ws.negative_w,
+                                                  _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
+                                                  _ptr(gbuf), 1, stream))
+        ws.saved_blocks = None
+    elif ws.sharded and ws.shift is None:
         if ws.wrz_cols is None:
             ws.stats_work.wait()
             ws.wrz_cols = ws.rz_cols * ws.negative_w

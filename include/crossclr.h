@@ -202,6 +202,31 @@ int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const v
                             float temperature, float negative_weight, const float* rz, const float* wrz,
                             const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
 
+/* ---- sharded step: rectangular blocks with saved exponentials (ABI version 3) -------------------------------------------
+ * In a sharded run this rank evaluates, besides its local block, the blocks of its pair partners (ranks rank+1 ..
+ * rank+(world-1)/2, whose column sums it ships to them: crossclr_forward_pairs) and of the antipodal rank.  With a backward
+ * to follow those launches can save their exponentials too: crossclr_forward_rect_save is crossclr_forward_pairs
+ * (with_colsums = 1) or a plain rectangular launch over `nranks` ranks from `first_rank` (with_colsums = 0; modulo plan->world,
+ * columns taken from the whole gathered operand xhat_all [world][2][bpad][Dpad]) that also fills `stash`
+ * (crossclr_rect_stash_bytes(plan, nranks) bytes: 2 KiB per 32 x 32 tile, 0.54 GB per rank at b = 8192), and
+ * crossclr_backward_rect_saved consumes it: gbuf += W . xhat over those ranks' columns without recomputing the similarity
+ * product (rz_all / wrz_all / sw->neg_scale_cols: the gathered [world][2][bpad] statistics).  The blocks OTHER ranks
+ * evaluated (ranks rank-1 .. rank-(world-1)/2) are not held here: crossclr_backward_ranks recomputes them
+ * (crossclr_backward_w over a wrapping rank range).                                                                   */
+size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nranks);
+int crossclr_forward_rect_save(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
+                               int first_rank, int nranks, int with_colsums, float temperature, float negative_weight,
+                               const crossclr_sample_weights* sw, float* part, int slot0, float* colsum_out,
+                               void* stash, void* stream);
+int crossclr_backward_rect_saved(const crossclr_plan* plan, const void* xhat_all, const void* stash,
+                                 int first_rank, int nranks, float temperature, float negative_weight,
+                                 const float* rz_rows, const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                 const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+int crossclr_backward_ranks(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
+                            int first_rank, int nranks, float temperature, float negative_weight,
+                            const float* rz_rows, const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                            const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+
 /* ---- caller-side fusion: embeddings that are already unit vectors (ABI version 3) --------------
  * When the producer (a projection head with a fused L2-norm epilogue) hands over unit rows, the normalisation of
  * loss.py:79-80 is not repeated: crossclr_pack only casts / lays the rows out as the packed operand (inv_norm := 1) and forms

@@ -508,3 +508,114 @@ def test_prenormalized_entry_equals_the_plain_path(mode, B, D):
     assert abs(loss.item() - loss0.item()) <= 2e-6 * max(1.0, abs(loss0.item()))
     scale = gv0.abs().max().item()
     assert (vd.grad - gv0).abs().max().item() <= 1e-4 * scale and (td.grad - gt0).abs().max().item() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("world,B,D,weighted", [(2, 512, 128, False), (3, 768, 256, False), (4, 2048, 512, False), (5, 1280, 256, True),
+                                                (8, 2048, 512, False)])
+def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, weighted):
+    """The sharded step with a backward to follow: pair partners' and the antipodal rank's blocks save their exponentials in the
+    forward (crossclr_forward_rect_save) and feed the backward from them (crossclr_backward_rect_saved); the blocks the OTHER
+    side of a pair evaluated are recomputed (crossclr_backward_ranks).  One GPU plays every rank through the C-ABI; loss and
+    gradients must equal the single-device run on the concatenated batch."""
+    lib, p = nat.library(), L._ptr
+    b = B // world
+    v, t = orc.make_inputs("randn", B, D, 71)
+    vd, td = v.cuda(), t.cuda()
+    g = torch.Generator().manual_seed(3)
+    kv = (torch.rand(B, generator=g) > 0.2).float()
+    kt = (torch.rand(B, generator=g) > 0.2).float()
+    ov = 0.5 + torch.rand(B, generator=g)
+    ot = 0.5 + torch.rand(B, generator=g)
+    stream = L._stream_for(vd)
+    f32 = dict(dtype=torch.float32, device="cuda")
+    plans = [nat.make_plan(b, D, world, r, nat.MODE_BF16) for r in range(world)]
+    pl = plans[0]
+    assert pl.stash_bytes > 0
+    n2 = 2 * pl.bpad
+    xall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device="cuda")
+    inv = [torch.empty(n2, **f32) for _ in range(world)]
+    diag = [torch.empty(pl.bpad, **f32) for _ in range(world)]
+    kall = torch.zeros(world, 2, pl.bpad, **f32)
+    lwall = torch.zeros(world, 2, pl.bpad, **f32)
+    kall[:, 0, :b], kall[:, 1, :b] = kv.view(world, b).cuda(), kt.view(world, b).cuda()
+    lwall[:, 0, :b], lwall[:, 1, :b] = ov.view(world, b).cuda(), ot.view(world, b).cuda()
+
+    def sw(r, cols_all, lw):
+        if not weighted:
+            return None
+        return ctypes.pointer(nat.SampleWeights(kall[r].data_ptr(), kall.data_ptr() if cols_all else kall[r].data_ptr(),
+                                                lwall[r].data_ptr() if lw else 0))
+    for r in range(world):
+        xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+        nat.check(lib.crossclr_normalize(ctypes.byref(plans[r]), p(vd[r * b:]), p(td[r * b:]), vd.stride(0), td.stride(0), nat.IN_F32,
+                                         p(xr), p(inv[r]), p(diag[r]), stream))
+    K = (world - 1) // 2
+    parts = [torch.empty(pl.fwd_ws_floats, **f32) for _ in range(world)]
+    colsums = [torch.zeros(max(K, 1), n2, **f32) for _ in range(world)]
+    stashes, blocks = [], []
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+        st_loc = torch.empty(pl.stash_bytes, dtype=torch.uint8, device="cuda")
+        nat.check(lib.crossclr_forward_save(pp, p(xr), 0.03, 0.8, sw(r, False, False), p(parts[r]), 0, p(st_loc), stream))
+        saved = []
+        if K:
+            st = torch.empty(lib.crossclr_rect_stash_bytes(pp, K), dtype=torch.uint8, device="cuda")
+            nat.check(lib.crossclr_forward_rect_save(pp, p(xr), p(xall), (r + 1) % world, K, 1, 0.03, 0.8, sw(r, True, False), p(parts[r]),
+                                                     pl.fwd_slots, p(colsums[r]), p(st), stream))
+            saved.append(((r + 1) % world, K, st))
+        if world % 2 == 0:
+            opp = (r + world // 2) % world
+            st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device="cuda")
+            nat.check(lib.crossclr_forward_rect_save(pp, p(xr), p(xall), opp, 1, 0, 0.03, 0.8, sw(r, True, False), p(parts[r]),
+                                                     (2 if K else 1) * pl.fwd_slots, None, p(st), stream))
+            saved.append((opp, 1, st))
+        elif K:
+            nat.check(lib.crossclr_forward_add(pp, p(parts[r]), 2 * pl.fwd_slots, None, stream))
+        stashes.append(st_loc)
+        blocks.append(saved)
+    rz = torch.empty(world, n2, **f32)
+    wrz = torch.empty(world, n2, **f32)
+    total = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        nl = 2
+        if K:
+            received = torch.zeros(n2, **f32)
+            for k in range(K):
+                received += colsums[(r - 1 - k) % world][k]
+            nat.check(lib.crossclr_forward_add(pp, p(parts[r]), 3 * pl.fwd_slots, p(received), stream))
+            nl = 4
+        logz = torch.empty(n2, **f32)
+        ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device="cuda")
+        nat.check(lib.crossclr_forward_finish_w(pp, p(parts[r]), nl * pl.fwd_slots, p(diag[r]), 0.03, 0.8, sw(r, False, True), p(logz),
+                                                p(rz[r]), p(wrz[r]), p(ls), stream))
+        total += ls[:1]
+    lossN = (total / (2.0 * B)).item()
+    gv, gt = torch.empty_like(vd), torch.empty_like(td)
+    go = torch.ones(1, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+        gbuf = torch.empty(pl.gbuf_bytes // 4, **f32)
+        nat.check(lib.crossclr_backward_saved(pp, p(xr), p(stashes[r]), 0.03, 0.8, p(rz[r]), p(wrz[r]), sw(r, False, False), p(gbuf), 0, stream))
+        for first, n, st in blocks[r]:
+            nat.check(lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, n, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
+                                                       sw(r, True, False), p(gbuf), 1, stream))
+        if K:
+            nat.check(lib.crossclr_backward_ranks(pp, p(xr), p(xall), (r - K) % world, K, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
+                                                  sw(r, True, False), p(gbuf), 1, stream))
+        nat.check(lib.crossclr_backward_finish_w(pp, p(gbuf), p(vd[r * b:]), p(td[r * b:]), vd.stride(0), td.stride(0), nat.IN_F32,
+                                                 p(inv[r]), 0.03, sw(r, False, True), p(go), p(gv[r * b:]), p(gt[r * b:]),
+                                                 gv.stride(0), gt.stride(0), stream))
+    torch.cuda.synchronize()
+    vg, tg = vd.clone().requires_grad_(True), td.clone().requires_grad_(True)
+    loss1 = crossclr_amd.crossclr_loss(vg, tg, 0.03, 0.8, compute_mode="bf16",
+                                       negative_scale=(kv.cuda(), kt.cuda()) if weighted else None,
+                                       loss_weight=(ov.cuda(), ot.cuda()) if weighted else None)
+    loss1.backward()
+    torch.cuda.synchronize()
+    assert abs(lossN - loss1.item()) <= 2e-6 * max(1.0, abs(loss1.item()))
+    scale = vg.grad.abs().max().item()
+    assert (gv - vg.grad).abs().max().item() <= 3e-3 * scale      # bf16 weights rounded in different tile groupings
+    assert (gt - tg.grad).abs().max().item() <= 3e-3 * scale

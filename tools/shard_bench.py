@@ -49,22 +49,31 @@ for world in (1, 2, 4, 8):
         e1.record(); torch.cuda.synchronize()
         stages[name] = e0.elapsed_time(e1) / 5
     run("normalize", lambda: lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xr), p(inv), p(diag), stream))
-    run("fwd_local", lambda: lib.crossclr_forward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(part), 0, stream))
-    if world > 2:   # pair scheme: (world-1)/2 blocks with column sums (+ the antipodal block when world is even)
-        K = (world - 1) // 2
+    stash = torch.empty(plan.stash_bytes, dtype=torch.uint8, device="cuda") if plan.stash_bytes else None
+    if stash is not None:   # the local block takes the save-for-backward pair, like the module does when a backward follows
+        run("fwd_local(save)", lambda: lib.crossclr_forward_save(pp, p(xr), 0.03, 0.8, None, p(part), 0, p(stash), stream))
+    else:
+        run("fwd_local", lambda: lib.crossclr_forward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(part), 0, stream))
+    K = (world - 1) // 2 if world > 2 else 0
+    saved = []     # (first_rank, nranks, stash): the remote blocks this rank evaluates itself, exponentials saved like the module does
+    if K:
         colsum = torch.empty(K * 2 * plan.bpad, **f32)
-        run("fwd_pairs", lambda: lib.crossclr_forward_pairs(pp, p(xr), p(xall), (rank + 1) % world, K, 0.03, 0.8, None, p(part),
-                                                            plan.fwd_slots, p(colsum), stream))
-        if world % 2 == 0:
-            opp = (rank + world // 2) % world
-            run("fwd_antipode", lambda: lib.crossclr_forward(pp, p(xr), p(xall[opp * plan.operand_bytes:]), 1, opp, -1, 0.03, 0.8,
-                                                             p(part), 2 * plan.fwd_slots, stream))
-        else:
-            nat.check(lib.crossclr_forward_add(pp, p(part), 2 * plan.fwd_slots, None, stream))
+        st_p = torch.empty(lib.crossclr_rect_stash_bytes(pp, K), dtype=torch.uint8, device="cuda")
+        run("fwd_pairs(save)", lambda: lib.crossclr_forward_rect_save(pp, p(xr), p(xall), (rank + 1) % world, K, 1, 0.03, 0.8, None, p(part),
+                                                                    plan.fwd_slots, p(colsum), p(st_p), stream))
+        saved.append(((rank + 1) % world, K, st_p))
+    if world > 1 and world % 2 == 0:
+        opp = (rank + world // 2) % world
+        st_a = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device="cuda")
+        run("fwd_antipode(save)", lambda: lib.crossclr_forward_rect_save(pp, p(xr), p(xall), opp, 1, 0, 0.03, 0.8, None, p(part),
+                                                                       (2 if K else 1) * plan.fwd_slots, None, p(st_a), stream))
+        saved.append((opp, 1, st_a))
+    elif K:
+        nat.check(lib.crossclr_forward_add(pp, p(part), 2 * plan.fwd_slots, None, stream))
+    if K:
         run("fwd_add", lambda: lib.crossclr_forward_add(pp, p(part), 3 * plan.fwd_slots, p(colsum), stream))
         n = 4 * plan.fwd_slots
     elif world > 1:
-        run("fwd_remote", lambda: lib.crossclr_forward(pp, p(xr), p(xall), world, 0, rank, 0.03, 0.8, p(part), plan.fwd_slots, stream))
         n = 2 * plan.fwd_slots
     else:
         n = plan.fwd_slots
@@ -72,9 +81,16 @@ for world in (1, 2, 4, 8):
     for r in range(world):
         rzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = rz
         wrzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = wrz
-    run("bwd_local", lambda: lib.crossclr_backward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(rz), p(wrz), p(rz), p(wrz), p(gbuf), 0, stream))
-    if world > 1:
-        run("bwd_remote", lambda: lib.crossclr_backward(pp, p(xr), p(xall), world, 0, rank, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc), p(gbuf), 1, stream))
+    if stash is not None:
+        run("bwd_local(saved)", lambda: lib.crossclr_backward_saved(pp, p(xr), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(gbuf), 0, stream))
+    else:
+        run("bwd_local", lambda: lib.crossclr_backward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(rz), p(wrz), p(rz), p(wrz), p(gbuf), 0, stream))
+    for i, (first, nr, st) in enumerate(saved):
+        run(f"bwd_saved[{nr}]" + ("" if i == 0 else "'"), lambda: lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, nr, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc),
+                                                                                                   None, p(gbuf), 1, stream))
+    if K:
+        run(f"bwd_recompute[{K}]", lambda: lib.crossclr_backward_ranks(pp, p(xr), p(xall), (rank - K) % world, K, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc),
+                                                                       None, p(gbuf), 1, stream))
     run("bwd_finish", lambda: lib.crossclr_backward_finish(pp, p(gbuf), p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(inv), 0.03, p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream))
     tot = sum(stages.values())
     val = (b * world) ** 2 / (tot * 1e-3)
