@@ -6,6 +6,7 @@
 #include "crossclr_kernels_generic.h"
 #ifndef CROSSCLR_NO_FAST
 #include "crossclr_kernels_fast.h"
+#include "crossclr_kernels_saved32.h"
 #endif
 
 #include <math.h>
@@ -83,7 +84,7 @@ static const EnvKnobs& env_knobs() {
 #endif
 }
 static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
-                           const float* kcols, const float* shift, int mode, void* stream);
+                           const float* kcols, const float* shift, int mode, void* stream, float* stash = nullptr);
 
 // forward workspace ("part") layout, in floats:
 //   [4 launch groups][fwd_slots][2*bpad] | colpart (symmetric launch) [<= 2*bpad/128 row blocks][2*bpad]
@@ -217,6 +218,11 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     plan->stash_bytes = 0;
 #ifndef CROSSCLR_NO_FAST
     if (plan->fast_path && plan->fast_bwd && !env.disable_save) plan->stash_bytes = fast_stash_bytes(plan->bpad, plan->Dpad);
+    // exact-fp32 mode: the whole stacked [2 bpad] x [2 bpad] matrix of fp32 exponentials (1 GiB at b = 8192), up to 16 GiB
+    if (mode == CROSSCLR_MODE_FP32 && !env.disable_save && plan->operand_bytes < (1ull << 32)) {
+        const size_t sb = (size_t)2 * plan->bpad * (size_t)2 * plan->bpad * 4;
+        if (sb <= ((size_t)16 << 30)) plan->stash_bytes = sb;
+    }
 #endif
     return CROSSCLR_OK;
 }
@@ -310,17 +316,24 @@ template <typename T>
 static void forward_generic_t(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
                               const float* kcols, const float* shift, int mode, int tps, dim3 grid, void* stream) {
     dim3 block(256);
-#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift)
+    (void)plan;
+#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift, (float*)nullptr)
     if (kcols) { if (mode == 0) CROSSCLR_LFG(true, 0); else if (mode == 1) CROSSCLR_LFG(true, 1); else CROSSCLR_LFG(true, 2); }
     else { if (mode == 0) CROSSCLR_LFG(false, 0); else if (mode == 1) CROSSCLR_LFG(false, 1); else CROSSCLR_LFG(false, 2); }
 #undef CROSSCLR_LFG
 }
 static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
-                           const float* kcols, const float* shift, int mode, void* stream) {
+                           const float* kcols, const float* shift, int mode, void* stream, float* stash) {
     const int ntiles = g.col_ranks * 2 * plan->bpad / 128;
     const int nsplit = plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     dim3 grid(2 * plan->bpad / 128, nsplit);
+    if (stash) {   // exact-fp32 forward that also saves its exponentials (local block, common shift)
+        dim3 block(256);
+        if (kcols) LAUNCH((fwd_sums_kernel<float, true, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash);
+        else LAUNCH((fwd_sums_kernel<float, false, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash);
+        return launch_status("fwd_sums_kernel (save)");
+    }
     if (plan->mode == CROSSCLR_MODE_FP32) forward_generic_t<float>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
     else forward_generic_t<bf16_t>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
     return launch_status("fwd_sums_kernel");
@@ -386,6 +399,11 @@ extern "C" int crossclr_forward_save(const crossclr_plan* plan, const void* xhat
         return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
     float* out = part + (size_t)slot0 * 2 * plan->bpad;
     int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    if (!plan->fast_path) {   // exact-fp32 mode
+        rc = device_zero_header(header, stream);
+        if (rc) return rc;
+        return forward_generic(plan, g, xhat, xhat, out, kcols, nullptr, 0, stream, static_cast<float*>(stash));
+    }
     rc = fast_forward_save(plan, g, xhat, out, part + ws_colpart_off(plan), header, krows, stash, stream);
     return rc ? fail(rc, "fast_forward_save: unsupported Dpad %d", plan->Dpad) : launch_status("fast_fwd_kernel (save)");
 #endif
@@ -405,6 +423,24 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
     if (rc) return rc;
+    if (!plan->fast_path) {   // exact-fp32 mode
+        const int NQ = 2 * plan->bpad / 32;
+        const int tps = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
+        const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;
+        dim3 block(256);
+#define CROSSCLR_LS32(DC)                                                                                                              \
+    do {                                                                                                                               \
+        if (krows) LAUNCH((bwd_saved32_kernel<DC, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,            \
+                          (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                               \
+        else LAUNCH((bwd_saved32_kernel<DC, false>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,                 \
+                    (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                                     \
+    } while (0)
+        if (plan->Dpad % 256 == 0) CROSSCLR_LS32(256);
+        else if (plan->Dpad % 128 == 0) CROSSCLR_LS32(128);
+        else CROSSCLR_LS32(64);
+#undef CROSSCLR_LS32
+        return launch_status("bwd_saved32_kernel");
+    }
     rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, false, stream);
     return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_saved_kernel");
 #endif
@@ -646,7 +682,7 @@ extern "C" size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nrank
 #ifdef CROSSCLR_NO_FAST
     return 0;
 #else
-    if (!plan || !plan->stash_bytes || nranks < 1) return 0;
+    if (!plan || !plan->stash_bytes || !plan->fast_path || nranks < 1) return 0;
     return fast_stash_bytes_rect(plan->bpad, plan->Dpad, nranks);
 #endif
 }
@@ -659,7 +695,7 @@ extern "C" int crossclr_forward_rect_save(const crossclr_plan* plan, const void*
 #ifdef CROSSCLR_NO_FAST
     return fail(CROSSCLR_E_ARG, "crossclr_forward_rect_save needs the register-resident path");
 #else
-    if (!plan->stash_bytes) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path (stash_bytes == 0)");
+    if (!plan->stash_bytes || !plan->fast_path) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
     if (with_colsums && nranks > (plan->world - 1) / 2) return fail(CROSSCLR_E_ARG, "a pair range holds at most (world-1)/2 ranks");
     if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
         return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
@@ -691,7 +727,7 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
 #ifdef CROSSCLR_NO_FAST
     return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved needs the register-resident path");
 #else
-    if (!plan->stash_bytes) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path (stash_bytes == 0)");
+    if (!plan->stash_bytes || !plan->fast_path) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
     const float *krows, *kcols;
     if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
     Geo g;

@@ -176,9 +176,15 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 //   MODE 0: sums of exp2(x - g.m2) (one shift for everything).  Small temperatures (Geo::row_shift) take two passes:
 //   MODE 1: the slot receives the row MAXIMUM of the scaled logits x over the slot's unmasked columns (columns with k_q = 0 do
 //           not count: they are not in the soft-max), MODE 2: sums of exp2(x - shift[p]) with the per-row shift of pass 1.
-template <typename T, bool SW, int MODE>
+//   ST (save for backward; MODE 0, rows and columns the same local operand): every 32x32 fragment of exponentials (masked
+//   entries as 0, WITHOUT the k_q factor) is also written to `stash` in the registers' own layout -- fragment (p32, q32) of the
+//   stacked [2 bpad] x [2 bpad] matrix at ((p32 * (2 bpad / 32)) + q32) * 4 KiB, inside it [r4][lane][4 floats]: lane
+//   (p = lane & 31, half) holds E[32 p32 + p][32 q32 + 8 r4 + 4 half + j] -- what bwd_saved32_kernel loads back, 16 bytes per
+//   lane, fully coalesced, no transposition anywhere (the generic forward evaluates both triangles).
+template <typename T, bool SW, int MODE, bool ST = false>
 __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
-                                                       float* part, const float* kcols, const float* shift) {
+                                                       float* part, const float* kcols, const float* shift, float* stash) {
+    static_assert(!ST || MODE == 0, "exponentials are saved by the single-pass forward only");
     typedef Operand<T> Op;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
@@ -258,6 +264,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                 for (int r4 = 0; r4 < 4; ++r4) {
                     f32x4 kq = {1.f, 1.f, 1.f, 1.f};
                     if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
+                    f32x4 ev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * r4 + j;
@@ -268,10 +275,15 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                             if (!masked && !(SW && kq[j] == 0.f)) rowacc[pi] = fmaxf(rowacc[pi], x);
                         } else {
                             float e = fast_exp2(acc[qi][pi][r] * c2 - (MODE == 2 ? myshift[pi] : g.m2));
-                            if (SW) e *= kq[j];
                             if (masked) e = 0.f;
+                            ev[j] = e;
+                            if (SW) e *= kq[j];
                             rowacc[pi] += e;
                         }
+                    }
+                    if (ST) {
+                        const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (ct.row0 + 64 * wc + 32 * qi) >> 5;
+                        *reinterpret_cast<f32x4*>(stash + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = ev;
                     }
                 }
             }

@@ -1,0 +1,120 @@
+// crossclr_kernels_saved32.h -- the exact-fp32 backward that does not recompute the similarity product.
+//
+// compute_mode="fp32" runs the generic tiled kernels; their backward (bwd_kernel) re-evaluates S = X X^T for every 64 x 64 tile
+// and every slice of D before it can form the weights: 24 B^2 D executed for 8 B^2 D of gradient products.  Here the forward
+// (fwd_sums_kernel<float, SW, 0, true>) leaves its fp32 exponentials behind -- the analogue of the [B, 2B] float64 tensors
+// autograd keeps for the reference (trainer/loss.py:96-100, 59-60), 1/12 of their size -- and the backward is the gradient
+// product alone:   G[p][d] = sum_q  E[p][q] (rz_p + rz_q)  X[q][d]            (v_mfma_f32_32x32x2_f32).
+//
+//   block = 64 rows x DC embedding columns, 4 waves as (32-row half) x (DC/2 column half); 32-column tiles of the stacked operand
+//   * the E fragment of (rows, tile) comes from the stash in the register layout the forward's MFMA left it in (16 bytes per lane,
+//     coalesced) -- which IS the A-operand layout of the gradient product (lane = row p, k-slot = column q): W never touches LDS;
+//   * the [32][DC] slice of X arrives by buffer-addressed LDS-DMA, two stages, one DMA-preserving barrier per tile;
+//   * the loads of tile t+1 (E, statistics, X slice) are issued before the 64 MFMAs of tile t;
+//   * 2 blocks per CU (<= 80 KiB of LDS, <= 256 registers): the other block's MFMAs cover this block's weight arithmetic.
+// Local block only (rows and columns are the same operand); blocks of other ranks keep the recomputing kernel.
+#pragma once
+
+namespace crossclr {
+
+template <int DC, bool SW>
+__global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, const float* stash, Geo g, const float* rz, const float* wrz,
+                                                             float* gbuf, int accumulate, int tiles_per_slice, const float* k) {
+    constexpr int QT = 32;
+    constexpr int STG = QT * DC * 4;          // bytes per stage: [32][DC] floats, rows contiguous
+    constexpr int NR = DC / 32;               // DMA rounds per tile: 256 threads x 16 B = 4 KiB each
+    constexpr int NDT = DC / 64;              // 32-column output fragments per wave
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * STG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int row0 = blockIdx.x * 64, d0 = blockIdx.y * DC;
+    const int rmod = row0 / g.bpad;
+    const int NQ = 2 * g.bpad / QT;
+    const int t_begin = blockIdx.z * tiles_per_slice;
+    int t_stop = t_begin + tiles_per_slice;
+    if (t_stop > NQ) t_stop = NQ;
+
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+    const int p = row0 + 32 * wr + l31;                     // this lane's row of the stacked operand
+    const float rzp_inter = rz[p], rzp_intra = wrz[p];
+    const float kp = SW ? k[p] : 1.f;
+    const size_t pitch = (size_t)g.Dpad * 4;
+    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * pitch));
+    unsigned voff[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int L = (4 * r + wave) * 1024 + lane * 16;   // LDS byte this lane fills in round r
+        const int q = L / (DC * 4), byte = L - q * (DC * 4);
+        voff[r] = (unsigned)((size_t)q * pitch + (size_t)d0 * 4 + byte);
+    }
+    auto issue_x = [&](int t, int stage) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            lds_dma16_buf(rs_x, voff[r], (unsigned)((size_t)t * QT * pitch), lds + stage * STG + (4 * r + wave) * 1024);
+    };
+    // fragment (p32, t) of the stash: [r4][lane][4]
+    const float* frag_row0 = stash + (((size_t)(row0 / 32 + wr) * (size_t)NQ) << 10) + 4 * lane;
+    f32x4 e[4], rq[4], kq[4];
+    auto fetch = [&](int t) {
+        const bool same = (t * QT >= g.bpad) == (rmod == 1);
+        const float* stat = (same ? wrz : rz) + t * QT + 4 * half;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            e[r4] = *reinterpret_cast<const f32x4*>(frag_row0 + ((size_t)t << 10) + 256 * r4);
+            rq[r4] = *reinterpret_cast<const f32x4*>(stat + 8 * r4);
+            if (SW) kq[r4] = *reinterpret_cast<const f32x4*>(k + t * QT + 4 * half + 8 * r4);
+        }
+    };
+    if (t_begin < t_stop) { issue_x(t_begin, 0); fetch(t_begin); }
+    int stage = 0;
+    for (int t = t_begin; t < t_stop; ++t) {
+        wait_dma();                 // X slice of tile t (own pieces) and the E / statistics registers of tile t
+        barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1's stage
+        // weights of tile t: W[p][q] = E (rz_p + rz_q); sample weights: E (rz_p k_q + rz_q k_p) inside a modality
+        const bool same = (t * QT >= g.bpad) == (rmod == 1);
+        const float rzp = same ? rzp_intra : rzp_inter;
+        float w[16];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[4 * r4 + j] = (SW && same) ? e[r4][j] * (rzp * kq[r4][j] + rq[r4][j] * kp) : e[r4][j] * (rzp + rq[r4][j]);
+        if (t + 1 < t_stop) { issue_x(t + 1, stage ^ 1); fetch(t + 1); }
+        // G[p][d] += W[p][q] X[q][d]: k-slot `half` of step (kk, j) is column q = 8 kk + 4 half + j -- the fragment's own order
+        const unsigned char* xs = lds + stage * STG + ((4 * half) * DC + wc * (DC / 2) + l31) * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const float bv = *reinterpret_cast<const float*>(xs + ((8 * kk + j) * DC + 32 * dt) * 4);
+                    acc[dt] = mfma_32x32x2_f32(w[4 * kk + j], bv, acc[dt]);
+                }
+        stage ^= 1;
+    }
+    wait_dma();
+    float* gslice = gbuf + (size_t)blockIdx.z * 2 * g.bpad * g.Dpad;
+    if (accumulate) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] += acc[dt][r];
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] = acc[dt][r];
+    }
+}
+
+}  // namespace crossclr

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     // keeps the VMEM count per iteration constant and the k-step chain free of branches)
 #ifndef CROSSCLR_YABL
 #define CROSSCLR_YABL 0   // timing ablations of this kernel (WRONG results): bit0 every block streams the same 64 column tiles (L2-resident),
-                          // bit1 no stash stores, bit2 no column-sum butterfly, bit3 plain epilogue for every tile (no overlap), bit4 no DMA
+                          // bit1 no stash stores, bit2 no column-sum butterfly, bit3 plain epilogue for every tile (no overlap), bit4 no DMA,
+                          // bit5 no epilogue at all, bit6 no barrier
 #endif
     const int mt_last = col_segs * per_rank - 1;
     auto tile_of = [&](const Cursor& c) { return (CROSSCLR_YABL & 1) ? (c.mt & 63) : (c.mt < mt_last ? (c.mt < 0 ? 0 : c.mt) : mt_last); };
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             wait_loads_visible();   // here, once per row block -- not as vmcnt countdowns inside every tile's MFMA stream
         }
         wait_dma_keep<(NST - 2) * NOPS>();   // tile w has landed (the NST-2 tiles issued after it may still be in flight) ...
-        barrier_keep_dma();                  // ... everywhere; and every wave is done with tile w-1's stage
+        if (!(CROSSCLR_YABL & 64)) barrier_keep_dma();   // ... everywhere; and every wave is done with tile w-1's stage
         if (pending) { flush(); pending = false; }
         const int rstage = (stage + NST - 1) % NST;
         const auto xa = lds_addr(lds + stage * TILE);
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             if (KIND != 1) { crank = g.col_rank0 + cq[0].seg; if (g.col_wrap > 0 && crank >= g.col_wrap) crank -= g.col_wrap; }
             const int r0 = row0w - rmod * g.bpad;       // the wave's first row inside its modality
             const bool selfpairs = KIND != 1 && crank == g.row_rank && cmod == rmod && (in_mod0 == r0 || in_mod0 == r0 + 32);
-            prev.valid = true;
+            prev.valid = !(CROSSCLR_YABL & 32);
             // fast = nothing to mask: KIND 1 tiles of the diagonal block (j < TPR) hold the self pairs; padding rows only matter
             // where column sums are formed
             prev.fast = !SW && !ragged && !(colsum && padrows) && !(KIND == 1 && !colsum) && !selfpairs && !(CROSSCLR_YABL & 8);

@@ -244,7 +244,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # With a backward to follow, the remote blocks this rank evaluates itself (pair partners, antipodal rank; at 2 ranks: the
     # other rank) save their exponentials as well: the backward then recomputes only the blocks the OTHER ranks evaluated.
     ws.saved_blocks, ws.recompute_ranges = None, None
-    save_remote = (sharded and world >= 2 and ws.stash is not None and (use_pairs or world == 2) and
+    save_remote = (sharded and world >= 2 and ws.stash is not None and plan.fast_path == 1 and (use_pairs or world == 2) and
                    os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1")
     if save_remote:
         gather.wait()

@@ -224,3 +224,34 @@ def test_prenormalized_inputs_skip_the_normalisation_and_chain_through_autograd(
     crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.8, compute_mode="fp32", prenormalized=True)
     assert abs(crit(torch.nn.functional.normalize(v, dim=1), torch.nn.functional.normalize(t, dim=1)).item() -
                float(orc.streaming_stats(v, t, 0.05, 0.8)["loss"])) <= 1e-5
+
+
+@pytest.mark.parametrize("B,D,weighted", [(70, 100, False), (40, 200, False), (70, 24, True), (33, 130, True)])
+def test_fp32_saved_exponentials_backward_equals_the_recomputing_one(B, D, weighted, monkeypatch):
+    """compute_mode="fp32": the forward leaves its fp32 exponentials behind (plan.stash_bytes) and bwd_saved32_kernel forms
+    the gradient product from them; CROSSCLR_DISABLE_SAVE=1 is the recomputing bwd_kernel.  Same weights, same products:
+    agreement to fp32 rounding, for every slice width of D (64 / 128 / 256) and with per-sample weights."""
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_FP32).stash_bytes == (2 * nat.make_plan(B, D, 1, 0, nat.MODE_FP32).bpad) ** 2 * 4
+    v, t = orc.make_inputs("randn", B, D, 11)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(3)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="fp32", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    ls, gvs, gts = step()
+    monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_FP32).stash_bytes == 0
+    lr, gvr, gtr = step()
+    assert abs(ls - lr) <= 1e-6 * max(1.0, abs(lr))
+    scale = max(gvr.abs().max().item(), gtr.abs().max().item())
+    assert (gvs - gvr).abs().max().item() <= 2e-6 * scale
+    assert (gts - gtr).abs().max().item() <= 2e-6 * scale
+    if not weighted:
+        ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.8)
+        assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 2e-5 * scale
