@@ -848,7 +848,11 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
 // (tile (r32, item j) at (r32 * NT + j) * 2 KiB, always "direct"), the columns are the usable tiles of the column operand
 // (one rank skipped, or ranks col_rank0.. modulo col_wrap of the whole gathered operand), their statistics come from the
 // gathered arrays; everything else is shared.
-template <int DK, bool SW, bool RECT>
+// XP / TPRF (512 < Dpad <= 1024): the gradient product is independent per embedding column, so a wide operand is handled as
+// XP = 2 column parts of DK*16 each (blockIdx.z = part; row pitch XP * RB in memory, the LDS tile holds the part only; the
+// saved exponentials are read once per part); TPRF = 32-row groups per row block of the forward that wrote the stash
+// (8 for the pipelined 4 x 64-row forward, 4 for the 4 x 32-row forward of wide operands).
+template <int DK, bool SW, bool RECT, int XP = 1, int TPRF = 8>
 __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
                                                                 const float* rz, const float* wrz,
                                                                 const float* rz_cols, const float* wrz_cols, float* gbuf,
@@ -857,7 +861,8 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     constexpr int RB = DK * 32;
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
-    constexpr int TPR = 8;                 // 32-row groups per row block of the forward that wrote the stash (Dpad <= 512)
+    constexpr int TPR = TPRF;
+    constexpr int RBG = XP * RB;           // bytes per operand row in memory
 #ifndef CROSSCLR_NSX
 #define CROSSCLR_NSX 3
 #endif
@@ -908,13 +913,14 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
                          8 * (piece & 1);
     // column-tile DMA: piece k of this wave fills LDS bytes [(wave + 4k) KiB, +1 KiB) of the stage; lane -> (row, swizzled slot)
     const int col_segs = !RECT ? 1 : (g.col_wrap > 0 ? g.col_wrap : g.col_ranks);   // rank segments the column operand holds
-    const BufRsrc rs_x = make_rsrc(cols, (unsigned)((size_t)col_segs * 2 * g.bpad * RB));
+    const BufRsrc rs_x = make_rsrc(cols, (unsigned)((size_t)col_segs * 2 * g.bpad * RBG));
+    const int part = XP > 1 ? (int)blockIdx.z : 0;
     unsigned voffx[NXO];
 #pragma unroll
     for (int k = 0; k < NXO; ++k) {
         const int L = (wave + 4 * k) * 1024 + lane * 16;
         const int row = L / RB, slot = (L - row * RB) >> 4;
-        voffx[k] = (unsigned)(row * RB + (swz_slot(slot, row) << 4));
+        voffx[k] = (unsigned)(row * RBG + part * RB + (swz_slot(slot, row) << 4));
     }
     // saved-exponential tile.  direct: the 2-KiB fragment image as stored, lane-linear.  transposed: 16-byte chunk
     // (th_s, hf, rho) of stash tile (t, r32) [row rho = a column q of ours, chunk = 8 of OUR rows] goes to LDS slot
@@ -968,7 +974,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     auto col_mod = [&](const Col& c) { return c.in_seg >= per_mod ? 1 : 0; };
     auto issue_x_piece = [&](const Col& c, int stage, int k) {
         if (CROSSCLR_SABL & 2) return;
-        lds_dma16_buf(rs_x, voffx[k], (unsigned)c.mt * (unsigned)TILE, lds + stage * TILE + (wave + 4 * k) * 1024);
+        lds_dma16_buf(rs_x, voffx[k], (unsigned)c.mt * (unsigned)(QT * RBG), lds + stage * TILE + (wave + 4 * k) * 1024);
     };
     auto issue_e = [&](const Col& c, int estage) {      // 2 pieces of the saved exponentials + the tile's statistics
         if (CROSSCLR_SABL & 1) return;
@@ -1132,17 +1138,17 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
         se = se_next;
     }
     wait_dma();   // the re-fetches past the end must not outlive the block's LDS
-    float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (DK * 16);
+    float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (XP * DK * 16) + part * (DK * 16);
     if (accumulate) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31] += acc2[dt][r];
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31] += acc2[dt][r];
     } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (DK * 16) + 32 * dt + l31] = acc2[dt][r];
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31] = acc2[dt][r];
     }
 }
 
@@ -1405,13 +1411,27 @@ static inline int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
         else if (kind == 2) CROSSCLR_LP2(DK, 2);         \
         else CROSSCLR_LP2(DK, 3);                        \
     } while (0)
+#define CROSSCLR_LPW2(DK, SW, ST) \
+    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, 1, SW, ST, 1>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st)
+#define CROSSCLR_LPW(DK)                                      \
+    do {                                                       \
+        if (kind != 1) return CROSSCLR_E_ARG;                  \
+        if (sw && st) CROSSCLR_LPW2(DK, true, true);           \
+        else if (sw) CROSSCLR_LPW2(DK, true, false);           \
+        else if (st) CROSSCLR_LPW2(DK, false, true);           \
+        else CROSSCLR_LPW2(DK, false, false);                  \
+    } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LP(8); break;
         case 256: CROSSCLR_LP(16); break;
         case 384: CROSSCLR_LP(24); break;
         case 512: CROSSCLR_LP(32); break;
+        case 768: CROSSCLR_LPW(48); break;     // wide operands: one 32-row half per wave, symmetric launch only
+        case 1024: CROSSCLR_LPW(64); break;
         default: return CROSSCLR_E_ARG;
     }
+#undef CROSSCLR_LPW
+#undef CROSSCLR_LPW2
 #undef CROSSCLR_LP
 #undef CROSSCLR_LP2
 #undef CROSSCLR_LP3
@@ -1429,7 +1449,8 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     dim3 grid(wk.nblk);
     const bool sw = krows != nullptr && kcols != nullptr;
     static const bool old_fwd = getenv("CROSSCLR_FWD_KERNEL") && !strcmp(getenv("CROSSCLR_FWD_KERNEL"), "8wave");   // A/B knob
-    if (p->Dpad <= 512 && !old_fwd)   // software-pipelined 4-wave kernel (crossclr_kernels_sym.h): symmetric, rectangular and pairs
+    // software-pipelined 4-wave kernel (crossclr_kernels_sym.h): symmetric, rectangular and pairs (wide operands: symmetric only)
+    if ((p->Dpad <= 512 || (p->Dpad <= 1024 && symmetric)) && !old_fwd)
         return fast_forward_pipe(p, g, wk, rows, cols, part, colpart, header, symmetric ? 1 : (pairs ? 3 : 2), krows, kcols, nullptr, stream);
 #define CROSSCLR_LF2(DK, NW, SYM, SW) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW, false>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols, (unsigned char*)nullptr)
@@ -1458,7 +1479,7 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
 
 // the saved-exponentials pair (symmetric local block, Dpad <= 512): bytes of the stash, forward that fills it, backward that reads it
 static inline size_t fast_stash_bytes(int bpad, int Dpad) {
-    return Dpad <= 512 ? stash_tiles_total(8, 2 * bpad / 32) * 2048 : 0;
+    return Dpad <= 512 ? stash_tiles_total(8, 2 * bpad / 32) * 2048 : (Dpad <= 1024 ? stash_tiles_total(4, 2 * bpad / 32) * 2048 : 0);
 }
 // bytes of the stash of a rectangular (remote / pairs) launch over `nranks` column ranks
 static inline size_t fast_stash_bytes_rect(int bpad, int Dpad, int nranks) {
@@ -1481,6 +1502,22 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
     const bf16_t* c = (const bf16_t*)cols;
     const unsigned char* st = (const unsigned char*)stash;
+    if (p->Dpad > 512) {   // two column parts of Dpad/2 (local block only)
+        if (rect) return CROSSCLR_E_ARG;
+        dim3 grid2(2 * p->bpad / 128, p->bwd_slices, 2);
+#define CROSSCLR_LBW(DK)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, true, false, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);   \
+        else CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, false, false, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);     \
+    } while (0)
+        switch (p->Dpad) {
+            case 768: CROSSCLR_LBW(24); break;
+            case 1024: CROSSCLR_LBW(32); break;
+            default: return CROSSCLR_E_ARG;
+        }
+#undef CROSSCLR_LBW
+        return CROSSCLR_OK;
+    }
 #define CROSSCLR_LBS2(DK, SW, RECT) \
     CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, SW, RECT>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
 #define CROSSCLR_LBS(DK)                                                              \

@@ -21,7 +21,9 @@
 
 namespace crossclr {
 
-template <int DK, int KIND, bool SW, bool ST>
+// NH = 32-row halves per wave: 2 for Dpad <= 512 (256-row blocks); 1 for 512 < Dpad <= 1024 (the fragments of 64 rows would
+// not fit the register file: 128-row blocks, one MFMA per LDS read, a 2-deep tile ring of 64-KiB tiles).
+template <int DK, int KIND, bool SW, bool ST, int NH = 2>
 __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, const bf16_t* xc, Geo g, FwdWork wk, float* part,
                                                                float* colpart, int* header, const float* ks, const float* kc,
                                                                unsigned char* stash) {
@@ -29,13 +31,17 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     constexpr int RB = DK * 32;            // bytes per operand row
     constexpr int QT = 32;
     constexpr int TILE = QT * RB;
-    constexpr int TPR = 8;                 // 32-row groups per row block (the workspace / stash layout of the 8-wave kernel)
-    constexpr int NST = (4 * TILE + 4096 <= 160 * 1024) ? 4 : 3;
+    constexpr int TPR = 4 * NH;            // 32-row groups per row block (the workspace / stash layout)
+    constexpr int RW = 32 * NH;            // rows per wave
+    constexpr int RBLK = 4 * RW;           // rows per block
+    constexpr int NE = 16 * NH;            // exponentials per lane and tile
+    constexpr int NST = (4 * TILE + 4096 <= 160 * 1024) ? 4 : ((3 * TILE + 4096 <= 160 * 1024) ? 3 : 2);
     constexpr int NXO = DK / 4;            // DMA pieces per wave and tile
     constexpr int PF = 4;                  // A-fragment reads in flight ahead of their MFMA pair
     constexpr int CS0 = NST * TILE;        // two column-sum slots [4 waves][32] floats
     constexpr int KQ0 = CS0 + 2 * 4 * QT * 4;
-    static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512}");
+    static_assert(NH == 1 || NH == 2, "one or two 32-row halves per wave");
+    static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32 * (3 - NH), "Dpad in {128, 256, 384, 512}; NH = 1: up to 1024");
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[KQ0 + (SW ? NST * 256 : 0)];   // k_q ring: 64 lanes x 4 B per stage (32 used)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
@@ -132,12 +138,14 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     float* cs = reinterpret_cast<float*>(lds + CS0);
     // ---- per-row-block state ----
     int my_rb = -1, row0w = 0, rmod = 0;
-    float rowacc[2] = {0.f, 0.f}, kp[2] = {1.f, 1.f};
-    size_t st0[2] = {0, 0};                // ST: stash index of tile j = 0 of the current row block, per 32-row half
-    bf16x8 pf[2][DK];
+    float rowacc[NH], kp[NH];
+    size_t st0[NH];                        // ST: stash index of tile j = 0 of the current row block, per 32-row half
+#pragma unroll
+    for (int s = 0; s < NH; ++s) { rowacc[s] = 0.f; kp[s] = 1.f; st0[s] = 0; }
+    bf16x8 pf[NH][DK];
     auto store_rows = [&]() {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NH; ++s) {
             const float v = rowacc[s] + wave_xor_f32(rowacc[s], 32);
             if (half == 0) part[(size_t)(blockIdx.x - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + 32 * s + l31] = v;
         }
@@ -145,7 +153,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     // ---- the tile whose epilogue is still owed ----
     struct Prev { bool valid, fast; int j, cmod, in_mod0, stage, crank; };   // (the owed tile always belongs to the current row block)
     Prev prev = {false, false, 0, 0, 0, 0, 0};
-    f32x16 pacc[2];
+    f32x16 pacc[NH];
     // ---- column sums waiting for the next barrier ----
     bool pending = false;
     int ptile = 0, pbuf = 0, prb = 0;
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
         prb = my_rb;
     };
     // general (masked / weighted) epilogue of one tile, not overlapped with anything
-    auto epilogue_plain = [&](f32x16 (&acc)[2], const Prev& pv) {
+    auto epilogue_plain = [&](f32x16 (&acc)[NH], const Prev& pv) {
         const bool same_mod = pv.cmod == rmod;
         const float c2s = same_mod ? g.c_intra : g.c_inter;
         const bool upper = wants_colsum(pv.j);
@@ -187,7 +195,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) es[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NH; ++s) {
             const int r_in_mod = row0w + 32 * s - rmod * g.bpad + l31;
             float xx[16];
 #pragma unroll
@@ -198,7 +206,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
                     if (pv.in_mod0 + frag_row(r, half) >= g.b) xx[r] = ninf;
             }
             // the tile that holds this half's self pairs: KIND 1 t == r32; a rectangular launch that includes the rows' own rank
-            const bool diag_here = KIND == 1 ? (pv.j == 2 * wave + s)
+            const bool diag_here = KIND == 1 ? (pv.j == NH * wave + s)
                                              : (pv.crank == g.row_rank && same_mod && pv.in_mod0 == row0w + 32 * s - rmod * g.bpad);
             if (diag_here) {
 #pragma unroll
@@ -244,14 +252,15 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             }
             if (my_rb >= 0) store_rows();
             my_rb = cq[0].rb;
-            rowacc[0] = rowacc[1] = 0.f;
-            row0w = my_rb * 256 + 64 * wave;
+#pragma unroll
+            for (int s = 0; s < NH; ++s) rowacc[s] = 0.f;
+            row0w = my_rb * RBLK + RW * wave;
             rmod = row0w / g.bpad;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NH; ++s) {
                 if (SW) kp[s] = ks[row0w + 32 * s + l31];
-                if (ST) st0[s] = KIND == 1 ? stash_tile_index(TPR, NT, TPR * my_rb + 2 * wave + s, TPR * my_rb)
-                                           : (size_t)(TPR * my_rb + 2 * wave + s) * (size_t)NT;
+                if (ST) st0[s] = KIND == 1 ? stash_tile_index(TPR, NT, TPR * my_rb + NH * wave + s, TPR * my_rb)
+                                           : (size_t)(TPR * my_rb + NH * wave + s) * (size_t)NT;
                 const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * 16) + 8 * half;
 #pragma unroll
                 for (int k = 0; k < DK; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
@@ -267,9 +276,9 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) abase[j] = xa + off8[j];
 
-        f32x16 acc[2];
+        f32x16 acc[NH];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < NH; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
         u32x4 ring[PF];
@@ -284,7 +293,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             wait_lgkm<later>(ring[k % PF]);
             const bf16x8 a = __builtin_bit_cast(bf16x8, ring[k % PF]);
             acc[0] = mfma_32x32x16_bf16(a, pf[0][k], acc[0]);
-            acc[1] = mfma_32x32x16_bf16(a, pf[1][k], acc[1]);
+            if constexpr (NH == 2) acc[1] = mfma_32x32x16_bf16(a, pf[NH - 1][k], acc[NH - 1]);
             if constexpr (k + PF < DK) fetch(IdxC<k + PF>{});
             if constexpr (k < NXO) issue_piece(cq[NST - 1], rstage, k);
             if constexpr (k == NXO) issue_stat(cq[NST - 1], rstage);
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
         if (prev.valid && prev.fast) {
             // ---- pipelined: the owed tile is unmasked and unweighted (and, KIND 1, strictly right of the diagonal block) ----
             const float c2s = (prev.cmod == rmod) ? g.c_intra : g.c_inter;
-            float e[2][16], es[16], k8[8], k4[4], k2[2];
+            float e[NH][16], es[16], k8[8], k4[4], k2[2];
             // chore plan over the DK k-steps:
             //   steps [0, DK/2): scale + exp2 + row sum of the 32 elements
             //   steps [DK/2, 3DK/4): es = e0 + e1 (16), bf16 pack + stash stores (4 fragments)
@@ -307,21 +316,21 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
                 kstep(ic);
                 if constexpr (k < S1) {
 #pragma unroll
-                    for (int idx = (32 * k) / S1; idx < (32 * (k + 1)) / S1; ++idx) {
+                    for (int idx = (NE * k) / S1; idx < (NE * (k + 1)) / S1; ++idx) {
                         const int s = idx >> 4, r = idx & 15;
                         const float v = fast_exp2(pacc[s][r] * c2s - g.m2);
                         e[s][r] = v;
                         rowacc[s] += v;
                     }
                 } else if constexpr (k < S2) {
-                    constexpr int n = S2 - S1, i = k - S1;         // n steps: 16 sums and 4 fragments
+                    constexpr int n = S2 - S1, i = k - S1;         // n steps: 16 sums and 2 NH fragments
                     if (KIND != 2) {
 #pragma unroll
-                        for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = e[0][r] + e[1][r];
+                        for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = NH == 2 ? e[0][r] + e[NH - 1][r] : e[0][r];
                     }
                     if (ST && !(CROSSCLR_YABL & 2)) {
 #pragma unroll
-                        for (int f = (4 * i) / n; f < (4 * (i + 1)) / n; ++f) {
+                        for (int f = (2 * NH * i) / n; f < (2 * NH * (i + 1)) / n; ++f) {
                             const int s = f >> 1, th = f & 1;
                             const BufRsrc rs_st = make_rsrc(stash + (st0[s] + (size_t)prev.j) * 2048, 2048u);
                             Bits8 pk;
@@ -372,12 +381,12 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             const int cmod = cq[0].in_seg >= per_mod ? 1 : 0;
             const int in_mod0 = (cq[0].in_seg - cmod * per_mod) * QT;
             const bool ragged = in_mod0 + QT > g.b;
-            const bool padrows = (row0w - rmod * g.bpad) + 64 > g.b;
+            const bool padrows = (row0w - rmod * g.bpad) + RW > g.b;
             const bool colsum = wants_colsum(cq[0].j);
             int crank = g.row_rank;
             if (KIND != 1) { crank = g.col_rank0 + cq[0].seg; if (g.col_wrap > 0 && crank >= g.col_wrap) crank -= g.col_wrap; }
             const int r0 = row0w - rmod * g.bpad;       // the wave's first row inside its modality
-            const bool selfpairs = KIND != 1 && crank == g.row_rank && cmod == rmod && (in_mod0 == r0 || in_mod0 == r0 + 32);
+            const bool selfpairs = KIND != 1 && crank == g.row_rank && cmod == rmod && (in_mod0 == r0 || (NH == 2 && in_mod0 == r0 + 32));
             prev.valid = !(CROSSCLR_YABL & 32);
             // fast = nothing to mask: KIND 1 tiles of the diagonal block (j < TPR) hold the self pairs; padding rows only matter
             // where column sums are formed
@@ -387,8 +396,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             prev.cmod = cmod;
             prev.in_mod0 = in_mod0;
             prev.stage = stage;
-            pacc[0] = acc[0];
-            pacc[1] = acc[1];
+#pragma unroll
+            for (int s = 0; s < NH; ++s) pacc[s] = acc[s];
         }
         if (SW) {   // weighted tiles read their k_q from the tile's ring stage: finish them before the stage is refilled
             epilogue_plain(pacc, prev);

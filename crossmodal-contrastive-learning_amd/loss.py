@@ -245,6 +245,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # other rank) save their exponentials as well: the backward then recomputes only the blocks the OTHER ranks evaluated.
     ws.saved_blocks, ws.recompute_ranges = None, None
     save_remote = (sharded and world >= 2 and ws.stash is not None and plan.fast_path == 1 and (use_pairs or world == 2) and
+                   lib.crossclr_rect_stash_bytes(pp, 1) > 0 and   # (wide operands, 512 < D <= 1024, save the local block only)
                    os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1")
     if save_remote:
         gather.wait()

@@ -255,3 +255,35 @@ def test_fp32_saved_exponentials_backward_equals_the_recomputing_one(B, D, weigh
     if not weighted:
         ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.8)
         assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("B,D,weighted", [(70, 600, False), (150, 1000, False), (40, 530, True)])
+def test_wide_operands_take_the_saved_backward_in_two_column_parts(B, D, weighted, monkeypatch):
+    """512 < D <= 1024 (bf16): the 4 x 32-row forward saves its exponentials (row blocks of 128: stash_tile_index with tpr = 4)
+    and fast_bwd_saved_kernel<DK, SW, false, 2, 4> forms the gradient in two column parts of Dpad/2."""
+    plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
+    assert plan.fast_path == 1 and plan.Dpad in (768, 1024) and plan.stash_bytes > 0
+    v, t = orc.make_inputs("randn", B, D, 23)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(5)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    ls, gvs, gts = step()
+    monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).stash_bytes == 0
+    lr, gvr, gtr = step()
+    assert abs(ls - lr) <= 1e-6 * max(1.0, abs(lr))
+    scale = max(gvr.abs().max().item(), gtr.abs().max().item())
+    assert (gvs - gvr).abs().max().item() <= 1e-2 * scale      # bf16 exponentials vs recomputed fp32 ones
+    assert (gts - gtr).abs().max().item() <= 1e-2 * scale
+    if not weighted:
+        ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.8)
+        assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 2e-2 * scale
+        assert (gts.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
