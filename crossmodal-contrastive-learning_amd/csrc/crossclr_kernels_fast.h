@@ -1139,11 +1139,17 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
     }
     wait_dma();   // the re-fetches past the end must not outlive the block's LDS
     float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (XP * DK * 16) + part * (DK * 16);
-    if (accumulate) {
+    if (accumulate) {   // 16 loads in flight, then 16 add + store (a plain += chain waits for every load on its own)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) {
+            float o[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31] += acc2[dt][r];
+            for (int r = 0; r < 16; ++r) o[r] = gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31];
+            sched_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31] = o[r] + acc2[dt][r];
+            sched_fence();
+        }
     } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -1347,12 +1353,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
         stage = (stage + 1) % NST;
     }
     float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * DP;
-    if (accumulate) {
+    if (accumulate) {   // 16 loads in flight, then add + store
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds) {
+        for (int d4 = 0; d4 < DS; d4 += 4) {
+            float o[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gslice[(size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16] += acc2[ds][r];
-            if ((ds & 3) == 3) sched_fence();
+            for (int ds = d4; ds < d4 + 4; ++ds)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[ds - d4][r] = gslice[(size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16];
+            sched_fence();
+#pragma unroll
+            for (int ds = d4; ds < d4 + 4; ++ds)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gslice[(size_t)(row0w + 4 * g4 + r) * DP + 16 * ds + i16] = o[ds - d4][r] + acc2[ds][r];
+            sched_fence();
         }
     } else {
 #pragma unroll
@@ -1411,27 +1425,33 @@ static inline int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
         else if (kind == 2) CROSSCLR_LP2(DK, 2);         \
         else CROSSCLR_LP2(DK, 3);                        \
     } while (0)
-#define CROSSCLR_LPW2(DK, SW, ST) \
-    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, 1, SW, ST, 1>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st)
-#define CROSSCLR_LPW(DK)                                      \
-    do {                                                       \
-        if (kind != 1) return CROSSCLR_E_ARG;                  \
-        if (sw && st) CROSSCLR_LPW2(DK, true, true);           \
-        else if (sw) CROSSCLR_LPW2(DK, true, false);           \
-        else if (st) CROSSCLR_LPW2(DK, false, true);           \
-        else CROSSCLR_LPW2(DK, false, false);                  \
+#define CROSSCLR_LPW3(DK, KIND, SW, ST) \
+    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST, 1>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st)
+#define CROSSCLR_LPW2(DK, KIND)                                   \
+    do {                                                           \
+        if (sw && st) CROSSCLR_LPW3(DK, KIND, true, true);         \
+        else if (sw) CROSSCLR_LPW3(DK, KIND, true, false);         \
+        else if (st) CROSSCLR_LPW3(DK, KIND, false, true);         \
+        else CROSSCLR_LPW3(DK, KIND, false, false);                \
+    } while (0)
+#define CROSSCLR_LPW(DK)                                 \
+    do {                                                  \
+        if (kind == 1) CROSSCLR_LPW2(DK, 1);              \
+        else if (kind == 2) CROSSCLR_LPW2(DK, 2);         \
+        else CROSSCLR_LPW2(DK, 3);                        \
     } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LP(8); break;
         case 256: CROSSCLR_LP(16); break;
         case 384: CROSSCLR_LP(24); break;
         case 512: CROSSCLR_LP(32); break;
-        case 768: CROSSCLR_LPW(48); break;     // wide operands: one 32-row half per wave, symmetric launch only
+        case 768: CROSSCLR_LPW(48); break;     // wide operands: one 32-row half per wave
         case 1024: CROSSCLR_LPW(64); break;
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_LPW
 #undef CROSSCLR_LPW2
+#undef CROSSCLR_LPW3
 #undef CROSSCLR_LP
 #undef CROSSCLR_LP2
 #undef CROSSCLR_LP3
@@ -1449,8 +1469,8 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     dim3 grid(wk.nblk);
     const bool sw = krows != nullptr && kcols != nullptr;
     static const bool old_fwd = getenv("CROSSCLR_FWD_KERNEL") && !strcmp(getenv("CROSSCLR_FWD_KERNEL"), "8wave");   // A/B knob
-    // software-pipelined 4-wave kernel (crossclr_kernels_sym.h): symmetric, rectangular and pairs (wide operands: symmetric only)
-    if ((p->Dpad <= 512 || (p->Dpad <= 1024 && symmetric)) && !old_fwd)
+    // software-pipelined 4-wave kernel (crossclr_kernels_sym.h): symmetric, rectangular and pairs
+    if (p->Dpad <= 1024 && !old_fwd)
         return fast_forward_pipe(p, g, wk, rows, cols, part, colpart, header, symmetric ? 1 : (pairs ? 3 : 2), krows, kcols, nullptr, stream);
 #define CROSSCLR_LF2(DK, NW, SYM, SW) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW, false>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols, (unsigned char*)nullptr)
@@ -1483,7 +1503,7 @@ static inline size_t fast_stash_bytes(int bpad, int Dpad) {
 }
 // bytes of the stash of a rectangular (remote / pairs) launch over `nranks` column ranks
 static inline size_t fast_stash_bytes_rect(int bpad, int Dpad, int nranks) {
-    return Dpad <= 512 ? (size_t)(2 * bpad / 32) * (size_t)(2 * bpad / 32) * (size_t)nranks * 2048 : 0;
+    return Dpad <= 1024 ? (size_t)(2 * bpad / 32) * (size_t)(2 * bpad / 32) * (size_t)nranks * 2048 : 0;
 }
 static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const void* x, float* part, float* colpart,
                                     int* header, const float* ks, void* stash, void* stream) {
@@ -1502,13 +1522,14 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
     const bf16_t* c = (const bf16_t*)cols;
     const unsigned char* st = (const unsigned char*)stash;
-    if (p->Dpad > 512) {   // two column parts of Dpad/2 (local block only)
-        if (rect) return CROSSCLR_E_ARG;
+    if (p->Dpad > 512) {   // two column parts of Dpad/2
         dim3 grid2(2 * p->bpad / 128, p->bwd_slices, 2);
-#define CROSSCLR_LBW(DK)                                                                                                                  \
-    do {                                                                                                                                  \
-        if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, true, false, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);   \
-        else CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, false, false, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);     \
+#define CROSSCLR_LBW2(DK, SW, RECT) \
+    CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, SW, RECT, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
+#define CROSSCLR_LBW(DK)                                                                             \
+    do {                                                                                              \
+        if (rect) { if (ks) CROSSCLR_LBW2(DK, true, true); else CROSSCLR_LBW2(DK, false, true); }     \
+        else { if (ks) CROSSCLR_LBW2(DK, true, false); else CROSSCLR_LBW2(DK, false, false); }        \
     } while (0)
         switch (p->Dpad) {
             case 768: CROSSCLR_LBW(24); break;
@@ -1516,6 +1537,7 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
             default: return CROSSCLR_E_ARG;
         }
 #undef CROSSCLR_LBW
+#undef CROSSCLR_LBW2
         return CROSSCLR_OK;
     }
 #define CROSSCLR_LBS2(DK, SW, RECT) \

@@ -59,7 +59,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (5, 20, 16, "bf16", 5e-3, 2e-2),
                                                        # 130 rows per rank: two 256-row blocks each, so the pairs launch and the
                                                        # symmetric local launch both leave column sums behind
-                                                       (3, 390, 16, "bf16", 5e-3, 2e-2)])
+                                                       (3, 390, 16, "bf16", 5e-3, 2e-2),
+                                                       # wide operands (512 < D <= 1024): one 32-row half per wave, 128-row blocks,
+                                                       # the backward in two column parts; pairs + saved remote blocks as well
+                                                       (3, 24, 530, "bf16", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()
