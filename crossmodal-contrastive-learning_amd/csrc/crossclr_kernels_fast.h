@@ -92,6 +92,12 @@ __device__ __forceinline__ void lds_dma4_buf(const BufRsrc& b, unsigned voff, un
 __device__ __forceinline__ void buf_store16(const BufRsrc& b, unsigned voff, unsigned soff, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ void buf_store4(const BufRsrc& b, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float buf_load4(const BufRsrc& b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, 0));
+}
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // s_waitcnt vmcnt(0) as a BUILTIN: unlike the asm form hipcc's wait-count pass sees it and marks its own pending global
 // loads complete -- otherwise it re-waits for them (vmcnt(N) countdowns that also drain the DMA ring) at every later use
@@ -123,6 +129,14 @@ __device__ __forceinline__ void lds_dma4_buf(const BufRsrc& b, unsigned voff, un
 }
 __device__ __forceinline__ void buf_store16(const BufRsrc& b, unsigned voff, unsigned soff, u32x4 v) {
     memcpy(const_cast<unsigned char*>(b.base) + voff + soff, &v, 16);
+}
+__device__ __forceinline__ void buf_store4(const BufRsrc& b, unsigned voff, unsigned soff, float v) {
+    if ((size_t)voff + soff + 4 <= b.bytes) memcpy(const_cast<unsigned char*>(b.base) + voff + soff, &v, 4);
+}
+__device__ __forceinline__ float buf_load4(const BufRsrc& b, unsigned voff, unsigned soff) {
+    float v = 0.f;
+    if ((size_t)voff + soff + 4 <= b.bytes) memcpy(&v, b.base + voff + soff, 4);
+    return v;
 }
 __device__ __forceinline__ void sched_fence() {}
 __device__ __forceinline__ void wait_loads_visible() {}
@@ -1138,23 +1152,29 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
         se = se_next;
     }
     wait_dma();   // the re-fetches past the end must not outlive the block's LDS
-    float* gslice = gbuf + (size_t)blockIdx.y * 2 * g.bpad * (XP * DK * 16) + part * (DK * 16);
-    if (accumulate) {   // 16 loads in flight, then 16 add + store (a plain += chain waits for every load on its own)
+    // G[row][d]: the lane holds column d = 32 dt + l31 of each fragment and 16 rows; buffer addressing (one per-lane offset, the
+    // row / fragment part as a scalar) keeps the 256 stores free of 64-bit per-lane address arithmetic (and of its spills)
+    constexpr unsigned GP = XP * DK * 16 * 4;           // bytes per gradient row
+    const BufRsrc rs_g = make_rsrc(gbuf + (size_t)blockIdx.y * 2 * g.bpad * (XP * DK * 16) + (size_t)row0w * (XP * DK * 16) + part * (DK * 16),
+                                   32u * GP);            // this wave's 32 rows
+    const unsigned vg = (unsigned)((4 * half) * GP + l31 * 4);
+    // accumulate: 16 loads in flight, then 16 add + store (a plain += chain waits for every load on its own).  ONE store path
+    // for both cases, fenced per fragment: with two branches hipcc hoists the copies of all 256 accumulators out of the
+    // AGPRs above the branch, and spills.
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            float o[16];
+    for (int dt = 0; dt < DT; ++dt) {
+        float o[16];
+        if (accumulate) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31];
-            sched_fence();
+            for (int r = 0; r < 16; ++r) o[r] = buf_load4(rs_g, vg, (unsigned)((8 * (r >> 2) + (r & 3)) * GP + 128 * dt));
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31] = o[r] + acc2[dt][r];
-            sched_fence();
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
         }
-    } else {
+        sched_fence();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gslice[(size_t)(row0w + frag_row(r, half)) * (XP * DK * 16) + 32 * dt + l31] = acc2[dt][r];
+        for (int r = 0; r < 16; ++r) buf_store4(rs_g, vg, (unsigned)((8 * (r >> 2) + (r & 3)) * GP + 128 * dt), o[r] + acc2[dt][r]);
+        sched_fence();
     }
 }
 
