@@ -10,6 +10,7 @@ through the `crossclr_amd` alias module at the repository root:
 from . import _native
 from .loss import AUTO_BF16_MIN_GLOBAL_BATCH, CrossCLR_onlyIntraModality, all_gather_with_grad, crossclr_loss
 from .influence import CrossCLR, influential_sample_weights
+from .ranking import MaxMargin_coot, cosine_sim, max_margin_loss, retrieval_ranks
 
 __all__ = ["CrossCLR_onlyIntraModality", "CrossCLR", "crossclr_loss", "all_gather_with_grad", "influential_sample_weights",
-           "AUTO_BF16_MIN_GLOBAL_BATCH", "_native"]
+           "MaxMargin_coot", "max_margin_loss", "cosine_sim", "retrieval_ranks", "AUTO_BF16_MIN_GLOBAL_BATCH", "_native"]

@@ -107,6 +107,12 @@ _SIGNATURES = {
     "crossclr_influence_conn": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                _P, _P, ctypes.c_int, _P, _P]),
     "crossclr_influence_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_float, ctypes.c_float, _P, _P, _P]),
+    # ABI version 3: score statistics of the inter-modal block (max-margin ranking loss, retrieval ranks)
+    "crossclr_score_diag": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P]),
+    "crossclr_score_rows": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P, _P, _P, _P]),
+    "crossclr_maxmargin_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P]),
+    "crossclr_maxmargin_backward_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                                          _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P]),
 }
 INFL_BLOCKS = 256
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

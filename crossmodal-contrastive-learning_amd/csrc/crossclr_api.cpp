@@ -812,6 +812,92 @@ extern "C" int crossclr_backward_finish_p(const crossclr_plan* plan, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// score statistics of the inter-modal block: max-margin ranking loss (trainer/loss.py:17-41) and retrieval ranks
+static int score_geo(const crossclr_plan* p, float margin, Geo* g) {
+    if (!p) return fail(CROSSCLR_E_ARG, "plan is NULL");
+    if (p->world != 1) return fail(CROSSCLR_E_ARG, "score statistics are single-device (plan->world must be 1)");
+    if (!isfinite(margin)) return fail(CROSSCLR_E_ARG, "margin must be finite");
+    memset(g, 0, sizeof(*g));
+    g->b = p->b; g->bpad = p->bpad; g->D = p->D; g->Dpad = p->Dpad;
+    g->col_ranks = 1; g->col_rank0 = 0; g->row_rank = 0; g->skip_rank = -1; g->col_wrap = 0;
+    g->c_inter = 1.f; g->c_intra = 1.f; g->m2 = margin;
+    return CROSSCLR_OK;
+}
+template <typename T>
+static void score_launch(const crossclr_plan* plan, const Geo& g, const void* x, float* out, float* cnt, const float* diag, int mode,
+                         void* stream) {
+    const int ntiles = 2 * plan->bpad / 128;
+    const int nsplit = mode == 4 ? 1 : plan->fwd_slots;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    dim3 grid(2 * plan->bpad / 128, nsplit), block(256);
+    if (mode == 4) LAUNCH((fwd_sums_kernel<T, false, 4>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt);
+    else LAUNCH((fwd_sums_kernel<T, false, 3>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt);
+}
+
+extern "C" int crossclr_score_diag(const crossclr_plan* plan, const void* xhat, float* diag, void* stream) {
+    if (!plan || !xhat || !diag) return fail(CROSSCLR_E_ARG, "NULL argument");
+    Geo g;
+    if (int rc = score_geo(plan, 0.f, &g)) return rc;
+    if (plan->mode == CROSSCLR_MODE_FP32) score_launch<float>(plan, g, xhat, diag, nullptr, nullptr, 4, stream);
+    else score_launch<bf16_t>(plan, g, xhat, diag, nullptr, nullptr, 4, stream);
+    return launch_status("fwd_sums_kernel (positive-pair scores)");
+}
+
+extern "C" int crossclr_score_rows(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
+                                   float* hinge, float* active, double* loss_sum, void* stream) {
+    if (!plan || !xhat || !diag || !part || !hinge || !active || !loss_sum) return fail(CROSSCLR_E_ARG, "NULL argument");
+    Geo g;
+    if (int rc = score_geo(plan, margin, &g)) return rc;
+    if (plan->fwd_slots <= 0) return fail(CROSSCLR_E_ARG, "bad plan");
+    float* cnt = part + (size_t)plan->fwd_slots * 2 * plan->bpad;     // launch group 1 of the forward workspace
+    if (plan->mode == CROSSCLR_MODE_FP32) score_launch<float>(plan, g, xhat, part, cnt, diag, 3, stream);
+    else score_launch<bf16_t>(plan, g, xhat, part, cnt, diag, 3, stream);
+    if (int rc = launch_status("fwd_sums_kernel (score rows)")) return rc;
+    const int nb = plan->loss_ws_doubles - 1;
+    LAUNCH(score_finish_kernel, dim3(nb), dim3(256), stream, (const float*)part, (const float*)cnt, plan->fwd_slots, plan->bpad, plan->b,
+           hinge, active, loss_sum);
+    // loss_sum[0] = sum of the hinges, loss_sum[1] = the reference's mean: / (B * B)   (trainer/loss.py:41)
+    LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb, 1.0 / ((double)plan->b * (double)plan->b));
+    return launch_status("score_finish_kernel");
+}
+
+template <typename T>
+static int maxmargin_backward_t(const crossclr_plan* p, const Geo& g, const void* x, const float* diag, float* gbuf, void* stream) {
+    dim3 block(256);
+    const unsigned rb = 2 * p->bpad / 64, nz = (unsigned)p->bwd_slices;
+    const int ntiles = 2 * p->bpad / 64;
+    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+#define CROSSCLR_LMM(DC) LAUNCH((bwd_kernel<T, DC, false, false, 1>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)x, (const T*)x, g, \
+                                diag, diag, diag, diag, gbuf, 0, tps, (const float*)nullptr, (const float*)nullptr, diag, diag)
+    if (p->Dpad % 256 == 0) CROSSCLR_LMM(256);
+    else if (p->Dpad % 128 == 0) CROSSCLR_LMM(128);
+    else CROSSCLR_LMM(64);
+#undef CROSSCLR_LMM
+    return launch_status("bwd_kernel (max-margin)");
+}
+
+extern "C" int crossclr_maxmargin_backward(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* gbuf,
+                                           void* stream) {
+    if (!plan || !xhat || !diag || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+    Geo g;
+    if (int rc = score_geo(plan, margin, &g)) return rc;
+    if (plan->mode == CROSSCLR_MODE_FP32) return maxmargin_backward_t<float>(plan, g, xhat, diag, gbuf, stream);
+    return maxmargin_backward_t<bf16_t>(plan, g, xhat, diag, gbuf, stream);
+}
+
+extern "C" int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* gbuf, const void* im, const void* s,
+                                                  long ld_im, long ld_s, int in_dtype, const float* ones, const float* active,
+                                                  const double* grad_out, void* grad_im, void* grad_s, long ld_gim, long ld_gs,
+                                                  void* stream) {
+    if (!plan || !ones || !active) return fail(CROSSCLR_E_ARG, "NULL argument");
+    // bwd_finish_kernel with unit rows as given: out = (sum_slices * inv_tau / (2B) - partner * inv_tau / B * (lw_im + lw_s) / 2) * grad_out;
+    // inv_tau = 2 / B and lw = the active-hinge counts make that (sum_slices - (a_im + a_s) partner) / B^2   (loss.py:33-41)
+    crossclr_sample_weights sw = {nullptr, nullptr, active};
+    return crossclr_backward_finish_p(plan, gbuf, im, s, ld_im, ld_s, in_dtype, ones, 0.5f * (float)plan->b, &sw, grad_out, grad_im, grad_s,
+                                      ld_gim, ld_gs, 1, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // influential-sample statistics
 template <typename TIN>
 static int infl_colsum_t(const void* xv, const void* xt, long ldv, long ldt, int b, int Din, float* inv_norm, float* partial,

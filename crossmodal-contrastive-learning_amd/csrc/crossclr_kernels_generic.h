@@ -181,6 +181,12 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 //   stacked [2 bpad] x [2 bpad] matrix at ((p32 * (2 bpad / 32)) + q32) * 4 KiB, inside it [r4][lane][4 floats]: lane
 //   (p = lane & 31, half) holds E[32 p32 + p][32 q32 + 8 r4 + 4 half + j] -- what bwd_saved32_kernel loads back, 16 bytes per
 //   lane, fully coalesced, no transposition anywhere (the generic forward evaluates both triangles).
+//   Score statistics of the inter-modal block (the max-margin ranking loss of trainer/loss.py:29-41
+//   and retrieval ranks), same tiling, no soft-max: the cosines S[p][q] of row p against the OTHER modality's columns,
+//   MODE 4: the slot receives S[p][partner(p)] (the positive pair's cosine, from the very MFMA sequence MODE 3 compares with:
+//           S > S_pp is then exact, a tie with oneself impossible),
+//   MODE 3: hinge sums  sum_q max(0, g.m2 + S[p][q] - shift[p])  over q != partner into `part`, and the number of active
+//           terms (g.m2 + S - shift[p] > 0) into `stash` (same slot layout, as floats); shift = the MODE 4 result, g.m2 = margin.
 template <typename T, bool SW, int MODE, bool ST = false>
 __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
                                                        float* part, const float* kcols, const float* shift, float* stash) {
@@ -210,12 +216,15 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
     const float kNone = -3.0e38f;   // "no unmasked column yet" (MODE 1)
     float rowacc[2] = {MODE == 1 ? kNone : 0.f, MODE == 1 ? kNone : 0.f};
     float myshift[2] = {0.f, 0.f};
-    if (MODE == 2) { myshift[0] = shift[row0 + 64 * wr + l31]; myshift[1] = shift[row0 + 64 * wr + 32 + l31]; }
+    if (MODE == 2 || MODE == 3) { myshift[0] = shift[row0 + 64 * wr + l31]; myshift[1] = shift[row0 + 64 * wr + 32 + l31]; }
+    float rowcnt[2] = {0.f, 0.f};   // MODE 3: active hinge terms
     KTileStage<128, 256> sp, sq;
 
     for (int t = t_begin; t < t_end; ++t) {
         const ColTile ct = col_tile(g, t, 128);
         if (ct.rank == g.skip_rank) continue;
+        if (MODE >= 3 && ct.mod == rmod) continue;                                                  // inter-modal block only
+        if (MODE == 4 && !(ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0)) continue;             // the partners' tile only
         const unsigned char* cbase = reinterpret_cast<const unsigned char*>(cols) + ct.row0 * pitch;
         f32x16 acc[2][2];
 #pragma unroll
@@ -253,7 +262,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
         // epilogue: e = exp2(c*g - m2), masked, summed into the lane's row
         const bool same_mod = (ct.mod == rmod);
         const float c2 = same_mod ? g.c_intra : g.c_inter;
-        const bool diag_tile = same_mod && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
+        const bool diag_tile = (MODE >= 3 ? !same_mod : same_mod) && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
         const bool ragged = ct.in_mod0 + 128 > g.b;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
@@ -273,6 +282,11 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                         if (MODE == 1) {
                             const float x = acc[qi][pi][r] * c2;
                             if (!masked && !(SW && kq[j] == 0.f)) rowacc[pi] = fmaxf(rowacc[pi], x);
+                        } else if (MODE == 3) {
+                            const float h = g.m2 + acc[qi][pi][r] - myshift[pi];
+                            if (!masked && h > 0.f) { rowacc[pi] += h; rowcnt[pi] += 1.f; }
+                        } else if (MODE == 4) {
+                            if (diag_tile && q_t == p_t) rowacc[pi] += acc[qi][pi][r];
                         } else {
                             float e = fast_exp2(acc[qi][pi][r] * c2 - (MODE == 2 ? myshift[pi] : g.m2));
                             if (masked) e = 0.f;
@@ -303,6 +317,40 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
     __syncthreads();
     if (tid < 128)
         part[(size_t)blockIdx.y * 2 * g.bpad + row0 + tid] = MODE == 1 ? fmaxf(red[tid], red[128 + tid]) : red[tid] + red[128 + tid];
+    if (MODE == 3) {   // the counts take the same route into `stash`
+        __syncthreads();
+        rowcnt[0] += wave_xor_f32(rowcnt[0], 32);
+        rowcnt[1] += wave_xor_f32(rowcnt[1], 32);
+        if (half == 0) {
+            red[wc * 128 + 64 * wr + l31] = rowcnt[0];
+            red[wc * 128 + 64 * wr + 32 + l31] = rowcnt[1];
+        }
+        __syncthreads();
+        if (tid < 128) stash[(size_t)blockIdx.y * 2 * g.bpad + row0 + tid] = red[tid] + red[128 + tid];
+    }
+}
+// score statistics, second half: slot sums -> hinge[p], active[p] (a count, as float), and the block partial of sum_p hinge (double; added up
+// in index order by fwd_finish_reduce_kernel: deterministic)
+__global__ void __launch_bounds__(256) score_finish_kernel(const float* part, const float* cnt, int nslots, int bpad, int b,
+                                                           float* hinge, float* active, double* loss_ws) {
+    CROSSCLR_SHARED double sh[256];
+    const int n = 2 * bpad;
+    double acc = 0.0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        float h = 0.f, c = 0.f;
+        for (int s = 0; s < nslots; ++s) { h += part[(size_t)s * n + p]; c += cnt[(size_t)s * n + p]; }
+        const bool valid = (p < bpad ? p : p - bpad) < b;
+        hinge[p] = valid ? h : 0.f;
+        active[p] = valid ? c : 0.f;
+        if (valid) acc += (double)h;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_ws[1 + blockIdx.x] = sh[0];
 }
 // pass 1 of the two-pass soft-max, second half: shift[p] = max(slot maxima, own previous value if `accumulate`, and the masked
 // self pair's logit 0 when it is part of the row's soft-max: k_p != 0)
@@ -495,7 +543,10 @@ __device__ __forceinline__ void bwd_gemm2(const unsigned char* wt, const unsigne
 // SW (sample weights): the intra-modal weight is s E (wrz_p k_q + wrz_q k_p) instead of s E (wrz_p + wrz_q).
 // RM (two-pass soft-max, small temperatures): rz = omega / (row sum relative to the ROW's shift), so the weight is
 //    s (exp2(x - shift_p) wrz_p k_q + exp2(x - shift_q) wrz_q k_p)  -- two exponentials, both <= 1: nothing can overflow.
-template <typename T, int DC, bool SW, bool RM>
+// LOSS = 1: the max-margin ranking loss (trainer/loss.py:29-41) on the same skeleton -- no soft-max: the weight of an inter-modal
+//    pair is the number of its active hinges, [g.m2 + S - d_p > 0] + [g.m2 + S - d_q > 0] (d = the positive pairs' cosines, passed
+//    in shift_rows / shift_cols; g.m2 = margin), 0 for the positive pair itself and inside a modality (those tiles are skipped).
+template <typename T, int DC, bool SW, bool RM, int LOSS = 0>
 __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, Geo g, const float* rz_rows,
                                                   const float* wrz_rows, const float* rz_cols, const float* wrz_cols,
                                                   float* gbuf, int accumulate, int tiles_per_slice,
@@ -535,7 +586,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
     const float rzp_inter = rz_rows[row0 + p_t];
     const float rzp_intra = wrz_rows[row0 + p_t];
     const float kp = SW ? krows[row0 + p_t] : 1.f;
-    const float shp = RM ? shift_rows[row0 + p_t] : 0.f;
+    const float shp = (RM || LOSS == 1) ? shift_rows[row0 + p_t] : 0.f;
 
     // column slice z walks its share of the USABLE tiles (the skipped rank's segment is cut out of the numbering,
     // so the slices stay balanced) ...
@@ -548,6 +599,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
     KTileStage<64, 256> sp, sq;
     for (int u = t_begin; u < t_stop; ++u) {
         const ColTile ct = col_tile(g, (skip_seg >= 0 && u >= skip_seg * per_rank) ? u + per_rank : u, 64);
+        if (LOSS == 1 && ct.mod == rmod) continue;   // (uniform for the block: no barrier is skipped by part of it)
         const unsigned char* cbase = reinterpret_cast<const unsigned char*>(cols) + ct.row0 * pitch;
         // ---------------- phase A ----------------
         f32x16 acc;
@@ -587,7 +639,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
         const float c2 = same_mod ? g.c_intra : g.c_inter;
         const float rzp = same_mod ? rzp_intra : rzp_inter;
         const float* rzq = (same_mod ? wrz_cols : rz_cols) + ct.stat0;
-        const bool diag_tile = same_mod && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
+        const bool diag_tile = (LOSS == 1 ? !same_mod : same_mod) && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int q0 = 32 * wq + 8 * r4 + 4 * half;  // frag_row(4*r4 + j, half) = q0 - 32wq + j
@@ -596,12 +648,16 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
             if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + q0);
             const float kpe = (SW && same_mod) ? kp : 1.f;
             f32x4 shq = {0.f, 0.f, 0.f, 0.f};
-            if (RM) shq = *reinterpret_cast<const f32x4*>(shift_cols + ct.stat0 + q0);
+            if (RM || LOSS == 1) shq = *reinterpret_cast<const f32x4*>(shift_cols + ct.stat0 + q0);
             f32x4 w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v;
-                if (RM) {
+                if (LOSS == 1) {
+                    const float x = g.m2 + acc[4 * r4 + j];
+                    v = (x - shp > 0.f ? 1.f : 0.f) + (x - shq[j] > 0.f ? 1.f : 0.f);
+                    if (ct.in_mod0 + q0 + j >= g.b) v = 0.f;    // (padding columns: their operand rows are zero anyway)
+                } else if (RM) {
                     const float x = acc[4 * r4 + j] * c2;
                     const float ep = fast_exp2(x - shp), eq = fast_exp2(x - shq[j]);
                     v = SW ? (ep * rzp * kq[j] + eq * rq[j] * kpe) : (ep * rzp + eq * rq[j]);

@@ -295,6 +295,32 @@ int crossclr_influence_conn(const void* x_video, const void* x_text, long ld_vid
 int crossclr_influence_finish(const crossclr_plan* plan, const double* conn_all, float score_threshold,
                               float temperature_weights, float* neg_scale, float* loss_weight, void* stream);
 
+/* ---- score statistics of the inter-modal block (single device: plan->world == 1) -------------
+ * The B x B matrix S = im . s^T of /root/reference/trainer/loss.py:30 (`cosine_sim`, loss.py:7-15: a plain product; the rows
+ * are used as given -- lay them out with crossclr_pack, or crossclr_normalize for cosines of raw features), never materialised:
+ *   crossclr_score_diag    diag[2][bpad]: the positive pairs' scores S_ii (loss.py:31), once per stacked row, from the same
+ *                          MFMA sequence crossclr_score_rows compares against (S_ij > S_ii is exact; no tie with oneself)
+ *   crossclr_score_rows    per stacked row p (p < bpad: im_i against every s_j; p >= bpad: s_j against every im_i), over the
+ *                          other modality's columns q != partner(p)                                   (loss.py:32-40):
+ *                            hinge[p]  = sum_q max(0, margin + S_pq - S_pp)      (rows of cost_s / columns of cost_im)
+ *                            active[p] = #{q : margin + S_pq - S_pp > 0}         (as float; exact below 2^24)
+ *                          loss_sum[0] = sum_p hinge[p]; loss_sum[1] = loss_sum[0] / (B * B) = MaxMargin_coot.forward (loss.py:41).
+ *                          margin = 0: active[p] is the retrieval rank of p's partner (0 = retrieved first): R@k = mean(active < k).
+ *                          `part` = the plan's forward workspace (plan->fwd_ws_floats floats); loss_sum as for crossclr_forward_finish.
+ *   crossclr_maxmargin_backward          gbuf = d(sum of hinges)/dS . X for every stacked row except the positive-pair terms
+ *                                         (replaces autograd of loss.py:30-41; weight of a pair = its active hinges, 0..2)
+ *   crossclr_maxmargin_backward_finish   column slices summed, positive-pair terms -(active_im_i + active_s_i) * partner_i,
+ *                                         / (B * B), x grad_out, gradients in the input dtype.  `ones` = the inv_norm array
+ *                                         crossclr_pack wrote (all ones); im / s = the tensors given to crossclr_pack.      */
+int crossclr_score_diag(const crossclr_plan* plan, const void* xhat, float* diag, void* stream);
+int crossclr_score_rows(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
+                        float* hinge, float* active, double* loss_sum, void* stream);
+int crossclr_maxmargin_backward(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* gbuf,
+                                void* stream);
+int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* gbuf, const void* im, const void* s, long ld_im,
+                                       long ld_s, int in_dtype, const float* ones, const float* active, const double* grad_out,
+                                       void* grad_im, void* grad_s, long ld_gim, long ld_gs, void* stream);
+
 /* Hardware assumption checks (MFMA fragment layouts, ds_read_b64_tr_b16 gather).  `out` is a
  * device buffer of at least 64 KiB; the caller compares it with the documented layouts.        */
 int crossclr_selftest(int which, const void* in, void* out, void* stream);

@@ -109,8 +109,11 @@ def test_reference_import_path_works():
     import importlib
     mod = importlib.import_module("trainer.loss")
     assert mod.CrossCLR_onlyIntraModality is crossclr_amd.CrossCLR_onlyIntraModality
-    # the module's other two top-level names import too; MaxMargin_coot is as unconstructible as in the reference
+    # the module's other two top-level names (trainer/loss.py:7-41): cosine_sim is the plain product; MaxMargin_coot -- which
+    # the reference cannot even construct (loss.py:24) -- is the working implementation with the declared signature / attributes
     a, b = torch.randn(3, 5), torch.randn(4, 5)
     assert torch.equal(mod.cosine_sim(a, b), a @ b.t())
-    with pytest.raises(NameError):
-        mod.MaxMargin_coot(use_cuda=False)
+    crit = mod.MaxMargin_coot(use_cuda=False, margin=0.25)
+    assert crit.margin == 0.25 and crit.use_cuda is False and crit.sim is mod.cosine_sim and list(crit.state_dict()) == []
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        crit(torch.randn(4, 8), torch.randn(4, 8))
