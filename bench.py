@@ -279,10 +279,11 @@ def main():
             kernels[k].update(algorithmic_tflops=round(tf, 2), frac=round(tf / peak, 4))
     saved = bool(st.get("saved_path"))
     if args.fwd_only:
-        dom, dom_kernel = "forward", ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel")
+        dom, dom_kernel = "forward", ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel<float, false, 0, false>")
     else:
         dom = "backward_saved" if saved else "backward"
-        dom_kernel = "fast_bwd_saved_kernel" if saved else ("fast_bwd" if st["fast_path"] else "bwd_kernel")
+        dom_kernel = (("fast_bwd_saved_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
+                      else ("fast_bwd" if st["fast_path"] else "bwd_kernel"))
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
     traffic = measured_traffic(b, d, args.mode, dom_kernel) if world == 1 and not args.influential else None
     step_tf = (6.0 if args.fwd_only else 14.0) * b * B * d / t_step / 1e12  # per-GPU algorithmic flops over the whole step

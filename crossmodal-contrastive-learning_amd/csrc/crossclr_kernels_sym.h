@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     };
     // general (masked / weighted) epilogue of one tile, not overlapped with anything
     auto epilogue_plain = [&](f32x16 (&acc)[NH], const Prev& pv) {
+        if (CROSSCLR_YABL & 32) { rowacc[0] += acc[0][0] + acc[NH - 1][1]; return; }
         const bool same_mod = pv.cmod == rmod;
         const float c2s = same_mod ? g.c_intra : g.c_inter;
         const bool upper = wants_colsum(pv.j);
@@ -286,17 +287,26 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             constexpr int k = decltype(ic)::value;
             ring[k % PF] = lds_read_b128_async<(k >> 3) * 256>(abase[k & 7]);
         };
-        // one k-step: wait for its A fragment, two MFMAs (both row halves), the read PF k-steps ahead, then the step's chores
-        auto kstep = [&](auto ic) {
+        // one k-step = two half-slots, each opened by an MFMA (NH == 2: one per row half; NH == 1: the second is empty): wait for
+        // the A fragment; MFMA; the read PF k-steps ahead + chore A; MFMA; this step's DMA piece + chore B.  One wave per SIMD
+        // issues in order, so whatever follows an MFMA runs in its shadow -- and an MFMA directly behind another MFMA waits for
+        // the pipe with nothing issued meanwhile: the chores are dealt evenly over the 2 DK half-slots.
+        auto kstep = [&](auto ic, auto&& chore_a, auto&& chore_b) {
             constexpr int k = decltype(ic)::value;
             constexpr int later = (DK - 1 - k) < (PF - 1) ? (DK - 1 - k) : (PF - 1);
             wait_lgkm<later>(ring[k % PF]);
             const bf16x8 a = __builtin_bit_cast(bf16x8, ring[k % PF]);
             acc[0] = mfma_32x32x16_bf16(a, pf[0][k], acc[0]);
-            if constexpr (NH == 2) acc[1] = mfma_32x32x16_bf16(a, pf[NH - 1][k], acc[NH - 1]);
             if constexpr (k + PF < DK) fetch(IdxC<k + PF>{});
+            chore_a();
+            if constexpr (NH == 2) {
+                sched_fence();
+                acc[1] = mfma_32x32x16_bf16(a, pf[NH - 1][k], acc[NH - 1]);
+            }
             if constexpr (k < NXO) issue_piece(cq[NST - 1], rstage, k);
             if constexpr (k == NXO) issue_stat(cq[NST - 1], rstage);
+            chore_b();
+            sched_fence();
         };
         // NOTE: the reads that prime the ring must sit in the SAME basic block as the k-step chain: an asm load's registers
         // count as written when the asm statement ends, so a register copy at a control-flow merge would read them early.
@@ -305,25 +315,24 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             // ---- pipelined: the owed tile is unmasked and unweighted (and, KIND 1, strictly right of the diagonal block) ----
             const float c2s = (prev.cmod == rmod) ? g.c_intra : g.c_inter;
             float e[NH][16], es[16], k8[8], k4[4], k2[2];
-            // chore plan over the DK k-steps:
-            //   steps [0, DK/2): scale + exp2 + row sum of the 32 elements
-            //   steps [DK/2, 3DK/4): es = e0 + e1 (16), bf16 pack + stash stores (4 fragments)
-            //   steps [3DK/4, DK): recursive-halving butterfly (8 + 4 + 2 + 1 + final) and the LDS slot write (KIND 1 / 3)
-            constexpr int S1 = DK / 2, S2 = 3 * DK / 4;
-            static_for<PF>([&](auto ic) { fetch(ic); });
-            static_for<DK>([&](auto ic) {
-                constexpr int k = decltype(ic)::value;
-                kstep(ic);
-                if constexpr (k < S1) {
+            // chore plan over the H = 2 DK half-slots:
+            //   [0, H/2): scale + exp2 + row sum of the 16 NH elements
+            //   [H/2, 3H/4): es = e0 + e1 (16), bf16 pack + stash stores (2 NH fragments)
+            //   [3H/4, H): recursive-halving butterfly (8 + 4 + 2 + 1 + final) and the LDS slot write (KIND 1 / 3)
+            constexpr int H = 2 * DK, H1 = H / 2, H2 = 3 * H / 4;
+            auto chore = [&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                if (CROSSCLR_YABL & 32) { if (h == 0) rowacc[0] += pacc[0][0] + pacc[NH - 1][1]; return; }   // (keeps the MFMAs alive)
+                if constexpr (h < H1) {
 #pragma unroll
-                    for (int idx = (NE * k) / S1; idx < (NE * (k + 1)) / S1; ++idx) {
+                    for (int idx = (NE * h) / H1; idx < (NE * (h + 1)) / H1; ++idx) {
                         const int s = idx >> 4, r = idx & 15;
                         const float v = fast_exp2(pacc[s][r] * c2s - g.m2);
                         e[s][r] = v;
                         rowacc[s] += v;
                     }
-                } else if constexpr (k < S2) {
-                    constexpr int n = S2 - S1, i = k - S1;         // n steps: 16 sums and 2 NH fragments
+                } else if constexpr (h < H2) {
+                    constexpr int n = H2 - H1, i = h - H1;         // n half-slots: 16 sums and 2 NH fragments
                     if (KIND != 2) {
 #pragma unroll
                         for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = NH == 2 ? e[0][r] + e[NH - 1][r] : e[0][r];
@@ -340,7 +349,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
                         }
                     }
                 } else if constexpr (KIND != 2) {
-                    constexpr int n = DK - S2, i = k - S2;         // n >= 2 steps for the butterfly
+                    constexpr int n = H - H2, i = h - H2;          // n >= 4 half-slots for the butterfly
                     constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;   // work units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: publish
 #pragma unroll
                     for (int u = lo; u < hi; ++u) {
@@ -369,12 +378,16 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
                         }
                     }
                 }
-                sched_fence();
+            };
+            static_for<PF>([&](auto ic) { fetch(ic); });
+            static_for<DK>([&](auto ic) {
+                constexpr int k = decltype(ic)::value;
+                kstep(ic, [&]() { chore(IdxC<2 * k>{}); }, [&]() { chore(IdxC<2 * k + 1>{}); });
             });
         } else {
             if (prev.valid) epilogue_plain(pacc, prev);
             static_for<PF>([&](auto ic) { fetch(ic); });
-            static_for<DK>([&](auto ic) { kstep(ic); sched_fence(); });
+            static_for<DK>([&](auto ic) { kstep(ic, []() {}, []() {}); });
         }
         // this tile's epilogue is owed to the next iteration
         {
@@ -387,7 +400,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
             if (KIND != 1) { crank = g.col_rank0 + cq[0].seg; if (g.col_wrap > 0 && crank >= g.col_wrap) crank -= g.col_wrap; }
             const int r0 = row0w - rmod * g.bpad;       // the wave's first row inside its modality
             const bool selfpairs = KIND != 1 && crank == g.row_rank && cmod == rmod && (in_mod0 == r0 || (NH == 2 && in_mod0 == r0 + 32));
-            prev.valid = !(CROSSCLR_YABL & 32);
+            prev.valid = true;
             // fast = nothing to mask: KIND 1 tiles of the diagonal block (j < TPR) hold the self pairs; padding rows only matter
             // where column sums are formed
             prev.fast = !SW && !ragged && !(colsum && padrows) && !(KIND == 1 && !colsum) && !selfpairs && !(CROSSCLR_YABL & 8);
