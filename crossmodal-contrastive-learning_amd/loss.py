@@ -90,7 +90,7 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges")
+                 "saved_blocks", "recompute_ranges", "exchange")
 
 
 _plan_cache: dict = {}
@@ -122,6 +122,50 @@ def _check_equal_rows_per_rank(b: int, D: int, group, dev) -> None:
         raise RuntimeError(f"CrossCLR (sharded): every rank must pass the same number of rows and columns; this rank has "
                            f"[{b}, {D}] but the group spans [{lo_b}..{hi_b}, {lo_d}..{hi_d}]")
     _checked_shapes.add(key)
+
+
+class _OperandExchange:
+    """How the ranks' packed operands reach each other.
+
+    all-gather (default): one `all_gather_into_tensor`; forward and backward wait for the same collective.
+    point-to-point, ordered by need (CROSSCLR_EXCHANGE=p2p; pairs scheme only): the forward of rank r touches only the ranks it
+    evaluates itself -- r+1 .. r+K and the antipodal rank -- so those slices travel first (one batch of isend / irecv, every
+    xGMI link busy at once); the slices only the backward's recompute needs (r-K .. r-1) follow in a second batch that has the
+    whole remote forward to hide behind.  Same bytes, less of them on the forward's critical path (4/7 at 8 ranks)."""
+
+    def __init__(self, xcols, xhat, group, world, rank, first_peers=None):
+        import torch.distributed as dist
+        self._first, self._rest = [], []
+        if first_peers is None:
+            self._first = [dist.all_gather_into_tensor(xcols, xhat, group=group, async_op=True)]
+            return
+        n = xhat.numel()
+        piece = lambda r: xcols[r * n:(r + 1) * n]
+        piece(rank).copy_(xhat)
+        others = [(rank + d) % world for d in range(1, world)]
+        early = [r for r in others if r in first_peers]
+        late = [r for r in others if r not in first_peers]
+        # rank s receives this rank's slice early iff this rank is one of ITS first peers: the offsets are symmetric
+        offs_early = {(q - rank) % world for q in early}
+        send_early = [(rank - d) % world for d in sorted(offs_early)]
+        send_late = [r for r in others if r not in send_early]
+        to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None and group is not dist.group.WORLD else (lambda r: r)
+        for recv_from, send_to, works in ((early, send_early, self._first), (late, send_late, self._rest)):
+            ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group) for r in recv_from]
+            ops += [dist.P2POp(dist.isend, xhat, to_global(r), group) for r in send_to]
+            if ops:
+                works.extend(dist.batch_isend_irecv(ops))
+
+    def wait_forward(self):
+        for w in self._first:
+            w.wait()
+        self._first = []
+
+    def wait(self):
+        self.wait_forward()
+        for w in self._rest:
+            w.wait()
+        self._rest = []
 
 
 def _carve(total: torch.Tensor, offset: int, nbytes: int, dtype):
@@ -213,12 +257,19 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         # all-gather of the packed operands runs on the collective's own stream (RCCL over xGMI)
         # while the local column block is processed on the compute stream
         ws.xcols = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device=dev)
-        gather = dist.all_gather_into_tensor(ws.xcols, ws.xhat, group=group, async_op=True)
+        first_peers = None
+        if (os.environ.get("CROSSCLR_EXCHANGE") == "p2p" and world >= 3 and plan.fast_path == 1 and not small_tau and
+                os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1"):
+            first_peers = {(rank + 1 + k) % world for k in range((world - 1) // 2)}
+            if world % 2 == 0:
+                first_peers.add((rank + world // 2) % world)
+        gather = ws.exchange = _OperandExchange(ws.xcols, ws.xhat, group, world, rank, first_peers)
         if ws.k_rows is not None:
             ws.k_cols = torch.empty(world * ws.k_rows.numel(), **f32)
             dist.all_gather_into_tensor(ws.k_cols, ws.k_rows, group=group)
     else:
         ws.xcols = ws.xhat
+        ws.exchange = None
     # Small temperatures (max |logit| = max(1,|w|)/tau > 128): no single soft-max shift fits fp32.  Like the reference's
     # float64 soft-max (loss.py:60) the rows then get their own shift -- the row maximum, found by a first pass -- and the
     # generic tiled kernels do the rest (no symmetric evaluation, no pair scheme, no save-for-backward in this regime).
@@ -248,7 +299,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                    lib.crossclr_rect_stash_bytes(pp, 1) > 0 and   # (wide operands, 512 < D <= 1024, save the local block only)
                    os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1")
     if save_remote:
-        gather.wait()
+        gather.wait_forward()   # (point-to-point exchange: the peers this rank evaluates itself; all-gather: everything)
         n2 = 2 * plan.bpad
         npairs = (world - 1) // 2 if use_pairs else 0
         sw_all = _sw(ws.k_rows, ws.k_cols, None)
@@ -279,7 +330,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         else:
             nlaunch = 2
     elif sharded and use_pairs:
-        gather.wait()
+        gather.wait_forward()   # (point-to-point exchange: the peers this rank evaluates itself; all-gather: everything)
         n2 = 2 * plan.bpad
         npairs = (world - 1) // 2
         colsum = torch.empty(npairs * n2, **f32)
@@ -323,6 +374,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         total = ws.loss_sum[:1].clone()
         dist.all_reduce(total, group=group)
         loss = (total / (2.0 * b * world)).reshape(())
+        if not save_for_backward and ws.exchange is not None:
+            ws.exchange.wait()     # nobody will wait later: the late slices' sends / receives must not outlive their buffers
     else:
         ws.rz_cols, ws.wrz_cols, ws.stats_work = ws.rz, ws.wrz, None
         loss = ws.loss_sum[1]      # = sum / (2 B), written by the finish kernel (a 0-dim view of the 8-byte-per-block loss buffer)
@@ -413,6 +466,8 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
             nat.check(lib.crossclr_backward_rect_saved(pp, _ptr(ws.xcols), _ptr(st), first, n, ws.temperature, ws.negative_w,
                                                        _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
                                                        _ptr(gbuf), 1, stream))
+        if ws.recompute_ranges:
+            ws.exchange.wait()                      # (point-to-point exchange: the slices only this recompute needs)
         for first, n in ws.recompute_ranges:        # blocks the other side of a pair evaluated: recompute
             nat.check(lib.crossclr_backward_ranks(pp, _ptr(ws.xhat), _ptr(ws.xcols), first, n, ws.temperature, ws.negative_w,
                                                   _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,

@@ -27,6 +27,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         from emu import build_emu
         from oracle import crossclr_oracle as orc
         nat.use_library_for_testing(build_emu.OUT)
+        p2p = mode.endswith("+p2p")      # the need-ordered point-to-point operand exchange instead of the all-gather
+        if p2p:
+            mode = mode[:-4]
+            os.environ["CROSSCLR_EXCHANGE"] = "p2p"
         v, t = orc.make_inputs("randn", B, D, 77)
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
@@ -34,6 +38,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         crit = crossclr_amd.CrossCLR_onlyIntraModality(tau, 0.7, compute_mode=mode, process_group=dist.group.WORLD)
         loss = crit(vl, tl)
         loss.backward()
+        if p2p:   # forward only: nobody waits for the late slices in a backward -- the forward itself must
+            with torch.no_grad():
+                again = crit(vl, tl)
+            assert abs(float(again) - float(loss)) <= 1e-12
         ref = orc.sharded_loss_and_grads(v, t, world, rank, tau, 0.7)
         scale = ref["grad_v"].abs().max().item()
         q.put((rank, float(loss), float(ref["loss"]),
@@ -62,7 +70,12 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (3, 390, 16, "bf16", 5e-3, 2e-2),
                                                        # wide operands (512 < D <= 1024): one 32-row half per wave, 128-row blocks,
                                                        # the backward in two column parts; pairs + saved remote blocks as well
-                                                       (3, 24, 530, "bf16", 5e-3, 2e-2)])
+                                                       (3, 24, 530, "bf16", 5e-3, 2e-2),
+                                                       # CROSSCLR_EXCHANGE=p2p: the operands travel point to point, the slices the
+                                                       # forward needs first (3 / 4 / 5 ranks: with and without an antipodal rank)
+                                                       (3, 24, 16, "bf16+p2p", 5e-3, 2e-2),
+                                                       (4, 24, 16, "bf16+p2p", 5e-3, 2e-2),
+                                                       (5, 20, 16, "bf16+p2p", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()
