@@ -32,3 +32,14 @@ def step():
 timeit("fwd + bwd", step)
 lossk = crit(vg, tg)
 timeit("backward only (retain_graph)", lambda: lossk.backward(retain_graph=True))
+# eager step, wall clock with the GPU drained, at the launch-bound sizes
+for Bx in (256, 1024, 2048):
+    vb = torch.randn(Bx, D, generator=g).cuda().requires_grad_(True); tb = torch.randn(Bx, D, generator=g).cuda().requires_grad_(True)
+    def stepb():
+        vb.grad = tb.grad = None
+        crit(vb, tb).backward()
+    for _ in range(100): stepb()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(1000): stepb()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"B={Bx}: eager fwd + bwd: {1e6*(t1-t0)/1000:7.1f} us/step (wall, GPU drained)")
