@@ -511,7 +511,9 @@ def test_prenormalized_entry_equals_the_plain_path(mode, B, D):
 
 
 @pytest.mark.parametrize("world,B,D,weighted", [(2, 512, 128, False), (3, 768, 256, False), (4, 2048, 512, False), (5, 1280, 256, True),
-                                                (8, 2048, 512, False), (2, 512, 1024, False), (3, 768, 700, True), (8, 2048, 1024, True)])
+                                                (8, 2048, 512, False), (2, 512, 1024, False), (3, 768, 700, True), (8, 2048, 1024, True),
+                                                # BASELINE config 4 at full size: 8 ranks x 8192 rows, every rank played on this GPU
+                                                (8, 65536, 512, False)])
 def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, weighted):
     """The sharded step with a backward to follow: pair partners' and the antipodal rank's blocks save their exponentials in the
     forward (crossclr_forward_rect_save) and feed the backward from them (crossclr_backward_rect_saved); the blocks the OTHER
