@@ -317,11 +317,21 @@ static void forward_generic_t(const crossclr_plan* plan, const Geo& g, const voi
                               const float* kcols, const float* shift, int mode, int tps, dim3 grid, void* stream) {
     dim3 block(256);
     (void)plan;
-#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift, (float*)nullptr)
+#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift, (float*)nullptr, (int*)nullptr)
     if (kcols) { if (mode == 0) CROSSCLR_LFG(true, 0); else if (mode == 1) CROSSCLR_LFG(true, 1); else CROSSCLR_LFG(true, 2); }
     else { if (mode == 0) CROSSCLR_LFG(false, 0); else if (mode == 1) CROSSCLR_LFG(false, 1); else CROSSCLR_LFG(false, 2); }
 #undef CROSSCLR_LFG
 }
+// symmetric evaluation of the local block by the generic forward (rows == columns, nothing saved): upper triangle + column sums
+template <typename T>
+static int forward_generic_sym(const crossclr_plan* plan, const Geo& g, const void* x, float* out, const float* k, float* colpart,
+                               int* header, void* stream) {
+    dim3 grid(2 * plan->bpad / 256, plan->fwd_slots), block(256);     // one blockIdx.x per PAIR of row blocks (I, ntiles - 1 - I)
+    if (k) LAUNCH((fwd_sums_kernel<T, true, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, (const float*)nullptr, colpart, header);
+    else LAUNCH((fwd_sums_kernel<T, false, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, (const float*)nullptr, colpart, header);
+    return launch_status("fwd_sums_kernel (symmetric)");
+}
+
 static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
                            const float* kcols, const float* shift, int mode, void* stream, float* stash) {
     const int ntiles = g.col_ranks * 2 * plan->bpad / 128;
@@ -330,8 +340,8 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
     dim3 grid(2 * plan->bpad / 128, nsplit);
     if (stash) {   // exact-fp32 forward that also saves its exponentials (local block, common shift)
         dim3 block(256);
-        if (kcols) LAUNCH((fwd_sums_kernel<float, true, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash);
-        else LAUNCH((fwd_sums_kernel<float, false, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash);
+        if (kcols) LAUNCH((fwd_sums_kernel<float, true, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr);
+        else LAUNCH((fwd_sums_kernel<float, false, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr);
         return launch_status("fwd_sums_kernel (save)");
     }
     if (plan->mode == CROSSCLR_MODE_FP32) forward_generic_t<float>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
@@ -377,6 +387,13 @@ extern "C" int crossclr_forward_w(const crossclr_plan* plan, const void* xhat_ro
         return rc ? fail(rc, "fast_forward: unsupported Dpad %d", plan->Dpad) : launch_status("fast_fwd_kernel");
     }
 #endif
+    if (xhat_rows == xhat_cols && col_ranks == 1 && col_rank0 == plan->rank && skip_rank < 0 && krows == kcols &&
+        !env_knobs().disable_symmetric) {
+        // the local block (single device, or the local block of a sharded run), forward only: upper triangle + column sums
+        float* colpart = part + ws_colpart_off(plan);
+        return plan->mode == CROSSCLR_MODE_FP32 ? forward_generic_sym<float>(plan, g, xhat_rows, out, kcols, colpart, header, stream)
+                                                : forward_generic_sym<bf16_t>(plan, g, xhat_rows, out, kcols, colpart, header, stream);
+    }
     rc = device_zero_header(header, stream);
     if (rc) return rc;
     return forward_generic(plan, g, xhat_rows, xhat_cols, out, kcols, nullptr, 0, stream);
@@ -830,8 +847,8 @@ static void score_launch(const crossclr_plan* plan, const Geo& g, const void* x,
     const int nsplit = mode == 4 ? 1 : plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     dim3 grid(2 * plan->bpad / 128, nsplit), block(256);
-    if (mode == 4) LAUNCH((fwd_sums_kernel<T, false, 4>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt);
-    else LAUNCH((fwd_sums_kernel<T, false, 3>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt);
+    if (mode == 4) LAUNCH((fwd_sums_kernel<T, false, 4>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt, (int*)nullptr);
+    else LAUNCH((fwd_sums_kernel<T, false, 3>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt, (int*)nullptr);
 }
 
 extern "C" int crossclr_score_diag(const crossclr_plan* plan, const void* xhat, float* diag, void* stream) {

@@ -287,3 +287,26 @@ def test_wide_operands_take_the_saved_backward_in_two_column_parts(B, D, weighte
         ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.8)
         assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 2e-2 * scale
         assert (gts.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
+
+
+@pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, False), (150, 24, True), (70, 16, False)])
+def test_generic_forward_only_evaluates_the_upper_triangle(B, D, weighted, monkeypatch):
+    """compute_mode="fp32" under no_grad (BASELINE config 2's shape of call): fwd_sums_kernel<..., SYM> evaluates the column
+    tiles at / right of the diagonal block only and recovers the mirrored tiles from column sums (workspace header kind 4).
+    Same loss as the full evaluation (CROSSCLR_DISABLE_SYMMETRIC=1) and as the saving forward that a training step runs."""
+    v, t = orc.make_inputs("randn", B, D, 19)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(4)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+    with torch.no_grad():
+        sym = crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="fp32", **kw).item()
+    train = crossclr_amd.crossclr_loss(v.clone().requires_grad_(True), t, 0.05, 0.8, compute_mode="fp32", **kw).item()
+    monkeypatch.setenv("CROSSCLR_DISABLE_SYMMETRIC", "1")
+    with torch.no_grad():
+        full = crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="fp32", **kw).item()
+    assert abs(sym - full) <= 1e-6 * max(1.0, abs(full)) and abs(sym - train) <= 1e-6 * max(1.0, abs(train))
+    if not weighted:
+        ref = float(orc.streaming_loss_and_grads(v, t, 0.05, 0.8)["loss"])
+        assert abs(sym - ref) <= 1e-5 * max(1.0, abs(ref))
