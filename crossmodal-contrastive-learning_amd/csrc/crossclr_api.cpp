@@ -317,7 +317,7 @@ static void forward_generic_t(const crossclr_plan* plan, const Geo& g, const voi
                               const float* kcols, const float* shift, int mode, int tps, dim3 grid, void* stream) {
     dim3 block(256);
     (void)plan;
-#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift, (float*)nullptr, (int*)nullptr)
+#define CROSSCLR_LFG(SW, MODE) LAUNCH((fwd_sums_kernel<T, SW, MODE>), grid, block, stream, (const T*)rows, (const T*)cols, g, tps, out, kcols, shift, (float*)nullptr, (int*)nullptr, (float*)nullptr)
     if (kcols) { if (mode == 0) CROSSCLR_LFG(true, 0); else if (mode == 1) CROSSCLR_LFG(true, 1); else CROSSCLR_LFG(true, 2); }
     else { if (mode == 0) CROSSCLR_LFG(false, 0); else if (mode == 1) CROSSCLR_LFG(false, 1); else CROSSCLR_LFG(false, 2); }
 #undef CROSSCLR_LFG
@@ -325,10 +325,16 @@ static void forward_generic_t(const crossclr_plan* plan, const Geo& g, const voi
 // symmetric evaluation of the local block by the generic forward (rows == columns, nothing saved): upper triangle + column sums
 template <typename T>
 static int forward_generic_sym(const crossclr_plan* plan, const Geo& g, const void* x, float* out, const float* k, float* colpart,
-                               int* header, void* stream) {
+                               int* header, void* stream, float* stash = nullptr) {
     dim3 grid(2 * plan->bpad / 256, plan->fwd_slots), block(256);     // one blockIdx.x per PAIR of row blocks (I, ntiles - 1 - I)
-    if (k) LAUNCH((fwd_sums_kernel<T, true, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, (const float*)nullptr, colpart, header);
-    else LAUNCH((fwd_sums_kernel<T, false, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, (const float*)nullptr, colpart, header);
+    const float* no_shift = nullptr;
+    if (stash) {   // (exact-fp32 plans only: T = float)
+        if (k) LAUNCH((fwd_sums_kernel<float, true, 0, true, true>), grid, block, stream, (const float*)x, (const float*)x, g, 0, out, k, no_shift, stash, header, colpart);
+        else LAUNCH((fwd_sums_kernel<float, false, 0, true, true>), grid, block, stream, (const float*)x, (const float*)x, g, 0, out, k, no_shift, stash, header, colpart);
+        return launch_status("fwd_sums_kernel (symmetric, save)");
+    }
+    if (k) LAUNCH((fwd_sums_kernel<T, true, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, no_shift, (float*)nullptr, header, colpart);
+    else LAUNCH((fwd_sums_kernel<T, false, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, no_shift, (float*)nullptr, header, colpart);
     return launch_status("fwd_sums_kernel (symmetric)");
 }
 
@@ -340,8 +346,8 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
     dim3 grid(2 * plan->bpad / 128, nsplit);
     if (stash) {   // exact-fp32 forward that also saves its exponentials (local block, common shift)
         dim3 block(256);
-        if (kcols) LAUNCH((fwd_sums_kernel<float, true, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr);
-        else LAUNCH((fwd_sums_kernel<float, false, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr);
+        if (kcols) LAUNCH((fwd_sums_kernel<float, true, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+        else LAUNCH((fwd_sums_kernel<float, false, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
         return launch_status("fwd_sums_kernel (save)");
     }
     if (plan->mode == CROSSCLR_MODE_FP32) forward_generic_t<float>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
@@ -417,6 +423,8 @@ extern "C" int crossclr_forward_save(const crossclr_plan* plan, const void* xhat
     float* out = part + (size_t)slot0 * 2 * plan->bpad;
     int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
     if (!plan->fast_path) {   // exact-fp32 mode
+        if (!env_knobs().disable_symmetric)   // upper triangle; every fragment stored twice (as evaluated + transposed)
+            return forward_generic_sym<float>(plan, g, xhat, out, kcols, part + ws_colpart_off(plan), header, stream, static_cast<float*>(stash));
         rc = device_zero_header(header, stream);
         if (rc) return rc;
         return forward_generic(plan, g, xhat, xhat, out, kcols, nullptr, 0, stream, static_cast<float*>(stash));
@@ -847,8 +855,8 @@ static void score_launch(const crossclr_plan* plan, const Geo& g, const void* x,
     const int nsplit = mode == 4 ? 1 : plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     dim3 grid(2 * plan->bpad / 128, nsplit), block(256);
-    if (mode == 4) LAUNCH((fwd_sums_kernel<T, false, 4>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt, (int*)nullptr);
-    else LAUNCH((fwd_sums_kernel<T, false, 3>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt, (int*)nullptr);
+    if (mode == 4) LAUNCH((fwd_sums_kernel<T, false, 4>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt, (int*)nullptr, (float*)nullptr);
+    else LAUNCH((fwd_sums_kernel<T, false, 3>), grid, block, stream, (const T*)x, (const T*)x, g, tps, out, (const float*)nullptr, diag, cnt, (int*)nullptr, (float*)nullptr);
 }
 
 extern "C" int crossclr_score_diag(const crossclr_plan* plan, const void* xhat, float* diag, void* stream) {

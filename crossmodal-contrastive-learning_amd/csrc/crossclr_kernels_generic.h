@@ -189,14 +189,16 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 //           terms (g.m2 + S - shift[p] > 0) into `stash` (same slot layout, as floats); shift = the MODE 4 result, g.m2 = margin.
 //   SYM (MODE 0, rows and columns the same local operand, nothing saved): the stacked matrix of exponentials is symmetric, so row
 //   block I evaluates only the column tiles t >= I (split y takes t = I + y, I + y + nsplit, ...); every tile right of the
-//   diagonal one also leaves its 128 column sums over the block's rows in colpart[I][128 t ..] (`stash` argument) -- the row
-//   sums of the mirrored tile that is never evaluated.  The launch announces itself in `header` as kind 4 (dense slots +
+//   diagonal one also leaves its 128 column sums over the block's rows in colpart[I][128 t ..] -- the row sums of the
+//   mirrored tile that is never evaluated -- and, with ST, stores each of its fragments a second time, transposed, where the
+//   mirrored tile's fragment belongs (16 scalar stores per lane and fragment: the stash stays the full matrix the backward reads).  The launch announces itself in `header` as kind 4 (dense slots +
 //   column sums of the row blocks above); fwd_finish_kernel adds them up in a fixed order.  4.06 B^2 D instead of 8 B^2 D executed.
 template <typename T, bool SW, int MODE, bool ST = false, bool SYM = false>
 __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
-                                                       float* part, const float* kcols, const float* shift, float* stash, int* header) {
+                                                       float* part, const float* kcols, const float* shift, float* stash, int* header,
+                                                       float* colpart) {
     static_assert(!ST || MODE == 0, "exponentials are saved by the single-pass forward only");
-    static_assert(!SYM || (MODE == 0 && !ST), "symmetric evaluation: single-pass sums, nothing saved");
+    static_assert(!SYM || MODE == 0, "symmetric evaluation: single-pass sums only");
     typedef Operand<T> Op;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
@@ -327,6 +329,11 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                     if (ST) {
                         const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (ct.row0 + 64 * wc + 32 * qi) >> 5;
                         *reinterpret_cast<f32x4*>(stash + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = ev;
+                        if (SYM && mirror) {   // fragment (q32, p32): lane' = column q, element of row p at [p >> 3][half' = (p >> 2) & 1][p & 3]
+                            float* tf = stash + ((q32 * (size_t)(2 * g.bpad / 32) + p32) << 10) + 256 * (l31 >> 3) + 128 * ((l31 >> 2) & 1) + (l31 & 3);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) tf[4 * (8 * r4 + 4 * half + j)] = pad_row ? 0.f : ev[j];
+                        }
                     }
                 }
             }
@@ -339,7 +346,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                 }
             }
             __syncthreads();
-            if (mirror && tid < 128) stash[(size_t)rbk * 2 * g.bpad + (size_t)t * 128 + tid] = red[tid] + red[128 + tid];
+            if (mirror && tid < 128) colpart[(size_t)rbk * 2 * g.bpad + (size_t)t * 128 + tid] = red[tid] + red[128 + tid];
             __syncthreads();
         }
     }

@@ -226,7 +226,10 @@ def test_prenormalized_inputs_skip_the_normalisation_and_chain_through_autograd(
                float(orc.streaming_stats(v, t, 0.05, 0.8)["loss"])) <= 1e-5
 
 
-@pytest.mark.parametrize("B,D,weighted", [(70, 100, False), (40, 200, False), (70, 24, True), (33, 130, True)])
+@pytest.mark.parametrize("B,D,weighted", [(70, 100, False), (40, 200, False), (70, 24, True), (33, 130, True),
+                                          # several 128-row blocks: the saving forward evaluates the upper triangle only and stores
+                                          # every off-diagonal fragment twice (as evaluated + transposed)
+                                          (150, 24, False), (300, 40, True)])
 def test_fp32_saved_exponentials_backward_equals_the_recomputing_one(B, D, weighted, monkeypatch):
     """compute_mode="fp32": the forward leaves its fp32 exponentials behind (plan.stash_bytes) and bwd_saved32_kernel forms
     the gradient product from them; CROSSCLR_DISABLE_SAVE=1 is the recomputing bwd_kernel.  Same weights, same products:
