@@ -315,7 +315,11 @@ def main():
                      "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
                      "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
                      "whole_step_algorithmic_tflops_per_gpu": round(step_tf, 2),
-                     "whole_step_frac": round(step_tf / peak, 4)},
+                     "whole_step_frac": round(step_tf / peak, 4),
+                     # what a loop of nothing but MFMAs sustains on this pool's MI355X (tools/micro/mfma_chains.hip,
+                     # profiles/r02c_micro.txt): the package sits at its 1400 W limit with toggling operands
+                     "sustained_mfma_tflops_random_operands": 1650.0 if args.mode == "bf16" else None,
+                     "frac_of_sustained": round(dom_tf / 1650.0, 4) if args.mode == "bf16" else None},
         "kernels": kernels,
     }
     if args.influential:
