@@ -38,10 +38,11 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         crit = crossclr_amd.CrossCLR_onlyIntraModality(tau, 0.7, compute_mode=mode, process_group=dist.group.WORLD)
         loss = crit(vl, tl)
         loss.backward()
-        if p2p:   # forward only: nobody waits for the late slices in a backward -- the forward itself must
-            with torch.no_grad():
-                again = crit(vl, tl)
-            assert abs(float(again) - float(loss)) <= 1e-12
+        # forward only (no_grad): nothing is saved, no statistics gather; point-to-point exchange: nobody waits for the late
+        # slices in a backward, the forward itself must; generic kernels: the local block takes the symmetric evaluation
+        with torch.no_grad():
+            again = crit(vl, tl)
+        assert abs(float(again) - float(loss)) <= 2e-6 * max(1.0, abs(float(loss))), (float(again), float(loss))
         ref = orc.sharded_loss_and_grads(v, t, world, rank, tau, 0.7)
         scale = ref["grad_v"].abs().max().item()
         q.put((rank, float(loss), float(ref["loss"]),
