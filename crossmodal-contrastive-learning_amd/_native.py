@@ -101,6 +101,11 @@ _SIGNATURES = {
     "crossclr_backward_s": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights),
                                            _P, _P, _P, ctypes.c_int, _P]),
+    "crossclr_stash_bytes_s": (ctypes.c_size_t, [ctypes.POINTER(Plan)]),
+    "crossclr_forward_save_s": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_float, ctypes.c_float, ctypes.POINTER(SampleWeights),
+                                               _P, _P, ctypes.c_int, _P, _P]),
+    "crossclr_backward_saved_s": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
+                                                 ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     "crossclr_forward_add": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_int, _P, _P]),
     "crossclr_influence_colsum": (ctypes.c_int, [_P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  _P, _P, _P, _P]),

@@ -322,19 +322,23 @@ static void forward_generic_t(const crossclr_plan* plan, const Geo& g, const voi
     else { if (mode == 0) CROSSCLR_LFG(false, 0); else if (mode == 1) CROSSCLR_LFG(false, 1); else CROSSCLR_LFG(false, 2); }
 #undef CROSSCLR_LFG
 }
-// symmetric evaluation of the local block by the generic forward (rows == columns, nothing saved): upper triangle + column sums
+// symmetric evaluation of the local block by the generic forward (rows == columns): upper triangle + column sums; `shift` != NULL:
+// the second pass of the two-pass soft-max (sums relative to per-row shifts); `stash` != NULL (exact-fp32 plans): save the exponentials
 template <typename T>
 static int forward_generic_sym(const crossclr_plan* plan, const Geo& g, const void* x, float* out, const float* k, float* colpart,
-                               int* header, void* stream, float* stash = nullptr) {
+                               int* header, void* stream, float* stash = nullptr, const float* shift = nullptr, bool rowmax = false) {
     dim3 grid(2 * plan->bpad / 256, plan->fwd_slots), block(256);     // one blockIdx.x per PAIR of row blocks (I, ntiles - 1 - I)
-    const float* no_shift = nullptr;
+#define CROSSCLR_LSY(TT, SW, MODE, ST) \
+    LAUNCH((fwd_sums_kernel<TT, SW, MODE, ST, true>), grid, block, stream, (const TT*)x, (const TT*)x, g, 0, out, k, shift, stash, header, colpart)
     if (stash) {   // (exact-fp32 plans only: T = float)
-        if (k) LAUNCH((fwd_sums_kernel<float, true, 0, true, true>), grid, block, stream, (const float*)x, (const float*)x, g, 0, out, k, no_shift, stash, header, colpart);
-        else LAUNCH((fwd_sums_kernel<float, false, 0, true, true>), grid, block, stream, (const float*)x, (const float*)x, g, 0, out, k, no_shift, stash, header, colpart);
+        if (shift) { if (k) CROSSCLR_LSY(float, true, 2, true); else CROSSCLR_LSY(float, false, 2, true); }
+        else { if (k) CROSSCLR_LSY(float, true, 0, true); else CROSSCLR_LSY(float, false, 0, true); }
         return launch_status("fwd_sums_kernel (symmetric, save)");
     }
-    if (k) LAUNCH((fwd_sums_kernel<T, true, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, no_shift, (float*)nullptr, header, colpart);
-    else LAUNCH((fwd_sums_kernel<T, false, 0, false, true>), grid, block, stream, (const T*)x, (const T*)x, g, 0, out, k, no_shift, (float*)nullptr, header, colpart);
+    if (rowmax) { if (k) CROSSCLR_LSY(T, true, 1, false); else CROSSCLR_LSY(T, false, 1, false); }
+    else if (shift) { if (k) CROSSCLR_LSY(T, true, 2, false); else CROSSCLR_LSY(T, false, 2, false); }
+    else { if (k) CROSSCLR_LSY(T, true, 0, false); else CROSSCLR_LSY(T, false, 0, false); }
+#undef CROSSCLR_LSY
     return launch_status("fwd_sums_kernel (symmetric)");
 }
 
@@ -344,10 +348,12 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
     const int nsplit = plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     dim3 grid(2 * plan->bpad / 128, nsplit);
-    if (stash) {   // exact-fp32 forward that also saves its exponentials (local block, common shift)
+    if (stash) {   // exact-fp32 forward that also saves its exponentials (local block; common shift, or per-row shifts: mode 2)
         dim3 block(256);
-        if (kcols) LAUNCH((fwd_sums_kernel<float, true, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
-        else LAUNCH((fwd_sums_kernel<float, false, 0, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+#define CROSSCLR_LSV(SW, MODE) LAUNCH((fwd_sums_kernel<float, SW, MODE, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr)
+        if (mode == 2) { if (kcols) CROSSCLR_LSV(true, 2); else CROSSCLR_LSV(false, 2); }
+        else { if (kcols) CROSSCLR_LSV(true, 0); else CROSSCLR_LSV(false, 0); }
+#undef CROSSCLR_LSV
         return launch_status("fwd_sums_kernel (save)");
     }
     if (plan->mode == CROSSCLR_MODE_FP32) forward_generic_t<float>(plan, g, rows, cols, out, kcols, shift, mode, tps, grid, stream);
@@ -577,9 +583,18 @@ extern "C" int crossclr_forward_rowmax(const crossclr_plan* plan, const void* xh
     const bool skipping = skip_rank >= col_rank0 && skip_rank < col_rank0 + col_ranks;
     const int n = 2 * plan->bpad;
     int nslots = plan->fwd_slots;
+    const float* colpart = nullptr;
     if (col_ranks - (skipping ? 1 : 0) <= 0) nslots = 0;   // nothing to look at: only the self pair / the previous value
-    else if ((rc = forward_generic(plan, g, xhat_rows, xhat_cols, part, kcols, nullptr, 1, stream))) return rc;
-    LAUNCH(rowmax_combine_kernel, dim3((n + 255) / 256), dim3(256), stream, (const float*)part, nslots, n, krows, accumulate, shift_rows);
+    else if (xhat_rows == xhat_cols && col_ranks == 1 && col_rank0 == plan->rank && skip_rank < 0 && krows == kcols &&
+             !env_knobs().disable_symmetric) {   // the local block: upper triangle, column maxima for the mirrored tiles
+        float* cp = part + ws_colpart_off(plan);
+        int* header = reinterpret_cast<int*>(part + ws_flag_off(plan));   // (launch group 0's header: rewritten by the pass that follows)
+        rc = plan->mode == CROSSCLR_MODE_FP32 ? forward_generic_sym<float>(plan, g, xhat_rows, part, kcols, cp, header, stream, nullptr, nullptr, true)
+                                              : forward_generic_sym<bf16_t>(plan, g, xhat_rows, part, kcols, cp, header, stream, nullptr, nullptr, true);
+        if (rc) return rc;
+        colpart = cp;
+    } else if ((rc = forward_generic(plan, g, xhat_rows, xhat_cols, part, kcols, nullptr, 1, stream))) return rc;
+    LAUNCH(rowmax_combine_kernel, dim3((n + 255) / 256), dim3(256), stream, (const float*)part, nslots, n, krows, accumulate, shift_rows, colpart);
     return launch_status("rowmax_combine_kernel");
 }
 
@@ -603,7 +618,72 @@ extern "C" int crossclr_forward_s(const crossclr_plan* plan, const void* xhat_ro
     if (rc) return rc;
     const bool skipping = skip_rank >= col_rank0 && skip_rank < col_rank0 + col_ranks;
     if (col_ranks - (skipping ? 1 : 0) <= 0) return device_zero(out, (size_t)plan->fwd_slots * 2 * plan->bpad * sizeof(float), stream);
+    if (xhat_rows == xhat_cols && col_ranks == 1 && col_rank0 == plan->rank && skip_rank < 0 && krows == kcols &&
+        !env_knobs().disable_symmetric) {   // the local block: upper triangle + column sums (two exponentials per element)
+        float* colpart = part + ws_colpart_off(plan);
+        return plan->mode == CROSSCLR_MODE_FP32
+                   ? forward_generic_sym<float>(plan, g, xhat_rows, out, kcols, colpart, header, stream, nullptr, shift_rows)
+                   : forward_generic_sym<bf16_t>(plan, g, xhat_rows, out, kcols, colpart, header, stream, nullptr, shift_rows);
+    }
     return forward_generic(plan, g, xhat_rows, xhat_cols, out, kcols, shift_rows, 2, stream);
+}
+
+// the two-pass regime's save-for-backward pair (exact-fp32 plans, local block): U and Ut, twice the single-pass stash
+static size_t stash_bytes_s(const crossclr_plan* plan) {
+    if (!plan || plan->fast_path || plan->mode != CROSSCLR_MODE_FP32 || !plan->stash_bytes) return 0;
+    return 2 * plan->stash_bytes <= ((size_t)16 << 30) ? 2 * plan->stash_bytes : 0;
+}
+extern "C" size_t crossclr_stash_bytes_s(const crossclr_plan* plan) { return stash_bytes_s(plan); }
+
+extern "C" int crossclr_forward_save_s(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
+                                       const crossclr_sample_weights* sw, const float* shift, float* part, int slot0, void* stash,
+                                       void* stream) {
+    if (!plan || !xhat || !shift || !part || !stash || slot0 < 0) return fail(CROSSCLR_E_ARG, "NULL/negative argument");
+    if (!stash_bytes_s(plan)) return fail(CROSSCLR_E_ARG, "this plan has no two-pass save-for-backward path (crossclr_stash_bytes_s == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    if (krows != kcols) return fail(CROSSCLR_E_ARG, "the local block's row and column negative scales are the same array");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    if (plan->fwd_slots <= 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    float* out = part + (size_t)slot0 * 2 * plan->bpad;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    if (!env_knobs().disable_symmetric)
+        return forward_generic_sym<float>(plan, g, xhat, out, kcols, part + ws_colpart_off(plan), header, stream, static_cast<float*>(stash), shift);
+    rc = device_zero_header(header, stream);
+    if (rc) return rc;
+    return forward_generic(plan, g, xhat, xhat, out, kcols, shift, 2, stream, static_cast<float*>(stash));
+}
+
+extern "C" int crossclr_backward_saved_s(const crossclr_plan* plan, const void* xhat, const void* stash, float temperature,
+                                         float negative_weight, const float* rz, const float* wrz,
+                                         const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat || !stash || !rz || !wrz || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (!stash_bytes_s(plan)) return fail(CROSSCLR_E_ARG, "this plan has no two-pass save-for-backward path (crossclr_stash_bytes_s == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    if (krows != kcols) return fail(CROSSCLR_E_ARG, "the local block's row and column negative scales are the same array");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    const int NQ = 2 * plan->bpad / 32;
+    const int tps = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
+    const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;
+    dim3 block(256);
+#define CROSSCLR_LS32R(DC)                                                                                                             \
+    do {                                                                                                                               \
+        if (krows) LAUNCH((bwd_saved32_kernel<DC, true, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,      \
+                          (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                               \
+        else LAUNCH((bwd_saved32_kernel<DC, false, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,           \
+                    (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                                     \
+    } while (0)
+    if (plan->Dpad % 256 == 0) CROSSCLR_LS32R(256);
+    else if (plan->Dpad % 128 == 0) CROSSCLR_LS32R(128);
+    else CROSSCLR_LS32R(64);
+#undef CROSSCLR_LS32R
+    return launch_status("bwd_saved32_kernel (two-pass)");
 }
 
 // ------------------------------------------------------------------------------------------------

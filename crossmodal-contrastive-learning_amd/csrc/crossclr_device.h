@@ -219,6 +219,28 @@ __device__ __forceinline__ float halving_sum16(const float (&e)[16], int l31) {
     const float k1 = (up ? k2[1] : k2[0]) + lane_xor<1>(up ? k2[0] : k2[1]);
     return k1 + lane_xor<16>(k1);
 }
+// the same exchange pattern for maxima (row maxima of the two-pass soft-max, mirrored tiles)
+__device__ __forceinline__ float halving_max16(const float (&e)[16], int l31) {
+    float k8[8], k4[4], k2[2];
+    {
+        const bool up = (l31 >> 3) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k8[i] = fmaxf(up ? e[8 + i] : e[i], lane_xor<15>(up ? e[i] : e[8 + i]));
+    }
+    {
+        const bool up = (l31 >> 2) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k4[i] = fmaxf(up ? k8[4 + i] : k8[i], lane_xor<7>(up ? k8[i] : k8[4 + i]));
+    }
+    {
+        const bool up = (l31 >> 1) & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) k2[i] = fmaxf(up ? k4[2 + i] : k4[i], lane_xor<2>(up ? k4[i] : k4[2 + i]));
+    }
+    const bool up = l31 & 1;
+    const float k1 = fmaxf(up ? k2[1] : k2[0], lane_xor<1>(up ? k2[0] : k2[1]));
+    return fmaxf(k1, lane_xor<16>(k1));
+}
 __device__ __forceinline__ int halving_elem16(int l31) {
     return 8 * ((l31 >> 3) & 1) + 4 * ((l31 >> 2) & 1) + 2 * ((l31 >> 1) & 1) + (l31 & 1);
 }

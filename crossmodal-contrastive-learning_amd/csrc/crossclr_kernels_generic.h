@@ -197,8 +197,11 @@ template <typename T, bool SW, int MODE, bool ST = false, bool SYM = false>
 __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
                                                        float* part, const float* kcols, const float* shift, float* stash, int* header,
                                                        float* colpart) {
-    static_assert(!ST || MODE == 0, "exponentials are saved by the single-pass forward only");
-    static_assert(!SYM || MODE == 0, "symmetric evaluation: single-pass sums only");
+    static_assert(!ST || MODE == 0 || MODE == 2, "exponentials are saved by the passes that form sums");
+    static_assert(!SYM || MODE == 0 || MODE == 1 || MODE == 2, "symmetric evaluation: the soft-max passes");
+    // MODE 2 (per-row shifts): U[p][q] = exp2(x - shift[p]) is NOT symmetric.  The mirrored tile's sums, and the backward
+    // (weight U[p][q] rz_p + U[q][p] rz_q), need exp2(x - shift[q]) as well: a second exponential per element; ST keeps both
+    // matrices -- U, and Ut[p][q] = U[q][p] behind it at stash + (2 bpad)^2 -- in the layout of the single-pass stash.
     typedef Operand<T> Op;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) es[qi][r] = 0.f;
+                for (int r = 0; r < 16; ++r) es[qi][r] = MODE == 1 ? -3.0e38f : 0.f;
         }
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
@@ -303,7 +306,8 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                 for (int r4 = 0; r4 < 4; ++r4) {
                     f32x4 kq = {1.f, 1.f, 1.f, 1.f};
                     if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
-                    f32x4 ev = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 ev = {0.f, 0.f, 0.f, 0.f}, etv = {0.f, 0.f, 0.f, 0.f}, shq = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == 2 && (ST || SYM)) shq = *reinterpret_cast<const f32x4*>(shift + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * r4 + j;
@@ -312,27 +316,39 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                         if (MODE == 1) {
                             const float x = acc[qi][pi][r] * c2;
                             if (!masked && !(SW && kq[j] == 0.f)) rowacc[pi] = fmaxf(rowacc[pi], x);
+                            // mirrored tile: row p is a column of row q's soft-max (not when its k is 0 inside a modality)
+                            if (SYM && !masked && !pad_row && !(SW && same_mod && kp[pi] == 0.f)) es[qi][r] = fmaxf(es[qi][r], x);
                         } else if (MODE == 3) {
                             const float h = g.m2 + acc[qi][pi][r] - myshift[pi];
                             if (!masked && h > 0.f) { rowacc[pi] += h; rowcnt[pi] += 1.f; }
                         } else if (MODE == 4) {
                             if (diag_tile && q_t == p_t) rowacc[pi] += acc[qi][pi][r];
                         } else {
-                            float e = fast_exp2(acc[qi][pi][r] * c2 - (MODE == 2 ? myshift[pi] : g.m2));
+                            const float x2 = acc[qi][pi][r] * c2;
+                            float e = fast_exp2(x2 - (MODE == 2 ? myshift[pi] : g.m2));
                             if (masked) e = 0.f;
                             ev[j] = e;
-                            if (SYM) es[qi][r] += pad_row ? 0.f : ((SW && same_mod) ? e * kp[pi] : e);
+                            float et = e;            // relative to the COLUMN's shift (single pass: one shift, symmetric matrix)
+                            if (MODE == 2 && (ST || SYM)) { et = fast_exp2(x2 - shq[j]); if (masked) et = 0.f; }
+                            etv[j] = et;
+                            if (SYM) es[qi][r] += pad_row ? 0.f : ((SW && same_mod) ? et * kp[pi] : et);
                             if (SW) e *= kq[j];
                             rowacc[pi] += e;
                         }
                     }
                     if (ST) {
                         const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (ct.row0 + 64 * wc + 32 * qi) >> 5;
+                        const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);     // floats of one matrix
                         *reinterpret_cast<f32x4*>(stash + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = ev;
+                        if (MODE == 2) *reinterpret_cast<f32x4*>(stash + nn + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = etv;
                         if (SYM && mirror) {   // fragment (q32, p32): lane' = column q, element of row p at [p >> 3][half' = (p >> 2) & 1][p & 3]
                             float* tf = stash + ((q32 * (size_t)(2 * g.bpad / 32) + p32) << 10) + 256 * (l31 >> 3) + 128 * ((l31 >> 2) & 1) + (l31 & 3);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) tf[4 * (8 * r4 + 4 * half + j)] = pad_row ? 0.f : ev[j];
+                            for (int j = 0; j < 4; ++j) tf[4 * (8 * r4 + 4 * half + j)] = pad_row ? 0.f : etv[j];      // U[q][p]
+                            if (MODE == 2) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) tf[nn + 4 * (8 * r4 + 4 * half + j)] = pad_row ? 0.f : ev[j];   // Ut[q][p] = U[p][q]
+                            }
                         }
                     }
                 }
@@ -341,12 +357,13 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
             if (mirror) {
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
-                    const float cs = halving_sum16(es[qi], l31);
+                    const float cs = MODE == 1 ? halving_max16(es[qi], l31) : halving_sum16(es[qi], l31);
                     if (l31 < 16) red[wr * 128 + 64 * wc + 32 * qi + frag_row(halving_elem16(l31), half)] = cs;
                 }
             }
             __syncthreads();
-            if (mirror && tid < 128) colpart[(size_t)rbk * 2 * g.bpad + (size_t)t * 128 + tid] = red[tid] + red[128 + tid];
+            if (mirror && tid < 128)
+                colpart[(size_t)rbk * 2 * g.bpad + (size_t)t * 128 + tid] = MODE == 1 ? fmaxf(red[tid], red[128 + tid]) : red[tid] + red[128 + tid];
             __syncthreads();
         }
     }
@@ -404,12 +421,18 @@ __global__ void __launch_bounds__(256) score_finish_kernel(const float* part, co
 }
 // pass 1 of the two-pass soft-max, second half: shift[p] = max(slot maxima, own previous value if `accumulate`, and the masked
 // self pair's logit 0 when it is part of the row's soft-max: k_p != 0)
+// colpart != NULL: the launch evaluated the upper triangle only (SYM): the column maxima the row blocks above left behind count too
 __global__ void __launch_bounds__(256) rowmax_combine_kernel(const float* part, int nslots, int n, const float* krows, int accumulate,
-                                                             float* shift) {
+                                                             float* shift, const float* colpart) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     float m = accumulate ? shift[p] : ((krows && krows[p] == 0.f) ? -3.0e38f : 0.f);
     for (int k = 0; k < nslots; ++k) m = fmaxf(m, part[(size_t)k * n + p]);
+    if (colpart) {
+        // (a column with k_p = 0 inside its modality is not in anybody's soft-max, but as a ROW it still has one: its own
+        //  maxima came from the slots; the mirrored maxima were formed with the row-side rule of the kernel)
+        for (int k = 0; k < p / 128; ++k) m = fmaxf(m, colpart[(size_t)k * n + p]);
+    }
     shift[p] = m;
 }
 

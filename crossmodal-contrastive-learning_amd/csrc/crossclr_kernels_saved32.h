@@ -17,7 +17,9 @@
 
 namespace crossclr {
 
-template <int DC, bool SW>
+// RM (two-pass soft-max, small temperatures): the stash holds U[p][q] = exp2(x - shift_p) and, behind it, Ut[p][q] = U[q][p];
+// rz = omega / (row sum relative to the ROW's shift), so the weight is U[p][q] rz_p + Ut[p][q] rz_q.
+template <int DC, bool SW, bool RM = false>
 __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, const float* stash, Geo g, const float* rz, const float* wrz,
                                                              float* gbuf, int accumulate, int tiles_per_slice, const float* k) {
     constexpr int QT = 32;
@@ -61,13 +63,15 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
     };
     // fragment (p32, t) of the stash: [r4][lane][4]
     const float* frag_row0 = stash + (((size_t)(row0 / 32 + wr) * (size_t)NQ) << 10) + 4 * lane;
-    f32x4 e[4], rq[4], kq[4];
+    f32x4 e[4], et[4], rq[4], kq[4];
+    const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);
     auto fetch = [&](int t) {
         const bool same = (t * QT >= g.bpad) == (rmod == 1);
         const float* stat = (same ? wrz : rz) + t * QT + 4 * half;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             e[r4] = *reinterpret_cast<const f32x4*>(frag_row0 + ((size_t)t << 10) + 256 * r4);
+            if (RM) et[r4] = *reinterpret_cast<const f32x4*>(frag_row0 + nn + ((size_t)t << 10) + 256 * r4);
             rq[r4] = *reinterpret_cast<const f32x4*>(stat + 8 * r4);
             if (SW) kq[r4] = *reinterpret_cast<const f32x4*>(k + t * QT + 4 * half + 8 * r4);
         }
@@ -85,7 +89,8 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
         for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                w[4 * r4 + j] = (SW && same) ? e[r4][j] * (rzp * kq[r4][j] + rq[r4][j] * kp) : e[r4][j] * (rzp + rq[r4][j]);
+                w[4 * r4 + j] = RM ? ((SW && same) ? e[r4][j] * rzp * kq[r4][j] + et[r4][j] * rq[r4][j] * kp : e[r4][j] * rzp + et[r4][j] * rq[r4][j])
+                                   : ((SW && same) ? e[r4][j] * (rzp * kq[r4][j] + rq[r4][j] * kp) : e[r4][j] * (rzp + rq[r4][j]));
         if (t + 1 < t_stop) { issue_x(t + 1, stage ^ 1); fetch(t + 1); }
         // G[p][d] += W[p][q] X[q][d]: k-slot `half` of step (kk, j) is column q = 8 kk + 4 half + j -- the fragment's own order
         const unsigned char* xs = lds + stage * STG + ((4 * half) * DC + wc * (DC / 2) + l31) * 4;

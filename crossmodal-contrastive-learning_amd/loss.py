@@ -398,7 +398,14 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
         gather.wait()
         nat.check(lib.crossclr_forward_rowmax(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(part),
                                               _ptr(ws.shift), 1, stream))
-    nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, stream))
+    # second pass over the local block; with a backward to follow (exact-fp32 plans) it also saves the exponentials relative to the
+    # row's and to the column's shift, and the backward does not recompute the similarity product
+    sbytes = lib.crossclr_stash_bytes_s(pp) if needs_backward else 0
+    if sbytes:
+        ws.stash = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        nat.check(lib.crossclr_forward_save_s(pp, _ptr(ws.xhat), T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, _ptr(ws.stash), stream))
+    else:
+        nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, stream))
     nlaunch = 1
     if ws.sharded:
         nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(ws.shift), _ptr(part),
@@ -434,9 +441,14 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
     rank, world = ws.rank, ws.world
     rz_loc, wrz_loc = ws.rz, ws.wrz   # column statistics of the local block = this rank's row statistics
     if ws.shift is not None:   # two-pass (small temperature) regime: generic kernels with per-row shifts
-        nat.check(lib.crossclr_backward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
-                                          _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None),
-                                          _ptr(ws.shift), _ptr(ws.shift), _ptr(gbuf), 0, stream))
+        if ws.stash is not None:
+            nat.check(lib.crossclr_backward_saved_s(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w, _ptr(ws.rz),
+                                                    _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
+            ws.stash = None
+        else:
+            nat.check(lib.crossclr_backward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                              _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None),
+                                              _ptr(ws.shift), _ptr(ws.shift), _ptr(gbuf), 0, stream))
         if ws.sharded:
             if ws.wrz_cols is None:
                 ws.stats_work.wait()

@@ -201,6 +201,17 @@ int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float tem
 int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash,
                             float temperature, float negative_weight, const float* rz, const float* wrz,
                             const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+/* Two-pass regime, save-for-backward pair (exact-fp32 plans, local block; ABI 3): the second pass also leaves
+ * U[p][q] = exp2(x_pq - shift_p) and Ut[p][q] = U[q][p] behind (crossclr_stash_bytes_s = twice plan->stash_bytes, 0 = not
+ * available), and the backward forms the weights U rz_p + Ut rz_q from them instead of recomputing the similarity product
+ * (replaces autograd of loss.py:96-100, 59-60 like crossclr_backward_saved).  `shift` = the row maxima of crossclr_forward_rowmax. */
+size_t crossclr_stash_bytes_s(const crossclr_plan* plan);
+int crossclr_forward_save_s(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
+                            const crossclr_sample_weights* sw, const float* shift, float* part, int slot0, void* stash, void* stream);
+int crossclr_backward_saved_s(const crossclr_plan* plan, const void* xhat, const void* stash, float temperature,
+                              float negative_weight, const float* rz, const float* wrz, const crossclr_sample_weights* sw,
+                              float* gbuf, int accumulate, void* stream);
+
 
 /* ---- sharded step: rectangular blocks with saved exponentials (ABI version 3) -------------------------------------------
  * In a sharded run this rank evaluates, besides its local block, the blocks of its pair partners (ranks rank+1 ..

@@ -3,6 +3,8 @@ lane on host threads through the emulation shim in tests/emu/ and checked agains
 golden vectors.  Shapes are tiny (the emulation runs one OS thread per GPU lane); the same code at
 full size is covered by the `-m gpu` tests.  The emulated library is injected explicitly here --
 the product binding never selects it."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -313,3 +315,37 @@ def test_generic_forward_only_evaluates_the_upper_triangle(B, D, weighted, monke
     if not weighted:
         ref = float(orc.streaming_loss_and_grads(v, t, 0.05, 0.8)["loss"])
         assert abs(sym - ref) <= 1e-5 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("B,D,weighted,sym", [(70, 24, False, True), (150, 40, False, True), (150, 24, True, True), (150, 24, True, False)])
+def test_two_pass_regime_saves_both_exponential_matrices(B, D, weighted, sym, monkeypatch):
+    """tau = 0.004 (max |logit| 250 > 128), compute_mode="fp32": the second pass saves U[p][q] = exp2(x - shift_p) and
+    Ut[p][q] = U[q][p] (crossclr_forward_save_s) and the backward forms U rz_p + Ut rz_q from them (crossclr_backward_saved_s);
+    same results as the recomputing two-pass backward (CROSSCLR_DISABLE_SAVE=1), with the symmetric evaluation of the second pass
+    and without it, and as the float64 oracle."""
+    if not sym:
+        monkeypatch.setenv("CROSSCLR_DISABLE_SYMMETRIC", "1")
+    plan = nat.make_plan(B, D, 1, 0, nat.MODE_FP32)
+    assert nat.library().crossclr_stash_bytes_s(ctypes.byref(plan)) == 2 * plan.stash_bytes > 0
+    v, t = orc.make_inputs("randn", B, D, 29)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(6)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.004, 0.8, compute_mode="fp32", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    ls, gvs, gts = step()
+    monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
+    lr, gvr, gtr = step()
+    assert abs(ls - lr) <= 2e-6 * max(1.0, abs(lr))
+    scale = max(gvr.abs().max().item(), gtr.abs().max().item())
+    assert (gvs - gvr).abs().max().item() <= 1e-5 * scale and (gts - gtr).abs().max().item() <= 1e-5 * scale
+    if not weighted:
+        ref = orc.streaming_loss_and_grads(v, t, 0.004, 0.8)
+        assert abs(ls - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"])))
+        assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 1e-3 * scale
