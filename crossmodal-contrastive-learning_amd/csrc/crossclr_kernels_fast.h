@@ -1059,8 +1059,22 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* co
         af[1] = __builtin_bit_cast(bf16x8, pk[1]);
     }
     int sx = 0, se = 0;
+    int warm = 0;      // iterations done, saturating at NSX - 1
     for (; t < t_end; ++t) {
-        if (!(CROSSCLR_SABL & 3)) wait_dma_keep<NKEEP>();      // X(t) has landed (and E / statistics of tile t+1, issued long before)
+        // X(t) has landed (and E / statistics of tile t+1, issued long before).  VMEM operations issued after X(t)'s last piece
+        // may still be in flight: in the steady state NKEEP; in the first NSX - 1 iterations X(t) is a tile of the prologue,
+        // which issued ALL its E pieces before its column tiles -- fewer operations follow it: (NSX-2) NXO + iterations * NEO.
+        // (Waiting for NKEEP there let the first two tiles of every block be read before they had landed: gradients of whole
+        // row blocks differed from launch to launch for Dpad < 512, where a tile is short.)
+        if (!(CROSSCLR_SABL & 3)) {
+            if (warm >= NSX - 1) wait_dma_keep<NKEEP>();
+            else {
+                static_assert(NSX == 3 || NSX == 2, "start-up waits are written out for NSX <= 3");
+                if (warm == 0) wait_dma_keep<(NSX - 2) * NXO>();
+                else wait_dma_keep<(NSX - 2) * NXO + NEO>();
+                ++warm;
+            }
+        }
         if (!(CROSSCLR_SABL & 32)) barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1
         const int sx_free = sx == 0 ? NSX - 1 : sx - 1;        // stage of tile t-1 = stage of tile t+NSX-1
         const int se_free = se == 0 ? NSE - 1 : se - 1;
