@@ -90,3 +90,24 @@ def test_retrieval_of_identical_sets_is_perfect_and_timed():
         e1.record()
         torch.cuda.synchronize()
         print(f"retrieval ranks B={B} D={D} {mode}: {e0.elapsed_time(e1) / 5:.3f} ms")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64])
+def test_max_margin_input_dtypes_and_strided_rows(dtype):
+    """Inputs in any float dtype of the reference, rows taken as a strided view: loss in the input dtype (like the reference's
+    eager ops), gradients in the input dtype, values within the dtype's resolution of the float64 closed form on the same rows."""
+    g = torch.Generator().manual_seed(8)
+    big_a, big_b = torch.randn(200, 2 * 80, generator=g), torch.randn(200, 2 * 80, generator=g)
+    a = torch.nn.functional.normalize(big_a[:, :80], dim=1).to(dtype).cuda()
+    b = torch.nn.functional.normalize(big_b[:, :80], dim=1).to(dtype).cuda()
+    wide_a = torch.zeros(200, 160, dtype=dtype, device="cuda"); wide_a[:, :80] = a
+    av = wide_a[:, :80].requires_grad_(True)          # row stride 160
+    bv = b.clone().requires_grad_(True)
+    loss = crossclr_amd.max_margin_loss(av, bv, 0.1, compute_mode="fp32")
+    loss.backward()
+    assert loss.dtype == dtype and av.grad.dtype == dtype and av.grad.shape == av.shape
+    st = rk.max_margin_streaming(a.cpu().double(), b.cpu().double(), 0.1)
+    eps = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2, torch.float64: 1e-6}[dtype]
+    assert abs(loss.item() - float(st["loss"])) <= eps * max(1.0, abs(float(st["loss"])))
+    scale = float(st["grad_im"].abs().max())
+    assert (av.grad.double().cpu() - st["grad_im"]).abs().max().item() <= max(eps, 2e-3) * scale * 4
