@@ -33,3 +33,30 @@ def test_every_step_is_bit_identical(B, D, mode, weighted):
             assert torch.isfinite(ref[0]) and torch.isfinite(ref[1]).all() and torch.isfinite(ref[2]).all()
         else:
             assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]) and torch.equal(cur[2], ref[2])
+
+
+@pytest.mark.parametrize("what", ["two-pass fp32", "two-pass bf16", "max-margin", "retrieval"])
+def test_other_paths_are_bit_identical_too(what):
+    g = torch.Generator().manual_seed(17)
+    B, D = 1536, 200
+    v = torch.randn(B, D, generator=g).cuda().requires_grad_(True)
+    t = torch.randn(B, D, generator=g).cuda().requires_grad_(True)
+    ref = None
+    for _ in range(25):
+        v.grad = t.grad = None
+        if what.startswith("two-pass"):
+            loss = crossclr_amd.crossclr_loss(v, t, 0.004, 0.8, compute_mode=what.split()[1])
+        elif what == "max-margin":
+            loss = crossclr_amd.max_margin_loss(torch.nn.functional.normalize(v, dim=1), torch.nn.functional.normalize(t, dim=1), 0.1,
+                                                compute_mode="bf16")
+        else:
+            r = crossclr_amd.retrieval_ranks(v.detach(), t.detach())
+            cur = (r["v2t_ranks"].clone(), r["t2v_ranks"].clone(), r["v2t"].clone())
+            loss = None
+        if loss is not None:
+            loss.backward()
+            cur = (loss.detach().clone(), v.grad.clone(), t.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(cur, ref))
