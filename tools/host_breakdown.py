@@ -43,3 +43,15 @@ for Bx in (256, 1024, 2048):
     for _ in range(1000): stepb()
     torch.cuda.synchronize(); t1 = time.perf_counter()
     print(f"B={Bx}: eager fwd + bwd: {1e6*(t1-t0)/1000:7.1f} us/step (wall, GPU drained)")
+# the same loop with autograd's multithreading switched off (the backward then runs on the calling thread: no hand-over)
+for Bx in (256, 1024, 2048):
+    vb = torch.randn(Bx, D, generator=g).cuda().requires_grad_(True); tb = torch.randn(Bx, D, generator=g).cuda().requires_grad_(True)
+    def stepb():
+        vb.grad = tb.grad = None
+        crit(vb, tb).backward()
+    with torch.autograd.set_multithreading_enabled(False):
+        for _ in range(100): stepb()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(1000): stepb()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"B={Bx}: eager fwd + bwd, torch.autograd.set_multithreading_enabled(False): {1e6*(t1-t0)/1000:7.1f} us/step")
