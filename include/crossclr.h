@@ -194,8 +194,11 @@ int crossclr_forward_add(const crossclr_plan* plan, float* part, int slot0, cons
  * E = exp(logit - shift) of the upper triangle of the stacked 2b x 2b matrix to `stash` (plan->stash_bytes bytes,
  * 0.27 GB at b = 8192; caller-owned), and crossclr_backward_saved is crossclr_backward_w for the same block fed from
  * that stash instead of recomputing the similarity product: it executes the algorithmic 8 b^2 D flop instead of
- * 16 b^2 D.  Available when plan->stash_bytes > 0 (bf16 register-resident path, Dpad <= 512); `stash` must reach the
- * backward unmodified.  sw->neg_scale_rows (== the columns') and rz/wrz are this rank's [2][bpad] arrays.            */
+ * 16 b^2 D.  Available when plan->stash_bytes > 0: the bf16 register-resident path (Dpad <= 1024; bf16 exponentials, upper
+ * triangle, 2 KiB per 32 x 32 tile) and CROSSCLR_MODE_FP32 plans (the fp32 exponentials of the whole stacked matrix, 4 KiB per
+ * 32 x 32 fragment in the forward's register layout: (2 bpad)^2 * 4 bytes, offered up to 16 GiB).  The layout is private to the
+ * pair; `stash` must reach the backward unmodified.  sw->neg_scale_rows (== the columns') and rz/wrz are this rank's
+ * [2][bpad] arrays.                                                                                                    */
 int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
                           const crossclr_sample_weights* sw, float* part, int slot0, void* stash, void* stream);
 int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash,
