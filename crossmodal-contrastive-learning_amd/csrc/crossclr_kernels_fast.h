@@ -189,16 +189,13 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 #endif
 
 #ifndef CROSSCLR_TUNE
-#define CROSSCLR_TUNE 0   // A/B switches: bit0 draining barrier in fast_fwd_kernel, bit1 no per-MFMA fence in fast_bwd16_kernel, bit2 draining barrier there
+#define CROSSCLR_TUNE 0   // A/B switches: bit0 (unused), bit1 no per-MFMA fence in fast_bwd16_kernel, bit2 draining barrier there
 #endif
 #ifndef CROSSCLR_FUSED_WAIT
 #define CROSSCLR_FUSED_WAIT 1   // counted LDS wait and MFMA in one asm statement (0: asm wait + builtin MFMA, with hipcc's pad in between)
 #endif
 #ifndef CROSSCLR_SABL
 #define CROSSCLR_SABL 0   // fast_bwd_saved_kernel timing ablations (WRONG results): bit0 no E DMA, bit1 no X DMA, bit2 no weight VALU, bit3 no MFMA, bit4 no X transpose reads, bit5 no barrier
-#endif
-#ifndef CROSSCLR_FABL
-#define CROSSCLR_FABL 0   // forward timing ablations (WRONG results): bit0 no exp epilogue, bit1 no MFMA loop, bit2 no DMA/barrier, bit3 no column-sum butterfly
 #endif
 #ifndef CROSSCLR_FWD_PF
 #define CROSSCLR_FWD_PF 2
@@ -308,259 +305,21 @@ static inline int fwd_max_slots(const FwdWork& w) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward denominators, persistent: NW waves x 32 rows per block (NW = 8, two waves per SIMD, for Dpad <= 512;
-// NW = 4, one wave per SIMD with the 512-register budget, for Dpad <= 1024), 32-column tiles in a 4-deep
-// (2-deep when the tile is 48/64 KiB) LDS-DMA ring that keeps running across row-block boundaries, counted
-// s_waitcnt vmcnt(N), one barrier per tile.  A block re-reads its row fragments only when its range of the work list
-// crosses into the next row block.
-//  SYM: the stacked 2B x 2B matrix of exponentiated logits is symmetric, so only tiles at or right of
-//    a row block's own columns are evaluated; a tile strictly right of the diagonal block also
-//    yields the COLUMN sums of its 32 columns over the block's rows -- the row sums of the
-//    mirrored tile that is never computed.  Column sums: per-wave halving_sum16 in registers, then
-//    the waves' values meet in an LDS slot and are written by 32 threads one barrier later
-//    (the ring barrier of the next tile) to colpart[row block][column]: fixed order, no atomics,
-//    nothing to zero.
-// ---------------------------------------------------------------------------------------------
-//  SW (sample weights, include/crossclr.h): the exponential of an intra-modal column q counts k_q times in the row
-//    sums, and -- mirrored -- the exponential of row p counts k_p times in the column sums; the tile's 32 k_q ride
-//    along with the tile DMA (one more 128-byte LDS-DMA per tile).
-//  SYM = 2 ("pairs", sharded runs): rectangular like SYM = 0, but EVERY tile also yields its column sums over this rank's
-//    rows -- the row sums the column ranks would otherwise have to compute themselves from the transposed block.
-//  ST (save for backward, SYM = 1 only): every evaluated 32x32 tile of exponentials is also written to `stash` as bf16, in
-//    the layout of the MFMA A fragment the backward feeds on (lane = row p, 8 k-slots per 16-column half: the C layout
-//    of this kernel's product, so the store is two coalesced 1-KiB wave stores and costs 8 v_cvt_pk per tile).  Tile
-//    (r32, t) -- 32-row group r32, 32-column tile t >= NW * (r32 / NW) -- lives at stash_tile_index(...) * 2 KiB.
+// The persistent forward itself is fast_fwd_pipe_kernel (crossclr_kernels_sym.h); what it shares with the backward kernels
+// of this file lives here: the work list above and the layout of the saved exponentials.
+//  ST (save for backward): every evaluated 32x32 tile of exponentials is also written to `stash` as bf16, in the layout of
+//    the MFMA A fragment the backward feeds on (lane = row p, 8 k-slots per 16-column half: the C layout of the forward's
+//    product, so the store is two coalesced 1-KiB wave stores and costs 8 v_cvt_pk per tile).  Symmetric launch: tile
+//    (r32, t) -- 32-row group r32, 32-column tile t >= tpr * (r32 / tpr) -- lives at stash_tile_index(...) * 2 KiB
+//    (tpr = 32-row groups per row block of the forward: 8 for Dpad <= 512, 4 above).
 //    fast_bwd_saved_kernel turns it into W = E (1/Z_p + 1/Z_q) without recomputing the similarity product.
+// ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ size_t stash_tile_index(int tpr, int NT, int r32, int t) {
     const size_t rb = (size_t)(r32 / tpr), w = (size_t)(r32 % tpr);
     const size_t before = (size_t)tpr * (rb * NT - (size_t)(tpr / 2) * rb * (rb - 1));   // tiles of row blocks < rb
     return before + w * ((size_t)NT - tpr * rb) + ((size_t)t - tpr * rb);
 }
 static inline size_t stash_tiles_total(int tpr, int NT) { return stash_tile_index(tpr, NT, NT, NT); }
-
-template <int DK, int SYM, int NW, bool SW, bool ST = false>
-__global__ void __launch_bounds__(64 * NW, NW / 4) fast_fwd_kernel(const bf16_t* rows, const bf16_t* cols, Geo g, FwdWork wk,
-                                                          float* part, float* colpart, int* header,
-                                                          const float* krows, const float* kcols,
-                                                          unsigned char* stash) {
-    static_assert(!ST || SYM == 1, "the exponentials are saved by the symmetric launch only");
-    constexpr int RB = DK * 32;            // bytes per operand row
-    constexpr int QT = 32;
-    constexpr int TILE = QT * RB;
-    constexpr int RPB = 32 * NW;           // rows per thread block
-    constexpr int NST = (4 * TILE + 4096 <= 160 * 1024) ? 4 : 2;
-    constexpr int NOPS = QT * RB / 1024 / NW + (SW ? 1 : 0);  // VMEM wave-instructions per tile per wave
-    constexpr int CS = NW * QT * 4;        // one column-sum slot: [NW waves][32 columns] floats
-    constexpr int KQ0 = NST * TILE + (SYM ? 2 * CS : 0);   // [NST][32] floats: k of the tile's columns
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[KQ0 + (SW ? NST * 128 : 0)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    if (blockIdx.x == 0 && tid == 0) {  // tell crossclr_forward_finish how this launch laid out its slots
-        header[0] = wk.kind; header[1] = wk.tpr; header[2] = wk.NT; header[3] = wk.per;
-    }
-    const int per_rank = 2 * g.bpad / QT;
-    const int skip_seg = (SYM == 0 && g.skip_rank >= 0) ? g.skip_rank - g.col_rank0 : -1;
-    // flat work items [w, w_end): item -> (row block, column tile)
-    int w = blockIdx.x * wk.per;
-    int w_end = w + wk.per;
-    if (w_end > wk.total) w_end = wk.total;
-    struct Cursor { int rb, j; };  // j = index inside the row block's tile list
-    auto tile_of = [&](const Cursor& c) {
-        if (SYM == 1) return NW * c.rb + c.j;
-        return (skip_seg >= 0 && c.j >= skip_seg * per_rank) ? c.j + per_rank : c.j;
-    };
-    auto advance = [&](Cursor& c) {
-        const int n = SYM == 1 ? wk.NT - NW * c.rb : wk.NT;
-        if (++c.j == n) { c.j = 0; ++c.rb; }
-    };
-    Cursor cur;
-    {
-        int rb = 0;
-        while (fwd_prefix(wk, rb + 1) <= w) ++rb;
-        cur.rb = rb;
-        cur.j = w - fwd_prefix(wk, rb);
-    }
-    const size_t pitch = RB;
-    auto issue = [&](const Cursor& c, int stage) {
-        const ColTile ic = col_tile(g, tile_of(c), QT);
-        issue_tile_dma<RB, NW, QT>(reinterpret_cast<const unsigned char*>(cols) + ic.row0 * pitch, lds + stage * TILE, wave, lane,
-                                  SW ? kcols + ic.stat0 : nullptr, lds + KQ0 + stage * 128);
-    };
-    auto wait_keep = [&](int tiles_in_flight) {
-        if (tiles_in_flight >= 2) wait_dma_keep<2 * NOPS>();
-        else if (tiles_in_flight == 1) wait_dma_keep<NOPS>();
-        else wait_dma();
-    };
-    int off8[8];  // byte offset of logical chunk (2j + half) + 16*hi of this lane's tile row
-#pragma unroll
-    for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
-
-    // symmetric mode: column sums of the previous tile wait in cs[pbuf] for the next barrier
-    float* cs = reinterpret_cast<float*>(lds + NST * TILE);
-    bool pending = false;
-    int ptile = 0, pbuf = 0, prb = 0;
-    auto flush = [&]() {
-        if (tid < QT) {
-            const float* c = cs + pbuf * (NW * QT);
-            float sum = c[tid];
-#pragma unroll
-            for (int k = 1; k < NW; ++k) sum += c[k * QT + tid];
-            colpart[(size_t)prb * wk.NT * QT + QT * ptile + tid] = sum;   // row stride = all columns of this launch
-        }
-    };
-    // ring: cq[0] = item w being consumed, cq[1..NST-2] in flight, cq[NST-1] issued after the next barrier
-    Cursor cq[NST];
-    cq[0] = cur;
-#pragma unroll
-    for (int k = 1; k < NST; ++k) { cq[k] = cq[k - 1]; advance(cq[k]); }
-#pragma unroll
-    for (int k = 0; k < NST - 1; ++k)
-        if (w + k < w_end) issue(cq[k], k);
-    int stage = 0;
-    int my_rb = -1, row0w = 0, rmod = 0, r_in_mod = 0;
-    float rowacc = 0.f, kp = 1.f;
-    size_t st_tile0 = 0;   // ST: stash index of this wave's tile j = 0 of the current row block
-    bf16x8 pf[DK];
-    auto store_rows = [&]() {
-        float v = rowacc + wave_xor_f32(rowacc, 32);
-        if (half == 0) part[(size_t)(blockIdx.x - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + l31] = v;
-    };
-    while (w < w_end) {
-        if (cq[0].rb != my_rb) {  // (re)load this wave's 32 rows as MFMA B fragments
-            if (my_rb >= 0) store_rows();
-            my_rb = cq[0].rb;
-            rowacc = 0.f;
-            row0w = my_rb * RPB + 32 * wave;
-            rmod = row0w / g.bpad;
-            r_in_mod = row0w - rmod * g.bpad + l31;
-            if (SW) kp = krows[row0w + l31];
-            if (ST) st_tile0 = stash_tile_index(NW, wk.NT, NW * my_rb + wave, NW * my_rb);
-            if (CROSSCLR_FABL & 16) {
-#pragma unroll
-                for (int ks = 0; ks < DK; ++ks) {
-                    u32x4 v = {(unsigned)lane, (unsigned)ks, (unsigned)wave, 7u};
-                    pf[ks] = __builtin_bit_cast(bf16x8, v);
-                }
-            } else {
-                const bf16_t* src = rows + (size_t)(row0w + l31) * (DK * 16) + 8 * half;
-#pragma unroll
-                for (int ks = 0; ks < DK; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
-            }
-        }
-        const int t = tile_of(cq[0]);
-        if (!(CROSSCLR_FABL & 4)) {
-            int inflight = 0;
-#pragma unroll
-            for (int k = 1; k < NST - 1; ++k) inflight += (w + k < w_end);
-            wait_keep(inflight);
-#if CROSSCLR_TUNE & 1
-            __syncthreads();
-#else
-            barrier_keep_dma();  // item w landed everywhere; every wave is done with item w-1's stage (LDS ops only: the ring stays in flight)
-#endif
-            if (w + NST - 1 < w_end) issue(cq[NST - 1], (stage + NST - 1) % NST);
-        }
-        if (SYM && pending) { flush(); pending = false; }
-        const ColTile ct = col_tile(g, t, QT);
-        const unsigned char* bt = lds + stage * TILE;
-        f32x16 acc, acc_odd;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_odd[r] = 0.f; }
-        if (CROSSCLR_FABL & 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bt[r] * 0.01f;
-        } else {
-            // two accumulator chains (even / odd k-steps) so consecutive MFMAs are independent
-            constexpr int FPF = (CROSSCLR_FWD_PF < DK / 2) ? CROSSCLR_FWD_PF : DK / 2;
-            bf16x8 ring[FPF];
-#pragma unroll
-            for (int i = 0; i < FPF; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(bt + off8[i & 7] + (i >> 3) * 256);
-#pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                const bf16x8 a = ring[ks % FPF];
-                if (ks + FPF < DK)
-                    ring[ks % FPF] = *reinterpret_cast<const bf16x8*>(bt + off8[(ks + FPF) & 7] + ((ks + FPF) >> 3) * 256);
-                if (ks & 1) acc_odd = mfma_32x32x16_bf16(a, pf[ks], acc_odd);
-                else acc = mfma_32x32x16_bf16(a, pf[ks], acc);
-            }
-            SCHED_PIPELINE(DK, 1, FPF);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += acc_odd[r];
-        }
-        const bool same_mod = (ct.mod == rmod);
-        const float c2s = same_mod ? g.c_intra : g.c_inter;
-        // scaled logits x = log2(e)/tau * s * cos - shift, in place
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = acc[r] * c2s - g.m2;
-        // masks as patches on the (rare) tiles that need them, so the common tile pays fma + exp + add
-        // per element and no compare/select: exp2(-inf) = 0 whatever the sign of negative_weight
-        const float ninf = -__builtin_inff();
-        if (ct.in_mod0 + QT > g.b) {  // ragged tile: columns beyond the valid batch
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ct.in_mod0 + frag_row(r, half) >= g.b) acc[r] = ninf;
-        }
-        if (same_mod && ct.rank == g.row_rank && ct.in_mod0 == (r_in_mod - l31)) {  // holds the diagonal
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (frag_row(r, half) == l31) acc[r] = ninf;
-        }
-        const bool upper = SYM == 2 || (SYM == 1 && t >= NW * (my_rb + 1));  // strictly right of the diagonal block / any pair tile
-        if (upper && (r_in_mod - l31) + 32 > g.b) {      // padding ROWS must not reach the column sums
-            if (r_in_mod >= g.b) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = ninf;
-            }
-        }
-        float e[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = (CROSSCLR_FABL & 1) ? acc[r] : fast_exp2(acc[r]);
-        if (ST) {   // save the tile for the backward: registers 8th .. 8th+7 are the A fragment of k-step th
-            const BufRsrc rs_st = make_rsrc(stash + (st_tile0 + (size_t)cq[0].j) * 2048, 2048u);
-#pragma unroll
-            for (int th = 0; th < 2; ++th) {
-                struct { bf16_t v[8]; } pk;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pk.v[j] = f32_to_bf16_bits(e[8 * th + j]);
-                buf_store16(rs_st, (unsigned)(lane * 16 + 1024 * th), 0u, __builtin_bit_cast(u32x4, pk));
-            }
-        }
-        if (SW && same_mod) {
-            const float* kq = reinterpret_cast<const float*>(lds + KQ0 + stage * 128);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kq + 8 * r4 + 4 * half);   // columns frag_row(4 r4 + j, half)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    rowacc += e[4 * r4 + j] * k4[j];
-                    e[4 * r4 + j] *= kp;        // what the mirrored tile's rows (these columns) see of row p
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rowacc += e[r];
-        }
-        if (upper) {
-            const float colsum = (CROSSCLR_FABL & 8) ? e[l31 & 15] : halving_sum16(e, l31);
-            pbuf ^= 1;
-            if (l31 < 16) cs[pbuf * (NW * QT) + wave * QT + frag_row(halving_elem16(l31), half)] = colsum;
-            pending = true;
-            ptile = SYM == 1 ? t : cq[0].j;   // column position inside this launch's column range
-            prb = my_rb;
-        }
-        stage = (stage + 1) % NST;
-        ++w;
-#pragma unroll
-        for (int k = 0; k < NST - 1; ++k) cq[k] = cq[k + 1];
-        advance(cq[NST - 1]);
-    }
-    if (SYM) {
-        __syncthreads();
-        if (pending) flush();
-    }
-    if (my_rb >= 0) store_rows();
-}
 
 // ---------------------------------------------------------------------------------------------
 // backward: 4 waves x 32 rows per block, ONE wave per SIMD so each wave owns the whole 512-entry
@@ -1470,33 +1229,10 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
     const bf16_t* c = (const bf16_t*)cols;
     dim3 grid(wk.nblk);
     const bool sw = krows != nullptr && kcols != nullptr;
-    static const bool old_fwd = getenv("CROSSCLR_FWD_KERNEL") && !strcmp(getenv("CROSSCLR_FWD_KERNEL"), "8wave");   // A/B knob
+    (void)r; (void)c; (void)grid; (void)sw;
     // software-pipelined 4-wave kernel (crossclr_kernels_sym.h): symmetric, rectangular and pairs
-    if (p->Dpad <= 1024 && !old_fwd)
-        return fast_forward_pipe(p, g, wk, rows, cols, part, colpart, header, symmetric ? 1 : (pairs ? 3 : 2), krows, kcols, nullptr, stream);
-#define CROSSCLR_LF2(DK, NW, SYM, SW) \
-    CROSSCLR_FAST_LAUNCH((fast_fwd_kernel<DK, SYM, NW, SW, false>), grid, dim3(64 * NW), stream, r, c, g, wk, part, colpart, header, krows, kcols, (unsigned char*)nullptr)
-#define CROSSCLR_LF(DK, NW)                                        \
-    do {                                                            \
-        if (pairs && sw) CROSSCLR_LF2(DK, NW, 2, true);             \
-        else if (pairs) CROSSCLR_LF2(DK, NW, 2, false);             \
-        else if (symmetric && sw) CROSSCLR_LF2(DK, NW, 1, true);    \
-        else if (symmetric) CROSSCLR_LF2(DK, NW, 1, false);         \
-        else if (sw) CROSSCLR_LF2(DK, NW, 0, true);                 \
-        else CROSSCLR_LF2(DK, NW, 0, false);                        \
-    } while (0)
-    switch (p->Dpad) {
-        case 128: CROSSCLR_LF(8, 8); break;
-        case 256: CROSSCLR_LF(16, 8); break;
-        case 384: CROSSCLR_LF(24, 8); break;
-        case 512: CROSSCLR_LF(32, 8); break;
-        case 768: CROSSCLR_LF(48, 4); break;
-        case 1024: CROSSCLR_LF(64, 4); break;
-        default: return CROSSCLR_E_ARG;
-    }
-#undef CROSSCLR_LF
-#undef CROSSCLR_LF2
-    return CROSSCLR_OK;
+    if (p->Dpad > 1024) return CROSSCLR_E_ARG;
+    return fast_forward_pipe(p, g, wk, rows, cols, part, colpart, header, symmetric ? 1 : (pairs ? 3 : 2), krows, kcols, nullptr, stream);
 }
 
 // the saved-exponentials pair (symmetric local block, Dpad <= 512): bytes of the stash, forward that fills it, backward that reads it

@@ -1,14 +1,14 @@
-// crossclr_kernels_sym.h -- the software-pipelined forward (Dpad <= 512): symmetric local block, rectangular remote blocks, pairs.
+// crossclr_kernels_sym.h -- the software-pipelined forward (Dpad <= 1024): symmetric local block, rectangular remote blocks, pairs.
 //
-// Same mathematics and the same workspace layouts as fast_fwd_kernel<DK, SYM, 8, SW> (reference trainer/loss.py:83-100, 59-60):
+// The persistent forward (reference trainer/loss.py:83-100, 59-60); workspace layouts: FwdWork / fwd_finish_kernel:
 //   KIND 1  symmetric: rows and columns are the same operand; upper triangle of the stacked 2b x 2b matrix of exponentials,
 //           the mirrored half recovered from column sums                                  (single device / local block)
 //   KIND 2  rectangular: this rank's rows against other ranks' columns (segments in memory order, one rank skipped)
 //   KIND 3  pairs: rectangular over ranks col_rank0, col_rank0+1, ... (mod col_wrap) of the whole gathered operand, and EVERY
 //           tile also yields its column sums over this rank's rows (what the column ranks would otherwise compute)
-// built differently from that kernel:
+// built like this:
 //   * 4 waves x 64 rows per 256-row block, ONE wave per SIMD (512 registers): both 32-row halves' fragments stay resident
-//     (2 x Dpad/4 registers), so one ds_read_b128 of the column tile feeds TWO MFMAs (half the LDS reads of the 8-wave kernel);
+//     (2 x Dpad/4 registers), so one ds_read_b128 of the column tile feeds TWO MFMAs (half the LDS reads of a 32-row wave);
 //   * the epilogue of tile t-1 (scale, exp2, row sums, bf16 pack + stash stores, 64-row column sums) is cut into chores that
 //     are pinned between the 64 MFMAs of tile t (sched_fence per k-step): with one wave per SIMD nothing else would hide them;
 //   * every LDS read is asm with hand-counted lgkmcnt, the barrier does not drain VMEM, the column tiles arrive by
