@@ -930,7 +930,14 @@ static int score_geo(const crossclr_plan* p, float margin, Geo* g) {
 }
 template <typename T>
 static void score_launch(const crossclr_plan* plan, const Geo& g, const void* x, float* out, float* cnt, const float* diag, int mode,
-                         void* stream) {
+                         void* stream, float* colpart = nullptr) {
+    if (mode == 3 && colpart) {   // one pass: rows of modality 0 against the column tiles of modality 1, column statistics for the rest
+        const int half_tiles = plan->bpad / 128, nsplit = plan->fwd_slots;
+        const int tps = (half_tiles + nsplit - 1) / nsplit;
+        LAUNCH((fwd_sums_kernel<T, false, 3, false, true>), dim3(plan->bpad / 128, nsplit), dim3(256), stream, (const T*)x, (const T*)x, g, tps, out,
+               (const float*)nullptr, diag, cnt, (int*)nullptr, colpart);
+        return;
+    }
     const int ntiles = 2 * plan->bpad / 128;
     const int nsplit = mode == 4 ? 1 : plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
@@ -955,12 +962,13 @@ extern "C" int crossclr_score_rows(const crossclr_plan* plan, const void* xhat, 
     if (int rc = score_geo(plan, margin, &g)) return rc;
     if (plan->fwd_slots <= 0) return fail(CROSSCLR_E_ARG, "bad plan");
     float* cnt = part + (size_t)plan->fwd_slots * 2 * plan->bpad;     // launch group 1 of the forward workspace
-    if (plan->mode == CROSSCLR_MODE_FP32) score_launch<float>(plan, g, xhat, part, cnt, diag, 3, stream);
-    else score_launch<bf16_t>(plan, g, xhat, part, cnt, diag, 3, stream);
+    float* colpart = env_knobs().disable_symmetric ? nullptr : part + ws_colpart_off(plan);   // one pass for both directions
+    if (plan->mode == CROSSCLR_MODE_FP32) score_launch<float>(plan, g, xhat, part, cnt, diag, 3, stream, colpart);
+    else score_launch<bf16_t>(plan, g, xhat, part, cnt, diag, 3, stream, colpart);
     if (int rc = launch_status("fwd_sums_kernel (score rows)")) return rc;
     const int nb = plan->loss_ws_doubles - 1;
     LAUNCH(score_finish_kernel, dim3(nb), dim3(256), stream, (const float*)part, (const float*)cnt, plan->fwd_slots, plan->bpad, plan->b,
-           hinge, active, loss_sum);
+           hinge, active, loss_sum, (const float*)colpart);
     // loss_sum[0] = sum of the hinges, loss_sum[1] = the reference's mean: / (B * B)   (trainer/loss.py:41)
     LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb, 1.0 / ((double)plan->b * (double)plan->b));
     return launch_status("score_finish_kernel");

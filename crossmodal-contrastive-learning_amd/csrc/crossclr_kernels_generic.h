@@ -198,7 +198,12 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                                                        float* part, const float* kcols, const float* shift, float* stash, int* header,
                                                        float* colpart) {
     static_assert(!ST || MODE == 0 || MODE == 2, "exponentials are saved by the passes that form sums");
-    static_assert(!SYM || MODE == 0 || MODE == 1 || MODE == 2, "symmetric evaluation: the soft-max passes");
+    static_assert(!SYM || MODE <= 3, "symmetric evaluation: the soft-max passes; MODE 3: one pass for both directions");
+    // MODE 3 + SYM (score statistics in ONE pass): only the rows of modality 0 are walked (grid.x = bpad / 128), against the column
+    // tiles of modality 1; every tile also yields, per column q, the hinge sum and the active count over the block's rows against
+    // the COLUMN's own positive-pair score shift[q] -- the statistics of the stacked rows of modality 1 -- into
+    // colpart[rb][q] (hinges) and colpart[bpad / 128 + rb][q] (counts).  The score matrix is evaluated once, not once per direction.
+    constexpr bool PAIRED = SYM && MODE != 3;      // the paired-row-block walk of the symmetric soft-max passes
     // MODE 2 (per-row shifts): U[p][q] = exp2(x - shift[p]) is NOT symmetric.  The mirrored tile's sums, and the backward
     // (weight U[p][q] rz_p + U[q][p] rz_q), need exp2(x - shift[q]) as well: a second exponential per element; ST keeps both
     // matrices -- U, and Ut[p][q] = U[q][p] behind it at stash + (2 bpad)^2 -- in the layout of the single-pass stash.
@@ -215,27 +220,28 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
     const int nchunks = g.Dpad / Op::kChunkElems;
 
     const int ntiles = g.col_ranks * 2 * g.bpad / 128;
-    if (SYM && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { header[0] = 4; header[1] = 4; header[2] = 0; header[3] = 0; }
+    if (PAIRED && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { header[0] = 4; header[1] = 4; header[2] = 0; header[3] = 0; }
     // SYM: row block I has ntiles - I tiles; it is paired with row block J = ntiles - 1 - I (I + 1 tiles) so that every
     // blockIdx.x owns ntiles + 1 tiles, cut evenly over the column splits: equal work for every thread block.  A block
     // therefore walks up to two segments (rows of I, then rows of J) and writes slot blockIdx.y of both row blocks.
     const int sym_total = ntiles + 1;
-    const int sym_k0 = SYM ? (int)((long)blockIdx.y * sym_total / (long)gridDim.y) : 0;
-    const int sym_k1 = SYM ? (int)((long)(blockIdx.y + 1) * sym_total / (long)gridDim.y) : 0;
-    for (int seg = 0; seg < (SYM ? 2 : 1); ++seg) {
-    const int rbk = !SYM ? (int)blockIdx.x : (seg == 0 ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x);   // row block of this segment
+    const int sym_k0 = PAIRED ? (int)((long)blockIdx.y * sym_total / (long)gridDim.y) : 0;
+    const int sym_k1 = PAIRED ? (int)((long)(blockIdx.y + 1) * sym_total / (long)gridDim.y) : 0;
+    for (int seg = 0; seg < (PAIRED ? 2 : 1); ++seg) {
+    const int rbk = !PAIRED ? (int)blockIdx.x : (seg == 0 ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x);   // row block of this segment
     const int seg_first = seg == 0 ? 0 : ntiles - (int)blockIdx.x;                                          // its place in the block's tile list
     const int row0 = rbk * 128;                  // first row of the segment inside [2][bpad]
     const int rmod = row0 / g.bpad;
     const int r_in_mod0 = row0 - rmod * g.bpad;
     const unsigned char* rbase = reinterpret_cast<const unsigned char*>(rows) + (size_t)row0 * pitch;
 
-    int t_begin = SYM ? rbk + (sym_k0 > seg_first ? sym_k0 - seg_first : 0) : (int)blockIdx.y * tiles_per_split;
-    int t_end = SYM ? rbk + (sym_k1 - seg_first) : t_begin + tiles_per_split;
+    int t_begin = PAIRED ? rbk + (sym_k0 > seg_first ? sym_k0 - seg_first : 0)
+                         : (SYM ? ntiles / 2 : 0) + (int)blockIdx.y * tiles_per_split;      // (MODE 3 + SYM: the tiles of modality 1)
+    int t_end = PAIRED ? rbk + (sym_k1 - seg_first) : t_begin + tiles_per_split;
     if (t_end > ntiles) t_end = ntiles;
     const int t_step = 1;
     float kp[2] = {1.f, 1.f};       // SYM + SW: k of this lane's rows (they are the mirrored tile's intra-modal negative columns)
-    if (SYM && SW) { kp[0] = kcols[row0 + 64 * wr + l31]; kp[1] = kcols[row0 + 64 * wr + 32 + l31]; }
+    if (PAIRED && SW) { kp[0] = kcols[row0 + 64 * wr + l31]; kp[1] = kcols[row0 + 64 * wr + 32 + l31]; }
 
     const float kNone = -3.0e38f;   // "no unmasked column yet" (MODE 1)
     float rowacc[2] = {MODE == 1 ? kNone : 0.f, MODE == 1 ? kNone : 0.f};
@@ -288,13 +294,13 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
         const float c2 = same_mod ? g.c_intra : g.c_inter;
         const bool diag_tile = (MODE >= 3 ? !same_mod : same_mod) && ct.rank == g.row_rank && ct.in_mod0 == r_in_mod0;
         const bool ragged = ct.in_mod0 + 128 > g.b;
-        const bool mirror = SYM && t > rbk;     // this tile also stands for its never-evaluated mirror image
-        float es[2][16];
+        const bool mirror = SYM && (MODE == 3 || t > rbk);     // this tile also stands for its never-evaluated mirror image
+        float es[2][16], ec[2][16];             // column side: sums / maxima / hinge sums; MODE 3: active counts
         if (SYM) {
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) es[qi][r] = MODE == 1 ? -3.0e38f : 0.f;
+                for (int r = 0; r < 16; ++r) { es[qi][r] = MODE == 1 ? -3.0e38f : 0.f; ec[qi][r] = 0.f; }
         }
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
@@ -307,7 +313,8 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                     f32x4 kq = {1.f, 1.f, 1.f, 1.f};
                     if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
                     f32x4 ev = {0.f, 0.f, 0.f, 0.f}, etv = {0.f, 0.f, 0.f, 0.f}, shq = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == 2 && (ST || SYM)) shq = *reinterpret_cast<const f32x4*>(shift + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
+                    if ((MODE == 2 && (ST || SYM)) || (MODE == 3 && SYM))
+                        shq = *reinterpret_cast<const f32x4*>(shift + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * r4 + j;
@@ -321,6 +328,10 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                         } else if (MODE == 3) {
                             const float h = g.m2 + acc[qi][pi][r] - myshift[pi];
                             if (!masked && h > 0.f) { rowacc[pi] += h; rowcnt[pi] += 1.f; }
+                            if (SYM) {   // the same score seen from column q: against ITS positive pair
+                                const float hc = g.m2 + acc[qi][pi][r] - shq[j];
+                                if (!masked && !pad_row && hc > 0.f) { es[qi][r] += hc; ec[qi][r] += 1.f; }
+                            }
                         } else if (MODE == 4) {
                             if (diag_tile && q_t == p_t) rowacc[pi] += acc[qi][pi][r];
                         } else {
@@ -365,6 +376,16 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
             if (mirror && tid < 128)
                 colpart[(size_t)rbk * 2 * g.bpad + (size_t)t * 128 + tid] = MODE == 1 ? fmaxf(red[tid], red[128 + tid]) : red[tid] + red[128 + tid];
             __syncthreads();
+            if (MODE == 3) {   // the active counts take the same route, into the second half of colpart
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    const float cs = halving_sum16(ec[qi], l31);
+                    if (l31 < 16) red[wr * 128 + 64 * wc + 32 * qi + frag_row(halving_elem16(l31), half)] = cs;
+                }
+                __syncthreads();
+                if (tid < 128) colpart[(size_t)(g.bpad / 128 + rbk) * 2 * g.bpad + (size_t)t * 128 + tid] = red[tid] + red[128 + tid];
+                __syncthreads();
+            }
         }
     }
     // combine the two lane halves, then the two column waves
@@ -393,19 +414,26 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
         __syncthreads();
         if (tid < 128) stash[(size_t)blockIdx.y * 2 * g.bpad + row0 + tid] = red[tid] + red[128 + tid];
     }
-    if (SYM) __syncthreads();    // (the next segment reuses `red`)
+    if (PAIRED) __syncthreads();    // (the next segment reuses `red`)
     }   // segments
 }
 // score statistics, second half: slot sums -> hinge[p], active[p] (a count, as float), and the block partial of sum_p hinge (double; added up
 // in index order by fwd_finish_reduce_kernel: deterministic)
+// colpart != NULL (one-pass evaluation): the stacked rows of modality 1 get their statistics from the column sums the row blocks
+// of modality 0 left behind (hinges: rows 0 .. bpad/128 - 1 of colpart, counts: the next bpad/128 rows), in row-block order
 __global__ void __launch_bounds__(256) score_finish_kernel(const float* part, const float* cnt, int nslots, int bpad, int b,
-                                                           float* hinge, float* active, double* loss_ws) {
+                                                           float* hinge, float* active, double* loss_ws, const float* colpart) {
     CROSSCLR_SHARED double sh[256];
     const int n = 2 * bpad;
     double acc = 0.0;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         float h = 0.f, c = 0.f;
-        for (int s = 0; s < nslots; ++s) { h += part[(size_t)s * n + p]; c += cnt[(size_t)s * n + p]; }
+        if (colpart && p >= bpad) {
+            const int nrb = bpad / 128;
+            for (int k = 0; k < nrb; ++k) { h += colpart[(size_t)k * n + p]; c += colpart[(size_t)(nrb + k) * n + p]; }
+        } else {
+            for (int s = 0; s < nslots; ++s) { h += part[(size_t)s * n + p]; c += cnt[(size_t)s * n + p]; }
+        }
         const bool valid = (p < bpad ? p : p - bpad) < b;
         hinge[p] = valid ? h : 0.f;
         active[p] = valid ? c : 0.f;
