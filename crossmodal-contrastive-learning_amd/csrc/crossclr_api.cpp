@@ -473,7 +473,7 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
         return launch_status("bwd_saved32_kernel");
     }
     rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, false, stream);
-    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_saved_kernel");
+    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel");
 #endif
 }
 
@@ -839,7 +839,7 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
     int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);
     if (rc) return rc;
     rc = fast_backward_saved(plan, g, xhat_all, stash, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, true, stream);
-    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_saved_kernel (rect)");
+    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel (rect)");
 #endif
 }
 

@@ -191,12 +191,6 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 #ifndef CROSSCLR_TUNE
 #define CROSSCLR_TUNE 0   // A/B switches: bit0 (unused), bit1 no per-MFMA fence in fast_bwd16_kernel, bit2 draining barrier there
 #endif
-#ifndef CROSSCLR_FUSED_WAIT
-#define CROSSCLR_FUSED_WAIT 1   // counted LDS wait and MFMA in one asm statement (0: asm wait + builtin MFMA, with hipcc's pad in between)
-#endif
-#ifndef CROSSCLR_SABL
-#define CROSSCLR_SABL 0   // fast_bwd_saved_kernel timing ablations (WRONG results): bit0 no E DMA, bit1 no X DMA, bit2 no weight VALU, bit3 no MFMA, bit4 no X transpose reads, bit5 no barrier
-#endif
 #ifndef CROSSCLR_FWD_PF
 #define CROSSCLR_FWD_PF 2
 #endif
@@ -312,7 +306,7 @@ static inline int fwd_max_slots(const FwdWork& w) {
 //    product, so the store is two coalesced 1-KiB wave stores and costs 8 v_cvt_pk per tile).  Symmetric launch: tile
 //    (r32, t) -- 32-row group r32, 32-column tile t >= tpr * (r32 / tpr) -- lives at stash_tile_index(...) * 2 KiB
 //    (tpr = 32-row groups per row block of the forward: 8 for Dpad <= 512, 4 above).
-//    fast_bwd_saved_kernel turns it into W = E (1/Z_p + 1/Z_q) without recomputing the similarity product.
+//    fast_bwd_dsl_kernel turns it into W = E (1/Z_p + 1/Z_q) without recomputing the similarity product.
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ size_t stash_tile_index(int tpr, int NT, int r32, int t) {
     const size_t rb = (size_t)(r32 / tpr), w = (size_t)(r32 % tpr);
@@ -565,359 +559,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_kernel(const bf16_t* rows, co
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward from the SAVED exponentials (single-device step / local block of a sharded run, Dpad <= 512).
-// The symmetric forward (ST) left every evaluated 32x32 tile of E = exp(logit - shift) in HBM as the bf16 A fragment
-// of this kernel's product, so the similarity product is not recomputed: per 32-column tile a wave only forms
-//   W[p][q] = E[p][q] * (omega_p/Z_p + omega_q/Z_q)            (2 ds_read_b128 or 4 transpose reads + 56 VALU)
-//   G[p][:] += W[p][q] . Xq[q][:]                               (32 MFMAs, B fragments by ds_read_b64_tr_b16)
-// i.e. it executes exactly the algorithmic 8 B^2 D flop (fast_bwd_kernel: 16 B^2 D).  The tile of the mirrored half
-// of the matrix (column tile t left of the wave's own 256-row block) was never evaluated: it is the TRANSPOSE of
-// stash tile (t, r32), read through the 16-lane transpose read from an image whose 16-byte chunks were permuted by
-// the DMA source address so that one tr-read delivers k-slots (q) for the lane's own row p -- after the read both
-// cases hold the same logical fragment and share all code.
-// 4 waves x 32 rows per block, ONE wave per SIMD (32 x Dpad fp32 accumulators = 256 AGPRs at D = 512; the 128 VGPRs
-// of row fragments the recomputing kernel needs are gone).  Rings: column tiles NSX deep (32 KiB each at D = 512),
-// saved-exponential tiles NSE deep (2 KiB per wave, they come from HBM rather than L2, so they are fetched further
-// ahead).  Every iteration issues the same number of VMEM operations (past the end the last tile is re-fetched), so ONE
-// counted s_waitcnt vmcnt(NKEEP) per tile is exact.
-// HBM per launch: the stash is read once directly and once transposed (2 x 0.27 GB at B = 8192) -- O(B^2) bytes, which is
-// the price of not recomputing; the kernel stays MFMA-bound.
-// ---------------------------------------------------------------------------------------------
-// RECT: the same kernel for a rectangular block of the sharded step (this rank's rows x other ranks' columns: the blocks
-// this rank evaluated itself in the forward -- its pair partners and the antipodal rank): the stash is rectangular
-// (tile (r32, item j) at (r32 * NT + j) * 2 KiB, always "direct"), the columns are the usable tiles of the column operand
-// (one rank skipped, or ranks col_rank0.. modulo col_wrap of the whole gathered operand), their statistics come from the
-// gathered arrays; everything else is shared.
-// XP / TPRF (512 < Dpad <= 1024): the gradient product is independent per embedding column, so a wide operand is handled as
-// XP = 2 column parts of DK*16 each (blockIdx.z = part; row pitch XP * RB in memory, the LDS tile holds the part only; the
-// saved exponentials are read once per part); TPRF = 32-row groups per row block of the forward that wrote the stash
-// (8 for the pipelined 4 x 64-row forward, 4 for the 4 x 32-row forward of wide operands).
-template <int DK, bool SW, bool RECT, int XP = 1, int TPRF = 8>
-__global__ void __launch_bounds__(256, 1) fast_bwd_saved_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
-                                                                const float* rz, const float* wrz,
-                                                                const float* rz_cols, const float* wrz_cols, float* gbuf,
-                                                                int accumulate, int tiles_per_slice, const float* ks,
-                                                                const float* kc) {
-    constexpr int RB = DK * 32;
-    constexpr int QT = 32;
-    constexpr int TILE = QT * RB;
-    constexpr int TPR = TPRF;
-    constexpr int RBG = XP * RB;           // bytes per operand row in memory
-#ifndef CROSSCLR_NSX
-#define CROSSCLR_NSX 3
-#endif
-#ifndef CROSSCLR_NSE
-#define CROSSCLR_NSE 6
-#endif
-    constexpr int NSX = CROSSCLR_NSX;      // column-tile ring (shared by the block's four waves)
-    constexpr int NSE = CROSSCLR_NSE;      // saved-exponential + statistics rings (private to a wave)
-    constexpr int ESTG = 4 * 2048;         // one stage of the E ring: [4 waves][2 KiB]
-    constexpr int SSTG = 4 * 256;          // one stage of a statistics ring: [4 waves][64 floats] (the tile's 32 + 32 spare)
-    constexpr int DT = DK / 2;             // 32-wide output fragments
-    constexpr int NI = 2 * DT;             // MFMAs per tile: item i = (k-step tp = i / DT, output fragment dt = i % DT)
-    constexpr int PF = (CROSSCLR_PF < NI / 2) ? CROSSCLR_PF : NI / 2;   // transpose-read pairs in flight ahead of their MFMA
-    constexpr int NXO = DK / 4;            // VMEM operations per wave and tile: column-tile pieces ...
-    constexpr int NEO = 3 + (SW ? 1 : 0);  // ... saved-exponential pieces + statistics
-    constexpr int NKEEP = NEO + (NSX - 2) * (NXO + NEO);   // operations issued after X(t)'s last piece: may still be in flight at tile t
-    static_assert(NSX >= 2 && NSE >= NSX + 2, "E / statistics of tile t+1 must have been issued before the pieces of X(t)");
-    constexpr int E0 = NSX * TILE, S0 = E0 + NSE * ESTG, K0 = S0 + NSE * SSTG;
-    static_assert(K0 + (SW ? NSE * SSTG : 0) <= 160 * 1024, "LDS budget");
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[K0 + (SW ? NSE * SSTG : 0)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int row0w = blockIdx.x * 128 + 32 * wave;
-    const int r32 = uniform(row0w >> 5);
-    const int per_rank = 2 * g.bpad / QT, per_mod = g.bpad / QT;
-    const int skip_seg = (RECT && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
-    // column tiles of this launch: the operand's own (the first NT/2 are modality 0), or the usable tiles of the rank range
-    const int NT = RECT ? (g.col_ranks - (skip_seg >= 0 ? 1 : 0)) * per_rank : per_rank;
-    const int rmod = (2 * r32 >= per_rank) ? 1 : 0;
-    const int rb0 = (r32 / TPR) * TPR;           // first tile the forward evaluated for this wave's rows
-    unsigned char* ebuf = lds + E0 + wave * 2048;      // + estage * ESTG
-    unsigned char* sbuf = lds + S0 + wave * 256;       // + estage * SSTG: omega/Z (or w omega/Z) of the tile's columns
-    unsigned char* kbuf = lds + K0 + wave * 256;       // SW: k of the tile's columns
-
-    const float rzp_inter = rz[row0w + l31];
-    const float rzp_intra = wrz[row0w + l31];
-    const float kp = SW ? ks[row0w + l31] : 1.f;
-
-    // transpose-read roles (column tile): in a 16-lane group lane 4j+c addresses row j, 8-byte piece c
-    const int grp = lane >> 4, i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3, dsub = grp & 1;
-    int comb[4][2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            comb[k][u] = (4 * half + jrow) * RB + 64 * (k ^ jrow) + 16 * ((2 * dsub + (piece >> 1)) ^ (2 * u + half)) +
-                         8 * (piece & 1);
-    // column-tile DMA: piece k of this wave fills LDS bytes [(wave + 4k) KiB, +1 KiB) of the stage; lane -> (row, swizzled slot)
-    const int col_segs = !RECT ? 1 : (g.col_wrap > 0 ? g.col_wrap : g.col_ranks);   // rank segments the column operand holds
-    const BufRsrc rs_x = make_rsrc(cols, (unsigned)((size_t)col_segs * 2 * g.bpad * RBG));
-    const int part = XP > 1 ? (int)blockIdx.z : 0;
-    unsigned voffx[NXO];
-#pragma unroll
-    for (int k = 0; k < NXO; ++k) {
-        const int L = (wave + 4 * k) * 1024 + lane * 16;
-        const int row = L / RB, slot = (L - row * RB) >> 4;
-        voffx[k] = (unsigned)(row * RBG + part * RB + (swz_slot(slot, row) << 4));
-    }
-    // saved-exponential tile.  direct: the 2-KiB fragment image as stored, lane-linear.  transposed: 16-byte chunk
-    // (th_s, hf, rho) of stash tile (t, r32) [row rho = a column q of ours, chunk = 8 of OUR rows] goes to LDS slot
-    // 16*(rho>>2) + (rho&3) + 4*hf + 8*th_s, so that the four rows a transpose read gathers sit in one 256-byte line
-    // and its 32 lanes touch 32 different 8-byte words (conflict-free); the permutation rides on the DMA source offset.
-    const unsigned eoff_d0 = (unsigned)(lane * 16);
-    const unsigned eoff_t0 = (unsigned)((((lane >> 3) & 1) * 64 + ((lane >> 2) & 1) * 32 + ((lane >> 4) * 4 + (lane & 3))) * 16);
-    // transposed read: lane (half, g1 = grp&1, jj = jrow, c = piece) addresses row rho = 16th + 8u + 4half + jj, chunk
-    // (hf = c&1, th_s = g1), 8-byte half c>>1  ->  th*1024 + u*512 + [half*256 + (jj + 4(c&1) + 8 g1)*16 + 8(c>>1)]
-    const int etr = half * 256 + (jrow + 4 * (piece & 1) + 8 * dsub) * 16 + 8 * (piece >> 1);
-    const unsigned stat_bytes = (unsigned)((size_t)col_segs * 2 * g.bpad * 4);
-    const BufRsrc rs_rz = make_rsrc(rz_cols, stat_bytes), rs_wrz = make_rsrc(wrz_cols, stat_bytes);
-    const BufRsrc rs_k = make_rsrc(SW ? kc : rz_cols, stat_bytes);
-
-    f32x16 acc2[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
-
-    int t = blockIdx.y * tiles_per_slice;
-    int t_end = t + tiles_per_slice;
-    if (t_end > NT) t_end = NT;
-    auto clampt = [&](int u) { return u < t_end ? u : t_end - 1; };   // past the end: re-fetch the last tile (fixed VMEM count)
-    // Column cursors (RECT): item u -> tile index inside the column operand (mt) and its modality; the three streams that walk
-    // the items (weights of t+1, column-tile DMA of t+NSX-1, E / statistics DMA of t+NSE-1) advance one item per iteration, so
-    // the mapping is tracked incrementally (one division per block, none per tile).  !RECT: mt = u, modality = (2u >= NT).
-    struct Col { int u, mt, seg, in_seg; };
-    auto col_seg_start = [&](Col& c) {
-        c.in_seg = 0;
-        int r = c.seg;
-        if (g.col_wrap > 0) { r += g.col_rank0; if (r >= g.col_wrap) r -= g.col_wrap; }
-        c.mt = r * per_rank;
-    };
-    auto col_at = [&](int u) {
-        Col c;
-        c.u = u = clampt(u);
-        if (!RECT) { c.mt = u; c.seg = 0; c.in_seg = u; return c; }
-        const int su = u / per_rank;
-        c.seg = su + ((skip_seg >= 0 && su >= skip_seg) ? 1 : 0);
-        col_seg_start(c);
-        c.in_seg = u - su * per_rank;
-        c.mt += c.in_seg;
-        return c;
-    };
-    auto col_next = [&](Col& c) {
-        if (c.u + 1 >= t_end) return;                   // stay on the last tile
-        ++c.u; ++c.mt; ++c.in_seg;
-        if (RECT && c.in_seg == per_rank) { ++c.seg; if (c.seg == skip_seg) ++c.seg; col_seg_start(c); }
-    };
-    auto col_mod = [&](const Col& c) { return c.in_seg >= per_mod ? 1 : 0; };
-    auto issue_x_piece = [&](const Col& c, int stage, int k) {
-        if (CROSSCLR_SABL & 2) return;
-        lds_dma16_buf(rs_x, voffx[k], (unsigned)c.mt * (unsigned)(QT * RBG), lds + stage * TILE + (wave + 4 * k) * 1024);
-    };
-    auto issue_e = [&](const Col& c, int estage) {      // 2 pieces of the saved exponentials + the tile's statistics
-        if (CROSSCLR_SABL & 1) return;
-        const int u = c.u;
-        const bool direct = RECT || u >= rb0;
-        // stash_tile_index in 32-bit scalar arithmetic (the host refuses plans whose stash has 2^31 tiles or more)
-        const unsigned a32 = direct ? (unsigned)r32 : (unsigned)u, b32 = direct ? (unsigned)u : (unsigned)r32;
-        const unsigned rbp = a32 / TPR, wp = a32 % TPR;
-        const unsigned idx = RECT ? (unsigned)r32 * (unsigned)NT + (unsigned)u
-                                  : TPR * rbp * ((unsigned)NT - (TPR / 2) * rbp + (TPR / 2)) + wp * ((unsigned)NT - TPR * rbp) + (b32 - TPR * rbp);
-        const BufRsrc rs_e = make_rsrc(stash + (size_t)((CROSSCLR_SABL & 64) ? (idx & 1023) : idx) * 2048, 2048u);   // bit6: E from a 2-MiB window (L2)
-        const unsigned o0 = direct ? eoff_d0 : eoff_t0;      // second half (LDS chunks 64..127): +1 KiB direct, +16 rows transposed
-        lds_dma16_buf(rs_e, o0, 0u, ebuf + estage * ESTG);
-        lds_dma16_buf(rs_e, o0 + (direct ? 1024u : 256u), 0u, ebuf + estage * ESTG + 1024);
-        const bool same = col_mod(c) == rmod;
-        lds_dma4_buf(same ? rs_wrz : rs_rz, (unsigned)(lane * 4), (unsigned)(c.mt * QT * 4), sbuf + estage * SSTG);
-        if (SW) lds_dma4_buf(rs_k, (unsigned)(lane * 4), (unsigned)(c.mt * QT * 4), kbuf + estage * SSTG);
-    };
-    struct Pair { s16x4 lo, hi; };
-    struct Bits8 { bf16_t e[8]; };
-    // the lane's saved exponentials of tile u: row p = l31, k-slot j of k-step th <-> column 16th + 8(j>>2) + 4half + (j&3)
-    // (all LDS reads of the main loop are asm: hipcc then puts no s_waitcnt lgkmcnt of its own into the MFMA stream, and
-    // the counted waits below never drain the transpose-read ring)
-    struct Staged { u32x4 e[2]; Pair tr[2]; u32x4 rq[4]; u32x4 kq[4]; };   // tile u: saved exponentials (both forms), omega/Z and k of its columns
-    // Both forms of the saved tile are read -- the lane-linear fragment image (right when the tile was stored for these
-    // rows) and the transposing gather (right when it was stored for the mirrored block) -- and the wanted one is selected
-    // AFTER the counted wait: an asm load's registers count as written when the asm statement ends, so they must never be
-    // live across a control-flow merge (a register copy there would read them before the data lands); six cheap LDS reads
-    // and eight v_cndmask per tile buy a branch-free main loop.
-    auto read_staged = [&](int estage, Staged& st) {
-        const unsigned char* eb = ebuf + estage * ESTG;
-        const auto ed = lds_addr(eb + 16 * lane);
-        st.e[0] = lds_read_b128_async<0>(ed);
-        st.e[1] = lds_read_b128_async<1024>(ed);
-        const auto ea = lds_addr(eb + etr);
-        st.tr[0].lo = lds_read_tr16_b64_async<0>(ea);
-        st.tr[0].hi = lds_read_tr16_b64_async<512>(ea);
-        st.tr[1].lo = lds_read_tr16_b64_async<1024>(ea);
-        st.tr[1].hi = lds_read_tr16_b64_async<1536>(ea);
-        const auto sa = lds_addr(sbuf + estage * SSTG + 16 * half);   // quad (th, r4): columns 16th + 8r4 + 4half ..+3
-        st.rq[0] = lds_read_b128_async<0>(sa);
-        st.rq[1] = lds_read_b128_async<32>(sa);
-        st.rq[2] = lds_read_b128_async<64>(sa);
-        st.rq[3] = lds_read_b128_async<96>(sa);
-        if (SW) {
-            const auto ka = lds_addr(kbuf + estage * SSTG + 16 * half);
-            st.kq[0] = lds_read_b128_async<0>(ka);
-            st.kq[1] = lds_read_b128_async<32>(ka);
-            st.kq[2] = lds_read_b128_async<64>(ka);
-            st.kq[3] = lds_read_b128_async<96>(ka);
-        }
-    };
-    // W = E (omega_p/Z_p + omega_q/Z_q) for four columns (k-step th, register quad r4), packed to bf16 in place
-    // YOUNGER = LDS operations certainly issued after the staged reads (>= that many): the wait is then a no-op in practice
-    auto weigh4 = [&](const Col& c, Staged& st, Bits8 (&pk)[2], int th, int r4, auto younger) {
-        constexpr int YOUNGER = decltype(younger)::value;
-        const bool direct = RECT || c.u >= rb0;
-        const bool same_mod = col_mod(c) == rmod;
-        const bool weighted = SW && same_mod;
-        const float rzp = same_mod ? rzp_intra : rzp_inter;
-        wait_lgkm<YOUNGER>(st.e[th], st.rq[2 * th + r4]);
-        wait_lgkm<YOUNGER>(st.tr[th].lo, st.tr[th].hi);
-        if (SW) wait_lgkm<YOUNGER>(st.kq[2 * th + r4]);
-        const f32x4 rq = __builtin_bit_cast(f32x4, st.rq[2 * th + r4]);
-        f32x4 kq = {1.f, 1.f, 1.f, 1.f};
-        if (weighted) kq = __builtin_bit_cast(f32x4, st.kq[2 * th + r4]);
-        const u32x4 etr4 = __builtin_bit_cast(u32x4, st.tr[th]);
-        const u32x4 esel = direct ? st.e[th] : etr4;        // (only the two dwords this quad uses survive dead-code elimination)
-        const Bits8 ev = __builtin_bit_cast(Bits8, esel);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
-            const float zz = weighted ? (rzp * kq[j] + rq[j] * kp) : (rzp + rq[j]);
-            pk[th].e[4 * r4 + j] = (CROSSCLR_SABL & 4) ? ev.e[4 * r4 + j] : f32_to_bf16_bits(v * zz);
-        }
-    };
-
-    bf16x8 af[2];      // A fragments of the tile being multiplied
-    Col cw, cx, ce;    // the next tile to weigh (t+1), to fetch (t+NSX-1), to fetch saved exponentials for (t+NSE-1)
-    if (t < t_end) {
-        ce = col_at(t);
-#pragma unroll
-        for (int k = 0; k < NSE - 1; ++k) { issue_e(ce, k); col_next(ce); }
-        cx = col_at(t);
-#pragma unroll
-        for (int k = 0; k < NSX - 1; ++k) {
-#pragma unroll
-            for (int j = 0; j < NXO; ++j) issue_x_piece(cx, k, j);
-            col_next(cx);
-        }
-        if (!(CROSSCLR_SABL & 3)) wait_dma_keep<(NSX - 1) * NXO>();     // the E / statistics pieces precede the column tiles
-        Bits8 pk[2];
-        Staged st;
-        read_staged(0, st);
-        cw = col_at(t);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) weigh4(cw, st, pk, q >> 1, q & 1, IdxC<0>{});
-        col_next(cw);
-        af[0] = __builtin_bit_cast(bf16x8, pk[0]);
-        af[1] = __builtin_bit_cast(bf16x8, pk[1]);
-    }
-    int sx = 0, se = 0;
-    int warm = 0;      // iterations done, saturating at NSX - 1
-    for (; t < t_end; ++t) {
-        // X(t) has landed (and E / statistics of tile t+1, issued long before).  VMEM operations issued after X(t)'s last piece
-        // may still be in flight: in the steady state NKEEP; in the first NSX - 1 iterations X(t) is a tile of the prologue,
-        // which issued ALL its E pieces before its column tiles -- fewer operations follow it: (NSX-2) NXO + iterations * NEO.
-        // (Waiting for NKEEP there let the first two tiles of every block be read before they had landed: gradients of whole
-        // row blocks differed from launch to launch for Dpad < 512, where a tile is short.)
-        if (!(CROSSCLR_SABL & 3)) {
-            if (warm >= NSX - 1) wait_dma_keep<NKEEP>();
-            else {
-                static_assert(NSX == 3 || NSX == 2, "start-up waits are written out for NSX <= 3");
-                if (warm == 0) wait_dma_keep<(NSX - 2) * NXO>();
-                else wait_dma_keep<(NSX - 2) * NXO + NEO>();
-                ++warm;
-            }
-        }
-        if (!(CROSSCLR_SABL & 32)) barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1
-        const int sx_free = sx == 0 ? NSX - 1 : sx - 1;        // stage of tile t-1 = stage of tile t+NSX-1
-        const int se_free = se == 0 ? NSE - 1 : se - 1;
-        const int se_next = se + 1 == NSE ? 0 : se + 1;
-        const auto xa = lds_addr(lds + sx * TILE);
-        decltype(lds_addr(lds)) base[4][2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) base[k][u] = xa + comb[k][u];
-        Pair ring[PF];
-        auto fetch = [&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int tp = i / DT, dt = i % DT;
-            if (CROSSCLR_SABL & 16) { ring[i % PF] = __builtin_bit_cast(Pair, af[tp]); return; }
-            ring[i % PF].lo = lds_read_tr16_b64_async<(16 * tp) * RB + 256 * (dt >> 2)>(base[dt & 3][0]);
-            ring[i % PF].hi = lds_read_tr16_b64_async<(16 * tp + 8) * RB + 256 * (dt >> 2)>(base[dt & 3][1]);
-        };
-        static_for<PF>([&](auto ic) { fetch(ic); });
-        Staged st;             // tile t+1: saved exponentials and column statistics ...
-        Bits8 pk[2];           // ... and its weights, built in the shadow of tile t's MFMAs
-        // One MFMA slot = { wait for the item's B fragment; MFMA; issue the reads PF items ahead; one chore }, pinned by
-        // sched_fence() so that hipcc neither bunches the chores in front of the MFMAs nor the reads behind them.
-        // Chores of tile t: slots 0 .. NXO-1 the pieces of X(t+NSX-1); then E / statistics of tile t+NSE-1; then read E(t+1);
-        // the last four slots-pairs weigh tile t+1 (its E and statistics landed iterations ago, they are private to the wave).
-        constexpr int C_E = NXO, C_RD = NXO + 1, WSTEP = NI >= 16 ? 2 : 1, C_W0 = NI - 4 * WSTEP;
-        static_assert(C_RD < C_W0, "chore schedule");
-        static_for<NI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int tp = i / DT, dt = i % DT;
-            constexpr int later = (NI - 1 - i) < (PF - 1) ? (NI - 1 - i) : (PF - 1);   // pairs issued after this one
-#if CROSSCLR_FUSED_WAIT
-            mfma_after_lgkm<2 * later>(acc2[dt], af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]));
-#else
-            wait_lgkm<2 * later>(ring[i % PF].lo, ring[i % PF].hi);
-            if (CROSSCLR_SABL & 8) acc2[dt][i & 15] += __builtin_bit_cast(float, ring[i % PF].lo[0] | (ring[i % PF].hi[1] << 16));
-            else
-            acc2[dt] = mfma_32x32x16_bf16(af[tp], __builtin_bit_cast(bf16x8, ring[i % PF]), acc2[dt]);
-#endif
-            if constexpr (i + PF < NI) fetch(IdxC<i + PF>{});
-            if constexpr (i < NXO) issue_x_piece(cx, sx_free, i);
-            if constexpr (i == C_E) issue_e(ce, se_free);
-            if constexpr (i == C_RD) read_staged(se_next, st);
-            if constexpr (i >= C_W0 && (i - C_W0) % WSTEP == 0) {
-                constexpr int q = (i - C_W0) / WSTEP;                      // quad (th = q >> 1, r4 = q & 1)
-                constexpr int last_fetch = NI - PF - 1;                    // last slot that issues transpose reads
-                constexpr int n_after = (i < last_fetch ? i : last_fetch) - C_RD;   // slots C_RD+1 .. i that issued a pair
-                constexpr int younger = n_after <= 0 ? 0 : (2 * n_after < 2 * PF ? 2 * n_after : 2 * PF);
-                weigh4(cw, st, pk, q >> 1, q & 1, IdxC<younger>{});
-            }
-            sched_fence();
-        });
-        af[0] = __builtin_bit_cast(bf16x8, pk[0]);
-        af[1] = __builtin_bit_cast(bf16x8, pk[1]);
-        col_next(cw); col_next(cx); col_next(ce);
-        sx = sx + 1 == NSX ? 0 : sx + 1;
-        se = se_next;
-    }
-    wait_dma();   // the re-fetches past the end must not outlive the block's LDS
-    // G[row][d]: the lane holds column d = 32 dt + l31 of each fragment and 16 rows; buffer addressing (one per-lane offset, the
-    // row / fragment part as a scalar) keeps the 256 stores free of 64-bit per-lane address arithmetic (and of its spills)
-    constexpr unsigned GP = XP * DK * 16 * 4;           // bytes per gradient row
-    const BufRsrc rs_g = make_rsrc(gbuf + (size_t)blockIdx.y * 2 * g.bpad * (XP * DK * 16) + (size_t)row0w * (XP * DK * 16) + part * (DK * 16),
-                                   32u * GP);            // this wave's 32 rows
-    const unsigned vg = (unsigned)((4 * half) * GP + l31 * 4);
-    // accumulate: 16 loads in flight, then 16 add + store (a plain += chain waits for every load on its own).  ONE store path
-    // for both cases, fenced per fragment: with two branches hipcc hoists the copies of all 256 accumulators out of the
-    // AGPRs above the branch, and spills.
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        float o[16];
-        if (accumulate) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = buf_load4(rs_g, vg, (unsigned)((8 * (r >> 2) + (r & 3)) * GP + 128 * dt));
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        }
-        sched_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) buf_store4(rs_g, vg, (unsigned)((8 * (r >> 2) + (r & 3)) * GP + 128 * dt), o[r] + acc2[dt][r]);
-        sched_fence();
-    }
-}
+// (the backward from the SAVED exponentials is fast_bwd_dsl_kernel, crossclr_kernels_dsl.h)
 
 // ---------------------------------------------------------------------------------------------
 // backward, 16-row wavefronts (v_mfma_f32_16x16x32_bf16).  A wave owns 16 rows: 16 x Dpad fp32 gradient
@@ -1141,6 +783,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 
 }  // namespace crossclr
 #include "crossclr_kernels_sym.h"
+#include "crossclr_kernels_dsl.h"
 namespace crossclr {
 
 // ---------------------------------------------------------------------------------------------
@@ -1260,10 +903,15 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
     const bf16_t* c = (const bf16_t*)cols;
     const unsigned char* st = (const unsigned char*)stash;
+#ifdef CROSSCLR_DSL_MINIMAL   // tuning builds (tools/build_variant.py): only the headline instantiation is compiled (seconds instead of minutes)
+    if (p->Dpad != 512 || ks || rect) return CROSSCLR_E_ARG;
+    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, false>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    return CROSSCLR_OK;
+#else
     if (p->Dpad > 512) {   // two column parts of Dpad/2
         dim3 grid2(2 * p->bpad / 128, p->bwd_slices, 2);
 #define CROSSCLR_LBW2(DK, SW, RECT) \
-    CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, SW, RECT, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
+    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, RECT, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
 #define CROSSCLR_LBW(DK)                                                                             \
     do {                                                                                              \
         if (rect) { if (ks) CROSSCLR_LBW2(DK, true, true); else CROSSCLR_LBW2(DK, false, true); }     \
@@ -1279,7 +927,7 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
         return CROSSCLR_OK;
     }
 #define CROSSCLR_LBS2(DK, SW, RECT) \
-    CROSSCLR_FAST_LAUNCH((fast_bwd_saved_kernel<DK, SW, RECT>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
+    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, RECT>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
 #define CROSSCLR_LBS(DK)                                                              \
     do {                                                                               \
         if (rect) { if (ks) CROSSCLR_LBS2(DK, true, true); else CROSSCLR_LBS2(DK, false, true); }    \
@@ -1295,6 +943,7 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
 #undef CROSSCLR_LBS
 #undef CROSSCLR_LBS2
     return CROSSCLR_OK;
+#endif
 }
 // which backward the fast path uses: 16-row wavefronts (rows per block 128 at Dpad <= 512, 64 above) or the
 // 32-row kernel (Dpad <= 512 only)

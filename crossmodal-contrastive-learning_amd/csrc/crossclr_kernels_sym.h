@@ -15,7 +15,7 @@
 //     buffer-addressed LDS-DMA (NST-deep ring) -- hipcc puts no wait of its own into the MFMA stream;
 //   * tiles that need a mask (the 256x256 diagonal blocks, ragged columns, padding rows) and the sample-weight variant take the
 //     plain, un-overlapped epilogue: 8 of ~65 tiles per row block.
-// ST: the bf16 exponentials of every evaluated tile are saved for fast_bwd_saved_kernel -- KIND 1: the triangular layout of
+// ST: the bf16 exponentials of every evaluated tile are saved for fast_bwd_dsl_kernel -- KIND 1: the triangular layout of
 // stash_tile_index; KIND 2/3: rectangular, tile (32-row group r32, item j) at (r32 * NT + j) * 2 KiB.
 #pragma once
 

@@ -168,6 +168,23 @@ class _OperandExchange:
         self._rest = []
 
 
+class _Range:
+    """roctx range around one stage of the step (rocprofv3 --marker-trace shows them); only with CROSSCLR_ROCTX=1 -- the push / pop
+    pair costs ~2 us of host time per stage.  `torch.cuda.nvtx` is roctx on ROCm builds of torch."""
+    enabled = os.environ.get("CROSSCLR_ROCTX") == "1"
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if _Range.enabled:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if _Range.enabled:
+            torch.cuda.nvtx.range_pop()
+
+
 def _carve(total: torch.Tensor, offset: int, nbytes: int, dtype):
     return total[offset:offset + nbytes].view(dtype)
 
@@ -189,6 +206,21 @@ def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor
             raise ValueError(f"{what}[{m}] must be a 1-D tensor with one entry per local sample ({b})")
         out[m, :b] = x.detach().to(device=dev, dtype=torch.float32)
     return out.view(-1)
+
+
+# Exact-fp32 plans advertise a stash of (2 bpad)^2 fp32 exponentials (1 GiB at b = 8192, 16 GiB at b = 32768; twice that in the
+# two-pass regime).  Above this many bytes the step recomputes instead of saving (CROSSCLR_MAX_STASH_GB, default 8); and an
+# allocation the device cannot satisfy falls back to the recomputing backward as well instead of failing the step.
+_MAX_STASH_BYTES = int(float(os.environ.get("CROSSCLR_MAX_STASH_GB", "8")) * (1 << 30))
+
+
+def _alloc_stash(nbytes: int, dev) -> Optional[torch.Tensor]:
+    if nbytes <= 0 or nbytes > _MAX_STASH_BYTES:
+        return None
+    try:
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    except torch.OutOfMemoryError:
+        return None
 
 
 def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
@@ -250,8 +282,9 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
 
     ws.prenormalized = bool(prenormalized)
     entry = lib.crossclr_pack if prenormalized else lib.crossclr_normalize    # unit rows are only laid out, not re-normalised
-    nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
-                    _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+    with _Range("crossclr.normalize"):
+        nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                        _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
     gather = None
     if sharded:
         # all-gather of the packed operands runs on the collective's own stream (RCCL over xGMI)
@@ -279,14 +312,14 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # Local (symmetric) block.  When a backward will follow and the plan offers it, the forward also saves its bf16
     # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
     # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
-    ws.stash = None
-    if save_for_backward and plan.stash_bytes > 0:
-        ws.stash = torch.empty(plan.stash_bytes, dtype=torch.uint8, device=dev)
-        nat.check(lib.crossclr_forward_save(pp, _ptr(ws.xhat), ws.temperature, ws.negative_w,
-                                            _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, _ptr(ws.stash), stream))
-    else:
-        nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
-                                         _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, stream))
+    ws.stash = _alloc_stash(plan.stash_bytes, dev) if save_for_backward else None
+    with _Range("crossclr.forward"):
+        if ws.stash is not None:
+            nat.check(lib.crossclr_forward_save(pp, _ptr(ws.xhat), ws.temperature, ws.negative_w,
+                                                _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, _ptr(ws.stash), stream))
+        else:
+            nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
+                                             _sw(ws.k_rows, ws.k_rows, None), _ptr(part), 0, stream))
     # Pair evaluation (bf16 register-resident path, >= 3 ranks): the (r, s) block of the symmetric matrix of exponentials
     # is evaluated by ONE of the two ranks, which ships its column sums to the other -- 3 instead of 7 remote blocks at
     # 8 ranks (+ the antipodal one, evaluated by both).  CROSSCLR_DISABLE_PAIR_FORWARD=1: every rank evaluates all blocks.
@@ -296,7 +329,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # other rank) save their exponentials as well: the backward then recomputes only the blocks the OTHER ranks evaluated.
     ws.saved_blocks, ws.recompute_ranges = None, None
     save_remote = (sharded and world >= 2 and ws.stash is not None and plan.fast_path == 1 and (use_pairs or world == 2) and
-                   lib.crossclr_rect_stash_bytes(pp, 1) > 0 and   # (wide operands, 512 < D <= 1024, save the local block only)
+                   lib.crossclr_rect_stash_bytes(pp, 1) > 0 and   # (0 beyond D = 1024: the register-resident kernels end there)
                    os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1")
     if save_remote:
         gather.wait_forward()   # (point-to-point exchange: the peers this rank evaluates itself; all-gather: everything)
@@ -360,9 +393,10 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         gather.wait()
         nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                          ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, stream))
-    nat.check(lib.crossclr_forward_finish_w(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), ws.temperature,
-                                            ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.logz), _ptr(ws.rz),
-                                            _ptr(ws.wrz), _ptr(ws.loss_sum), stream))
+    with _Range("crossclr.forward_finish"):
+        nat.check(lib.crossclr_forward_finish_w(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), ws.temperature,
+                                                ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.logz), _ptr(ws.rz),
+                                                _ptr(ws.wrz), _ptr(ws.loss_sum), stream))
     if sharded:
         # the backward's remote launch needs every rank's omega/Z: gathered asynchronously, waited for in the backward
         # (w * omega/Z of the columns is recomputed there: the same fp32 product the finish kernel forms).  Only when a
@@ -400,9 +434,8 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
                                               _ptr(ws.shift), 1, stream))
     # second pass over the local block; with a backward to follow (exact-fp32 plans) it also saves the exponentials relative to the
     # row's and to the column's shift, and the backward does not recompute the similarity product
-    sbytes = lib.crossclr_stash_bytes_s(pp) if needs_backward else 0
-    if sbytes:
-        ws.stash = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    ws.stash = _alloc_stash(lib.crossclr_stash_bytes_s(pp), dev) if needs_backward else None
+    if ws.stash is not None:
         nat.check(lib.crossclr_forward_save_s(pp, _ptr(ws.xhat), T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, _ptr(ws.stash), stream))
     else:
         nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, stream))
@@ -461,9 +494,10 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
                                               _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols),
                                               _sw(ws.k_rows, ws.k_cols, None), _ptr(ws.shift), _ptr(ws.shift_cols), _ptr(gbuf), 1, stream))
     elif ws.stash is not None:
-        nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
-                                              _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
-                                              stream))
+        with _Range("crossclr.backward"):
+            nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
+                                                  _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
+                                                  stream))
         ws.stash = None   # consumed: give the 0.27 GB back to the allocator as soon as the launch is queued
     else:
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
@@ -489,6 +523,8 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         if ws.wrz_cols is None:
             ws.stats_work.wait()
             ws.wrz_cols = ws.rz_cols * ws.negative_w
+        if ws.exchange is not None:
+            ws.exchange.wait()     # this launch reads EVERY rank's slice of xcols: also the late point-to-point ones
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                           ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols),
                                           _ptr(ws.wrz_cols), _sw(ws.k_rows, ws.k_cols, None), _ptr(gbuf), 1, stream))
@@ -498,10 +534,11 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
     gv = torch.empty(video.shape, dtype=video.dtype, device=dev)
     gt = torch.empty(text.shape, dtype=text.dtype, device=dev)
-    nat.check(lib.crossclr_backward_finish_p(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
-                                             ws.in_dtype, _ptr(ws.inv_norm), ws.temperature, _sw(None, None, ws.lw),
-                                             _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0),
-                                             1 if ws.prenormalized else 0, stream))
+    with _Range("crossclr.backward_finish"):
+        nat.check(lib.crossclr_backward_finish_p(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
+                                                 ws.in_dtype, _ptr(ws.inv_norm), ws.temperature, _sw(None, None, ws.lw),
+                                                 _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0),
+                                                 1 if ws.prenormalized else 0, stream))
     return gv, gt
 
 
@@ -521,6 +558,15 @@ class _device_of:
             self._guard.__exit__(*exc)
 
 
+def _refuse_double_backward(what: str) -> None:
+    """The autograd engine runs `backward` with grad mode ON exactly when the caller asked for a graph through it
+    (`create_graph=True`).  The reference's eager ops (loss.py:79-114) are twice differentiable; these closed-form kernels are
+    not -- raise instead of silently handing back a gradient that autograd would treat as a constant."""
+    if torch.is_grad_enabled():
+        raise RuntimeError(f"{what}: differentiating through the backward (create_graph=True / double backward) is not "
+                           "supported by the HIP kernels; use the eager reference for second-order terms")
+
+
 class _CrossCLRFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, video, text, temperature, negative_w, compute_mode, group, negative_scale, loss_weight, prenormalized):
@@ -535,6 +581,7 @@ class _CrossCLRFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        _refuse_double_backward("CrossCLR_onlyIntraModality")
         video_c, text_c = ctx.saved_tensors
         with _device_of(video_c):
             gv, gt = _backward_impl(ctx.ws, video_c, text_c, grad_out)

@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import _native as nat
-from .loss import _IN_DTYPE, _device_of, _plan_for, _ptr, _resolve_mode, _row_major, _stream_for, _validate
+from .loss import _IN_DTYPE, _device_of, _plan_for, _ptr, _refuse_double_backward, _resolve_mode, _row_major, _stream_for, _validate
 
 
 def cosine_sim(emb1: torch.Tensor, emb2: torch.Tensor) -> torch.Tensor:
@@ -75,6 +75,7 @@ class _MaxMarginFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        _refuse_double_backward("MaxMargin_coot")
         im_c, s_c = ctx.saved_tensors
         sc, lib = ctx.sc, nat.library()
         plan = sc.plan
@@ -100,8 +101,9 @@ def _check(im: torch.Tensor, s: torch.Tensor) -> None:
         raise RuntimeError("empty batch")
 
 
-def max_margin_loss(im: torch.Tensor, s: torch.Tensor, margin: float = 0.1, *, compute_mode: str = "auto") -> torch.Tensor:
-    """Functional form of `MaxMargin_coot.forward` (trainer/loss.py:29-41)."""
+def max_margin_loss(im: torch.Tensor, s: torch.Tensor, margin: float = 0.1, *, compute_mode: str = "fp32") -> torch.Tensor:
+    """Functional form of `MaxMargin_coot.forward` (trainer/loss.py:29-41).  compute_mode="fp32" (default) = exact-fp32 products like the
+    reference's `mm`; "bf16" is opt-in: the scores are products of the caller's UN-normalised rows, so there is no a-priori error bar."""
     _check(im, s)
     return _MaxMarginFunction.apply(im, s, float(margin), compute_mode)
 
@@ -111,7 +113,7 @@ class MaxMargin_coot(nn.Module):
     (`trainer/loss.py:17-41`; COOT, NeurIPS 2020).  Constructor arguments and attributes as the reference declares them
     (loss.py:23-27); `use_cuda` is kept for signature compatibility -- the inputs must be on the GPU either way."""
 
-    def __init__(self, use_cuda: bool = True, margin: float = 0.1, *, compute_mode: str = "auto"):
+    def __init__(self, use_cuda: bool = True, margin: float = 0.1, *, compute_mode: str = "fp32"):
         super().__init__()
         self.margin = margin
         self.sim = cosine_sim

@@ -27,10 +27,13 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         from emu import build_emu
         from oracle import crossclr_oracle as orc
         nat.use_library_for_testing(build_emu.OUT)
-        p2p = mode.endswith("+p2p")      # the need-ordered point-to-point operand exchange instead of the all-gather
-        if p2p:
-            mode = mode[:-4]
+        mode, *knobs = mode.split("+")
+        if "p2p" in knobs:       # the need-ordered point-to-point operand exchange instead of the all-gather
             os.environ["CROSSCLR_EXCHANGE"] = "p2p"
+        if "nosave" in knobs:    # remote blocks recompute in the backward (reads EVERY rank's slice: also the late p2p ones)
+            os.environ["CROSSCLR_DISABLE_REMOTE_SAVE"] = "1"
+        if "nopairs" in knobs:   # every rank evaluates all remote blocks itself
+            os.environ["CROSSCLR_DISABLE_PAIR_FORWARD"] = "1"
         v, t = orc.make_inputs("randn", B, D, 77)
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
@@ -76,7 +79,15 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        # forward needs first (3 / 4 / 5 ranks: with and without an antipodal rank)
                                                        (3, 24, 16, "bf16+p2p", 5e-3, 2e-2),
                                                        (4, 24, 16, "bf16+p2p", 5e-3, 2e-2),
-                                                       (5, 20, 16, "bf16+p2p", 5e-3, 2e-2)])
+                                                       (5, 20, 16, "bf16+p2p", 5e-3, 2e-2),
+                                                       # p2p with the recomputing remote backward: the launch over the whole gathered
+                                                       # operand must wait for the LATE slices too (round-2 advisor finding)
+                                                       (4, 24, 16, "bf16+p2p+nosave", 5e-3, 2e-2),
+                                                       (3, 24, 16, "bf16+nosave", 5e-3, 2e-2),
+                                                       (4, 24, 16, "bf16+nopairs", 5e-3, 2e-2),
+                                                       # 8 ranks (BASELINE configs 4 / 5's world size), tiny shapes: three pairs + the antipode
+                                                       (8, 32, 16, "bf16", 5e-3, 2e-2),
+                                                       (8, 32, 16, "bf16+p2p", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()

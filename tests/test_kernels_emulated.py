@@ -294,6 +294,41 @@ def test_wide_operands_take_the_saved_backward_in_two_column_parts(B, D, weighte
         assert (gts.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, True), (150, 200, False), (140, 300, True)])
+def test_saved_backward_with_mirrored_tiles(B, D, weighted, monkeypatch):
+    """bpad >= 256: row blocks behind the first read column tiles the forward evaluated for ANOTHER row block -- stash tile
+    (t, r32) holds E^T.  fast_bwd_dsl_kernel weighs them in their stored orientation and reads W^T through the transposing
+    gather (bodies M->M, M->D, D->D; DK = 8 / 16 / 24 here).  Against the recomputing backward and the float64 oracle."""
+    plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
+    assert plan.fast_path == 1 and plan.Dpad <= 512 and plan.stash_bytes > 0 and plan.bpad >= 256
+    v, t = orc.make_inputs("randn", B, D, 29)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(5)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    ls, gvs, gts = step()
+    ls2, gvs2, gts2 = step()
+    assert ls == ls2 and torch.equal(gvs, gvs2) and torch.equal(gts, gts2)
+    monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).stash_bytes == 0
+    lr, gvr, gtr = step()
+    assert abs(ls - lr) <= 1e-6 * max(1.0, abs(lr))
+    scale = max(gvr.abs().max().item(), gtr.abs().max().item())
+    assert (gvs - gvr).abs().max().item() <= 1e-2 * scale      # bf16 exponentials vs recomputed fp32 ones
+    assert (gts - gtr).abs().max().item() <= 1e-2 * scale
+    if not weighted:
+        ref = orc.streaming_loss_and_grads(v, t, 0.05, 0.8)
+        assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 2e-2 * scale
+        assert (gts.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
+
+
 @pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, False), (150, 24, True), (70, 16, False)])
 def test_generic_forward_only_evaluates_the_upper_triangle(B, D, weighted, monkeypatch):
     """compute_mode="fp32" under no_grad (BASELINE config 2's shape of call): fwd_sums_kernel<..., SYM> evaluates the column
@@ -349,3 +384,20 @@ def test_two_pass_regime_saves_both_exponential_matrices(B, D, weighted, sym, mo
         ref = orc.streaming_loss_and_grads(v, t, 0.004, 0.8)
         assert abs(ls - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"])))
         assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 1e-3 * scale
+
+
+def test_double_backward_raises_instead_of_returning_a_constant():
+    """The reference's loss (trainer/loss.py:79-114) is twice differentiable; the closed-form backward here is not: asking for a
+    graph through it must raise, never silently treat the first gradient as a constant."""
+    v, t = orc.make_inputs("randn", 8, 16, 1)
+    vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="fp32")
+    with pytest.raises(RuntimeError, match="double backward"):
+        torch.autograd.grad(loss, vv, create_graph=True)
+    a, b = torch.nn.functional.normalize(v, dim=1).requires_grad_(True), torch.nn.functional.normalize(t, dim=1).requires_grad_(True)
+    mm = crossclr_amd.max_margin_loss(a, b, 0.1)
+    with pytest.raises(RuntimeError, match="double backward"):
+        torch.autograd.grad(mm, a, create_graph=True)
+    mm2 = crossclr_amd.max_margin_loss(a, b, 0.1)
+    mm2.backward()          # the ordinary backward is unaffected
+    assert a.grad is not None
