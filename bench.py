@@ -48,6 +48,19 @@ GOLDEN_LOSS_B8192_SEED1234 = 10.627098744839678  # tests/golden/index.json: g7_b
 GOLDEN_LOSS_B4096_SEED1234 = 9.919463972018582   # tests/golden/index.json: g7_b4096_d512_s1234
 
 
+def csrc_sha():
+    """Hash of the kernel sources: profiles/*_pmc.json records the value it was measured at (tools/make_pmc_json.py), so a
+    traffic figure read from a committed profile can be flagged when the kernels have changed since."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "crossmodal-contrastive-learning_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(b, d, mode, kernel_substr):
     """HBM bytes per launch of a kernel from the newest committed PMC summary under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes).
@@ -64,7 +77,7 @@ def measured_traffic(b, d, mode, kernel_substr):
             continue
         for name, e in j.get("kernels", {}).items():
             if kernel_substr in name:
-                best = {"bytes": e["hbm_bytes_corrected"], "source": os.path.relpath(path, ROOT)}
+                best = {"bytes": e["hbm_bytes_corrected"], "source": os.path.relpath(path, ROOT), "csrc_sha": j.get("csrc_sha")}
     return best
 
 
@@ -118,6 +131,66 @@ def cpu_baseline(b, d, fwd_only=False):
                       f"B={bb} D={d}, {len(times)} steps (first = warm-up), median of the rest"}
 
 
+def secondary_lines(dev):
+    """Short driver-timed measurements of the other configurations (each a handful of steps, < 1 s together): HIP-event median of
+    the step, loss against the reference golden where one exists, algorithmic rate of the dominant kernel."""
+    import crossclr_amd
+    from crossclr_amd import _profile
+    out = {}
+
+    def timed(fn, n=8, warm=3):
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, z in ev:
+            a.record()
+            last = fn()
+            z.record()
+        torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(z) for a, z in ev)
+        return ms[len(ms) // 2], last
+
+    def case(name, rows, dim, mode, fwd_only, influential, golden):
+        v, t = make_inputs(rows, dim, 1234)
+        v, t = v.to(dev).requires_grad_(not fwd_only), t.to(dev).requires_grad_(not fwd_only)
+        extra = ()
+        if influential:
+            g = torch.Generator().manual_seed(4321)
+            c = torch.randn(16, 256, generator=g)
+            lab = torch.randint(0, 16, (rows,), generator=g)
+            extra = ((c[lab] + 0.1 * torch.randn(rows, 256, generator=g)).to(dev), (c[lab] + 0.1 * torch.randn(rows, 256, generator=g)).to(dev))
+            crit = crossclr_amd.CrossCLR(TAU, 0.0035, NEG_W, 0.9, compute_mode=mode).to(dev)
+        else:
+            crit = crossclr_amd.CrossCLR_onlyIntraModality(TAU, NEG_W, compute_mode=mode).to(dev)
+
+        def step():
+            if fwd_only:
+                with torch.no_grad():
+                    return crit(v, t, *extra)
+            v.grad = t.grad = None
+            loss = crit(v, t, *extra)
+            loss.backward()
+            return loss
+        ms, loss = timed(step)
+        sw = crossclr_amd.influential_sample_weights(extra[0], extra[1], 0.9, 0.0035) if influential else (None, None)
+        st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, mode, iters=3, warmup=1, negative_scale=sw[0], loss_weight=sw[1])
+        peak = PEAK_BF16_TFLOPS if mode == "bf16" else PEAK_F32_TFLOPS
+        dom = "step_forward" if fwd_only else "step_backward"
+        flops = (6.0 if fwd_only else 8.0) * rows * rows * dim
+        tf = flops / (st[dom] * 1e-3) / 1e12
+        out[name] = {"ms_per_step_event_median": round(ms, 4), "pairs_per_s": rows * rows / (ms * 1e-3), "loss": float(loss),
+                     "loss_delta_vs_reference": abs(float(loss) - golden) if golden is not None else None,
+                     "dominant_kernel": ("forward" if fwd_only else "backward") + (" (saved exponentials)" if st.get("saved_path") and not fwd_only else ""),
+                     "dominant_kernel_ms": round(st[dom], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
+                     "dominant_kernel_frac_of_peak": round(tf / peak, 4), "peak_tflops": peak,
+                     "workload": f"b={rows} D={dim} {mode} {'fwd' if fwd_only else 'fwd+bwd'}" + (" + influential-sample weights" if influential else "")}
+    case("fp32_b8192_fwd_bwd", 8192, 512, "fp32", False, False, GOLDEN_LOSS_B8192_SEED1234)
+    case("config2_fp32_fwd_b4096", 4096, 512, "fp32", True, False, GOLDEN_LOSS_B4096_SEED1234)
+    case("d1024_bf16_fwd_bwd", 8192, 1024, "bf16", False, False, None)
+    case("d1024_influential", 8192, 1024, "bf16", False, True, None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +203,7 @@ def main():
                     help="untimed device settle steps BEFORE the --warmup steps (GPU clocks / allocator reach steady state "
                          "only after ~20-50 steps: 0.79 -> 0.72 ms/step); reported in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary measurements (fp32, config 2, D = 1024)")
     ap.add_argument("--fwd-only", action="store_true", help="forward under no_grad only (BASELINE configs[1])")
     ap.add_argument("--selftest-emu", action="store_true",
                     help="TESTS ONLY (tests/test_bench_cpu.py): CPU tensors, gloo, the host-emulation build of the kernels -- "
@@ -241,6 +315,39 @@ def main():
     loss_val = float(loss.item())
     ev_ms = sorted(a.elapsed_time(z) for a, z in ev) if ev else []
 
+    # ---- multi-rank diagnostics (untimed, after the measured region): per rank, the HIP-event time of a step and how much of it the
+    # compute stream spent WAITING for collectives (events around every wait: communication not hidden behind compute) ----
+    per_rank = None
+    if world > 1:
+        from crossclr_amd import loss as L
+        diag_steps = 0 if emu else 5
+        waits, steps_ms = [], []
+        for _ in range(diag_steps):
+            L._comm_trace = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            steps_ms.append(e0.elapsed_time(e1))
+            by_tag = {}
+            for tag, a, z in L._comm_trace:
+                by_tag[tag] = by_tag.get(tag, 0.0) + a.elapsed_time(z)
+            waits.append(by_tag)
+        L._comm_trace = None
+        mine = {"rank": rank, "exchange": L._last_exchange_mode,
+                "step_ms_event_median": sorted(steps_ms)[len(steps_ms) // 2] if steps_ms else None,
+                "timed_step_ms_event_median": ev_ms[len(ev_ms) // 2] if ev_ms else None}
+        if waits:
+            tags = sorted({k for w in waits for k in w})
+            med = lambda xs: sorted(xs)[len(xs) // 2]
+            mine["exposed_comm_ms_by_wait"] = {k: round(med([w.get(k, 0.0) for w in waits]), 4) for k in tags}
+            mine["exposed_comm_ms"] = round(med([sum(w.values()) for w in waits]), 4)
+            mine["compute_ms"] = round(mine["step_ms_event_median"] - mine["exposed_comm_ms"], 4)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -253,7 +360,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "SELFTEST on the host emulation of the kernels (not a measurement)", "global_batch": B},
-               "loss": loss_val}
+               "loss": loss_val, "per_rank": per_rank}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         if world > 1:
             dist.barrier()
@@ -282,7 +389,7 @@ def main():
         dom, dom_kernel = "forward", ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel<float, false, 0, false>")
     else:
         dom = "backward_saved" if saved else "backward"
-        dom_kernel = (("fast_bwd_saved_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
+        dom_kernel = (("fast_bwd_dsl_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
                       else ("fast_bwd" if st["fast_path"] else "bwd_kernel"))
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
     traffic = measured_traffic(b, d, args.mode, dom_kernel) if world == 1 and not args.influential else None
@@ -311,6 +418,8 @@ def main():
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": (traffic["source"] + " (rocprofv3 --pmc passes of tools/kbench.py, read from the committed "
                                         "summary -- bench.py cannot profile itself)") if traffic else None,
+                     "traffic_csrc_sha": traffic["csrc_sha"] if traffic else None, "csrc_sha": csrc_sha(),
+                     "traffic_stale": (traffic["csrc_sha"] != csrc_sha()) if traffic else None,
                      "hbm_gbps_at_that_traffic": round(traffic["bytes"] / (st[dom] * 1e-3) / 1e9, 1) if traffic else None,
                      "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
                      "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
@@ -322,12 +431,19 @@ def main():
                      "frac_of_sustained": round(dom_tf / 1650.0, 4) if args.mode == "bf16" else None},
         "kernels": kernels,
     }
+    if per_rank is not None:
+        # (the waits are measured on a handful of extra steps with events around every collective wait: `exposed_comm_ms` is
+        #  communication the compute stream had to sit out, `compute_ms` the rest of that step)
+        out["per_rank"] = per_rank
+        out["config"]["operand_exchange"] = per_rank[0].get("exchange")
     if args.influential:
         out["config"]["pruned_fraction"] = [round(1.0 - float(k.mean()), 4) for k in sw[0]]
     if world == 1 and b == B_PER_GPU and d == DIM and not args.influential:
         out["loss_delta_vs_reference"] = abs(loss_val - GOLDEN_LOSS_B8192_SEED1234)
     if world == 1 and b == 4096 and d == DIM and not args.influential:
         out["loss_delta_vs_reference"] = abs(loss_val - GOLDEN_LOSS_B4096_SEED1234)
+    if world == 1 and b == B_PER_GPU and d == DIM and args.mode == "bf16" and not args.influential and not args.fwd_only and not args.no_secondary:
+        out["secondary"] = secondary_lines(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(b, d, args.fwd_only)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -20,6 +20,7 @@ MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
 ABI_VERSION = 3
+LAUNCH_GROUPS = 8      # CROSSCLR_LAUNCH_GROUPS of include/crossclr.h
 
 
 class Plan(ctypes.Structure):

@@ -90,7 +90,7 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
 //   [4 launch groups][fwd_slots][2*bpad] | colpart (symmetric launch) [<= 2*bpad/128 row blocks][2*bpad]
 //   | colpart (pairs launch) [row blocks][(world-1)/2 ranks * 2*bpad] | header [4][4] ints
 // (the symmetric launch's column sums are read by the finish kernel, so the pairs launch needs its own region)
-static const int kLaunchGroups = 4;
+static const int kLaunchGroups = CROSSCLR_LAUNCH_GROUPS;
 static size_t ws_colpart_off(const crossclr_plan* p) { return (size_t)kLaunchGroups * p->fwd_slots * 2 * p->bpad; }
 static size_t ws_colpart_rows(const crossclr_plan* p) { return (size_t)(2 * p->bpad / 128 + 1); }
 static size_t ws_paircol_off(const crossclr_plan* p) { return ws_colpart_off(p) + ws_colpart_rows(p) * 2 * p->bpad; }
@@ -211,7 +211,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         if (nb > 512) nb = 512;
         plan->loss_ws_doubles = 1 + nb;
     }
-    plan->fwd_ws_floats = ws_flag_off(plan) + 16;
+    plan->fwd_ws_floats = ws_flag_off(plan) + 4 * kLaunchGroups;   // + the launch groups' headers
     const size_t esz = mode == CROSSCLR_MODE_FP32 ? 4 : 2;
     plan->operand_bytes = (size_t)2 * plan->bpad * plan->Dpad * esz;
     plan->gbuf_bytes = (size_t)plan->bwd_slices * 2 * plan->bpad * plan->Dpad * 4;

@@ -90,7 +90,7 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges", "exchange")
+                 "saved_blocks", "recompute_ranges", "exchange", "k_work")
 
 
 _plan_cache: dict = {}
@@ -124,18 +124,48 @@ def _check_equal_rows_per_rank(b: int, D: int, group, dev) -> None:
     _checked_shapes.add(key)
 
 
+_last_exchange_mode = None    # what the most recent sharded forward used ("allgather" | "p2p" | "p2p_each"): read by bench.py
+_comm_trace = None     # bench.py's diagnostic steps set this to a list: (tag, start event, end event) around every wait on a collective
+
+
+def _traced_wait(tag: str, works) -> None:
+    """`work.wait()` makes the compute stream wait for the collective; with tracing on, HIP events around it measure how long the
+    stream actually sat idle (= communication NOT hidden behind compute)."""
+    if not works:
+        return
+    tr = _comm_trace
+    if tr is not None and torch.cuda.is_available():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for w in works:
+            w.wait()
+        e1.record()
+        tr.append((tag, e0, e1))
+    else:
+        for w in works:
+            w.wait()
+
+
 class _OperandExchange:
-    """How the ranks' packed operands reach each other.
+    """How the ranks' packed operands reach each other (CROSSCLR_EXCHANGE; `mode` below).
 
-    all-gather (default): one `all_gather_into_tensor`; forward and backward wait for the same collective.
-    point-to-point, ordered by need (CROSSCLR_EXCHANGE=p2p; pairs scheme only): the forward of rank r touches only the ranks it
-    evaluates itself -- r+1 .. r+K and the antipodal rank -- so those slices travel first (one batch of isend / irecv, every
-    xGMI link busy at once); the slices only the backward's recompute needs (r-K .. r-1) follow in a second batch that has the
-    whole remote forward to hide behind.  Same bytes, less of them on the forward's critical path (4/7 at 8 ranks)."""
+    allgather (default)  one `all_gather_into_tensor`; forward and backward wait for the same collective.
+    p2p                  (pairs scheme only) the forward of rank r touches only the ranks it evaluates itself -- r+1 .. r+K and the
+                         antipodal rank -- so those slices travel first (ONE batch of isend / irecv: every xGMI link busy at once);
+                         the slices only the backward's recompute needs (r-K .. r-1) follow in a second batch that has the whole
+                         remote forward to hide behind.  Same bytes, less of them on the forward's critical path (4/7 at 8 ranks).
+    p2p_each             one isend / irecv pair PER PEER DISTANCE, forward-critical distances first, each with its own completion:
+                         `wait_peer(r)` returns as soon as rank r's slice has landed, so the block against r can start while later
+                         slices are still on the wire ("remote column tiles start as each peer's slice lands").
+                         The price: a communicator executes its operations in order, so the distances go out one after another
+                         (one link at a time) instead of all links at once.
+    Which one wins on a real 8-GPU node is an open measurement: `bench.py --gpus N` reports the exchange it used and the time the
+    compute stream spent waiting for it."""
 
-    def __init__(self, xcols, xhat, group, world, rank, first_peers=None):
+    def __init__(self, xcols, xhat, group, world, rank, first_peers=None, each=False):
         import torch.distributed as dist
-        self._first, self._rest = [], []
+        self.mode = "allgather" if first_peers is None else ("p2p_each" if each else "p2p")
+        self._first, self._rest, self._peer = [], [], {}
         if first_peers is None:
             self._first = [dist.all_gather_into_tensor(xcols, xhat, group=group, async_op=True)]
             return
@@ -145,27 +175,68 @@ class _OperandExchange:
         others = [(rank + d) % world for d in range(1, world)]
         early = [r for r in others if r in first_peers]
         late = [r for r in others if r not in first_peers]
+        to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None and group is not dist.group.WORLD else (lambda r: r)
+        if each:
+            # distance d: receive from rank + d, send to rank - d -- every rank posts the distances in the SAME order (the order in
+            # which rank r needs rank r + d), so the pairs match up without a deadlock
+            for r in early + late:
+                d = (r - rank) % world
+                ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group),
+                       dist.P2POp(dist.isend, xhat, to_global((rank - d) % world), group)]
+                self._peer[r] = dist.batch_isend_irecv(ops)
+            return
         # rank s receives this rank's slice early iff this rank is one of ITS first peers: the offsets are symmetric
         offs_early = {(q - rank) % world for q in early}
         send_early = [(rank - d) % world for d in sorted(offs_early)]
         send_late = [r for r in others if r not in send_early]
-        to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None and group is not dist.group.WORLD else (lambda r: r)
         for recv_from, send_to, works in ((early, send_early, self._first), (late, send_late, self._rest)):
             ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group) for r in recv_from]
             ops += [dist.P2POp(dist.isend, xhat, to_global(r), group) for r in send_to]
             if ops:
                 works.extend(dist.batch_isend_irecv(ops))
 
+    def wait_peer(self, r):
+        """The slice of rank r has landed (p2p_each: exactly that; otherwise: the batch it travels in)."""
+        if self.mode == "p2p_each":
+            _traced_wait("operands:peer", self._peer.pop(r, None))
+        else:
+            self.wait_forward()
+
     def wait_forward(self):
-        for w in self._first:
-            w.wait()
+        _traced_wait("operands:forward", self._first)
         self._first = []
 
     def wait(self):
         self.wait_forward()
-        for w in self._rest:
-            w.wait()
+        _traced_wait("operands:late", self._rest)
         self._rest = []
+        for r in list(self._peer):
+            _traced_wait("operands:peer", self._peer.pop(r))
+
+
+# the pairs scheme's column-sum exchange: (device, world, rank, n2, npairs) -> (outbox, inbox, send / receive split sizes); the
+# buffers are reused from step to step (a step's all-to-all has completed -- on the compute stream's order -- before the next
+# step's kernels overwrite the outbox)
+_pair_buffers: dict = {}
+
+
+def _pair_exchange_buffers(dev, world, rank, n2, npairs):
+    key = (str(dev), world, rank, n2, npairs)
+    got = _pair_buffers.get(key)
+    if got is None:
+        if len(_pair_buffers) > 16:
+            _pair_buffers.clear()
+        # rank r evaluates the blocks against r+1 .. r+npairs and owes each of them n2 column sums; it is owed n2 sums by each of
+        # r-npairs .. r-1.  all_to_all_single moves exactly those rows (split sizes: n2 for a partner, 0 otherwise); rows are
+        # ordered by peer rank on both sides.
+        send_to = sorted((rank + 1 + k) % world for k in range(npairs))
+        recv_from = sorted((rank - 1 - k) % world for k in range(npairs))
+        in_split = [n2 if r in send_to else 0 for r in range(world)]
+        out_split = [n2 if r in recv_from else 0 for r in range(world)]
+        outbox = torch.empty(npairs, n2, dtype=torch.float32, device=dev)
+        inbox = torch.empty(npairs, n2, dtype=torch.float32, device=dev)
+        got = _pair_buffers[key] = (outbox, inbox, in_split, out_split, {r: i for i, r in enumerate(send_to)})
+    return got
 
 
 class _Range:
@@ -291,18 +362,28 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         # while the local column block is processed on the compute stream
         ws.xcols = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device=dev)
         first_peers = None
-        if (os.environ.get("CROSSCLR_EXCHANGE") == "p2p" and world >= 3 and plan.fast_path == 1 and not small_tau and
+        xmode = os.environ.get("CROSSCLR_EXCHANGE", "allgather")
+        if (xmode in ("p2p", "p2p_each") and world >= 3 and plan.fast_path == 1 and not small_tau and
                 os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1"):
-            first_peers = {(rank + 1 + k) % world for k in range((world - 1) // 2)}
+            first_peers = [(rank + 1 + k) % world for k in range((world - 1) // 2)]     # in the order the forward needs them
             if world % 2 == 0:
-                first_peers.add((rank + world // 2) % world)
-        gather = ws.exchange = _OperandExchange(ws.xcols, ws.xhat, group, world, rank, first_peers)
-        if ws.k_rows is not None:
+                first_peers.append((rank + world // 2) % world)
+        gather = ws.exchange = _OperandExchange(ws.xcols, ws.xhat, group, world, rank, first_peers, each=(xmode == "p2p_each"))
+        global _last_exchange_mode
+        _last_exchange_mode = gather.mode
+        ws.k_work = None
+        if ws.k_rows is not None:   # (asynchronous: the local block does not need the other ranks' negative scales)
             ws.k_cols = torch.empty(world * ws.k_rows.numel(), **f32)
-            dist.all_gather_into_tensor(ws.k_cols, ws.k_rows, group=group)
+            ws.k_work = dist.all_gather_into_tensor(ws.k_cols, ws.k_rows, group=group, async_op=True)
     else:
         ws.xcols = ws.xhat
         ws.exchange = None
+        ws.k_work = None
+
+    def k_cols_ready():
+        if ws.k_work is not None:
+            _traced_wait("negative scales", [ws.k_work])
+            ws.k_work = None
     # Small temperatures (max |logit| = max(1,|w|)/tau > 128): no single soft-max shift fits fp32.  Like the reference's
     # float64 soft-max (loss.py:60) the rows then get their own shift -- the row maximum, found by a first pass -- and the
     # generic tiled kernels do the rest (no symmetric evaluation, no pair scheme, no save-for-backward in this regime).
@@ -331,66 +412,78 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     save_remote = (sharded and world >= 2 and ws.stash is not None and plan.fast_path == 1 and (use_pairs or world == 2) and
                    lib.crossclr_rect_stash_bytes(pp, 1) > 0 and   # (0 beyond D = 1024: the register-resident kernels end there)
                    os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1")
-    if save_remote:
-        gather.wait_forward()   # (point-to-point exchange: the peers this rank evaluates itself; all-gather: everything)
+    npairs = (world - 1) // 2 if use_pairs else 0
+    if sharded and (save_remote or use_pairs):
         n2 = 2 * plan.bpad
-        npairs = (world - 1) // 2 if use_pairs else 0
+        k_cols_ready()
         sw_all = _sw(ws.k_rows, ws.k_cols, None)
-        ws.saved_blocks, ws.recompute_ranges = [], []
+        peers = [(rank + 1 + k) % world for k in range(npairs)]
+        opp = (rank + world // 2) % world if world % 2 == 0 else None    # the antipodal rank (at 2 ranks: the other rank)
+        if save_remote:
+            ws.saved_blocks, ws.recompute_ranges = [], []
         if npairs:
-            colsum = torch.empty(npairs * n2, **f32)
-            st = torch.empty(lib.crossclr_rect_stash_bytes(pp, npairs), dtype=torch.uint8, device=dev)
-            nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), (rank + 1) % world, npairs, 1, ws.temperature,
-                                                     ws.negative_w, sw_all, _ptr(part), plan.fwd_slots, _ptr(colsum), _ptr(st), stream))
-            ws.saved_blocks.append(((rank + 1) % world, npairs, st))
-            ws.recompute_ranges.append(((rank - npairs) % world, npairs))
-        if world % 2 == 0:   # the antipodal rank (at 2 ranks: the other rank): both sides evaluate their own rows
-            opp = (rank + world // 2) % world
-            st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
-            nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), opp, 1, 0, ws.temperature, ws.negative_w,
-                                                     sw_all, _ptr(part), (2 if npairs else 1) * plan.fwd_slots, None, _ptr(st), stream))
-            ws.saved_blocks.append((opp, 1, st))
+            outbox, inbox, in_split, out_split, out_row = _pair_exchange_buffers(dev, world, rank, n2, npairs)
+        # One launch per peer when the operands arrive peer by peer (p2p_each) and the workspace has a launch group for each
+        # (local + peers + antipode + received <= 8); otherwise ONE launch over the whole pair range behind one wait.
+        per_peer = npairs > 0 and gather.mode == "p2p_each" and npairs + 3 <= nat.LAUNCH_GROUPS
+        group_of = 1
+        if npairs and per_peer:
+            for k, peer in enumerate(peers):
+                gather.wait_peer(peer)
+                cs = outbox[out_row[peer]]
+                if save_remote:
+                    st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
+                    nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), peer, 1, 1, ws.temperature, ws.negative_w,
+                                                             sw_all, _ptr(part), group_of * plan.fwd_slots, _ptr(cs), _ptr(st), stream))
+                    ws.saved_blocks.append((peer, 1, st))
+                else:
+                    nat.check(lib.crossclr_forward_pairs(pp, _ptr(ws.xhat), _ptr(ws.xcols), peer, 1, ws.temperature, ws.negative_w,
+                                                         sw_all, _ptr(part), group_of * plan.fwd_slots, _ptr(cs), stream))
+                group_of += 1
         elif npairs:
-            nat.check(lib.crossclr_forward_add(pp, _ptr(part), 2 * plan.fwd_slots, None, stream))
+            gather.wait_forward()   # (p2p: the peers this rank evaluates itself; all-gather: everything)
+            colsum = torch.empty(npairs * n2, **f32)
+            if save_remote:
+                st = torch.empty(lib.crossclr_rect_stash_bytes(pp, npairs), dtype=torch.uint8, device=dev)
+                nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), peers[0], npairs, 1, ws.temperature,
+                                                         ws.negative_w, sw_all, _ptr(part), plan.fwd_slots, _ptr(colsum), _ptr(st), stream))
+                ws.saved_blocks.append((peers[0], npairs, st))
+            else:
+                nat.check(lib.crossclr_forward_pairs(pp, _ptr(ws.xhat), _ptr(ws.xcols), peers[0], npairs, ws.temperature,
+                                                     ws.negative_w, sw_all, _ptr(part), plan.fwd_slots, _ptr(colsum), stream))
+            # the outbox rows are ordered by peer rank (the all-to-all's order), the launch's by distance: one small copy per peer
+            cv = colsum.view(npairs, n2)
+            for k, peer in enumerate(peers):
+                outbox[out_row[peer]].copy_(cv[k])
+            group_of = 2
+        if save_remote and npairs:
+            ws.recompute_ranges.append(((rank - npairs) % world, npairs))
+        if opp is not None:   # both sides evaluate their own rows of the antipodal block
+            gather.wait_peer(opp)
+            if save_remote:
+                st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
+                nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), opp, 1, 0, ws.temperature, ws.negative_w,
+                                                         sw_all, _ptr(part), group_of * plan.fwd_slots, None, _ptr(st), stream))
+                ws.saved_blocks.append((opp, 1, st))
+            else:
+                sw_opp = None
+                if ws.k_rows is not None:
+                    sw_opp = ctypes.pointer(nat.SampleWeights(ws.k_rows.data_ptr(), ws.k_cols.data_ptr() + 4 * opp * n2, 0))
+                nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), ctypes.c_void_p(ws.xcols.data_ptr() + opp * plan.operand_bytes),
+                                                 1, opp, -1, ws.temperature, ws.negative_w, sw_opp, _ptr(part),
+                                                 group_of * plan.fwd_slots, stream))
+            group_of += 1
         if npairs:
-            outbox = torch.zeros(world, n2, **f32)
-            outbox[[(rank + 1 + k) % world for k in range(npairs)]] = colsum.view(npairs, n2)
-            inbox = torch.empty(world, n2, **f32)
-            dist.all_to_all_single(inbox.view(-1), outbox.view(-1), group=group)
-            received = inbox.sum(0)         # fixed order over source ranks: deterministic (kept in a variable: _ptr is a bare address)
-            nat.check(lib.crossclr_forward_add(pp, _ptr(part), 3 * plan.fwd_slots, _ptr(received), stream))
-            nlaunch = 4
-        else:
-            nlaunch = 2
-    elif sharded and use_pairs:
-        gather.wait_forward()   # (point-to-point exchange: the peers this rank evaluates itself; all-gather: everything)
-        n2 = 2 * plan.bpad
-        npairs = (world - 1) // 2
-        colsum = torch.empty(npairs * n2, **f32)
-        nat.check(lib.crossclr_forward_pairs(pp, _ptr(ws.xhat), _ptr(ws.xcols), (rank + 1) % world, npairs, ws.temperature,
-                                             ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots,
-                                             _ptr(colsum), stream))
-        if world % 2 == 0:   # the antipodal rank: both sides evaluate their own rows
-            opp = (rank + world // 2) % world
-            sw_opp = None
-            if ws.k_rows is not None:
-                sw_opp = ctypes.pointer(nat.SampleWeights(ws.k_rows.data_ptr(), ws.k_cols.data_ptr() + 4 * opp * n2, 0))
-            nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), ctypes.c_void_p(ws.xcols.data_ptr() + opp * plan.operand_bytes),
-                                             1, opp, -1, ws.temperature, ws.negative_w, sw_opp, _ptr(part),
-                                             2 * plan.fwd_slots, stream))
-        else:
-            nat.check(lib.crossclr_forward_add(pp, _ptr(part), 2 * plan.fwd_slots, None, stream))
-        # ship colsum[k] to rank+1+k: one all-to-all of [world][2*bpad] outboxes (row s goes to rank s; zeros where this rank
-        # evaluated nothing for s) -- world x less traffic than gathering every rank's whole outbox
-        outbox = torch.zeros(world, n2, **f32)
-        outbox[[(rank + 1 + k) % world for k in range(npairs)]] = colsum.view(npairs, n2)
-        inbox = torch.empty(world, n2, **f32)
-        dist.all_to_all_single(inbox.view(-1), outbox.view(-1), group=group)
-        received = inbox.sum(0)         # fixed order over source ranks: deterministic
-        nat.check(lib.crossclr_forward_add(pp, _ptr(part), 3 * plan.fwd_slots, _ptr(received), stream))
-        nlaunch = 4
+            # ship the column sums of block (r, s) to rank s: ONE all-to-all that moves exactly the rows somebody is owed
+            # (npairs x 2 bpad floats out, as many in; the received rows are added in rank order: deterministic)
+            dist.all_to_all_single(inbox.view(-1), outbox.view(-1), output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+            received = inbox.sum(0) if npairs > 1 else inbox[0]     # (kept in a variable: _ptr is a bare address)
+            nat.check(lib.crossclr_forward_add(pp, _ptr(part), group_of * plan.fwd_slots, _ptr(received), stream))
+            group_of += 1
+        nlaunch = group_of
     elif sharded:
         gather.wait()
+        k_cols_ready()
         nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
                                          ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, stream))
     with _Range("crossclr.forward_finish"):
@@ -505,7 +598,7 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
                                           _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
     if ws.sharded and ws.shift is None and ws.saved_blocks is not None:
         if ws.wrz_cols is None:
-            ws.stats_work.wait()
+            _traced_wait("statistics", [ws.stats_work])
             ws.wrz_cols = ws.rz_cols * ws.negative_w
         sw_all = _sw(ws.k_rows, ws.k_cols, None)
         for first, n, st in ws.saved_blocks:        # blocks this rank evaluated in the forward: from their saved exponentials
@@ -521,7 +614,7 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         ws.saved_blocks = None
     elif ws.sharded and ws.shift is None:
         if ws.wrz_cols is None:
-            ws.stats_work.wait()
+            _traced_wait("statistics", [ws.stats_work])
             ws.wrz_cols = ws.rz_cols * ws.negative_w
         if ws.exchange is not None:
             ws.exchange.wait()     # this launch reads EVERY rank's slice of xcols: also the late point-to-point ones

@@ -34,6 +34,7 @@
 extern "C" {
 #endif
 
+#define CROSSCLR_LAUNCH_GROUPS 8   /* launch groups the forward workspace has room for */
 #define CROSSCLR_ABI_VERSION 3
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
@@ -90,8 +91,8 @@ int crossclr_normalize(const crossclr_plan* plan, const void* video, const void*
                        void* xhat, float* inv_norm, float* diag_cos, void* stream);
 
 /* Shifted soft-max denominators of the plan's rows against the given columns, into the forward
- * workspace `part` (plan->fwd_ws_floats floats; up to four launch groups per step: slot0 = L * fwd_slots,
- * L = 0..3 -- the plain sharded scheme uses two):
+ * workspace `part` (plan->fwd_ws_floats floats; up to CROSSCLR_LAUNCH_GROUPS (8) launch groups per step: slot0 = L * fwd_slots,
+ * L = 0..7 -- the plain sharded scheme uses two):
  *   part[slot][2*bpad] = sum over the slot's columns q of exp(s(p,q) * xhat_p . xhat_q / tau - shift)
  * with s = 1 across modalities, negative_weight inside a modality, the intra-modal self pair
  * skipped (its exp(0) = 1 is added by crossclr_forward_finish).  Writes `plan->fwd_slots` slots
@@ -105,7 +106,7 @@ int crossclr_forward(const crossclr_plan* plan, const void* xhat_rows, const voi
                      float temperature, float negative_weight,
                      float* part, int slot0, void* stream);
 
-/* Reduce `nslots` (= fwd_slots times the number of launch groups used, 1..4) partial slots: logz[2][bpad] (natural log of the full denominator),
+/* Reduce `nslots` (= fwd_slots times the number of launch groups used, 1..8) partial slots: logz[2][bpad] (natural log of the full denominator),
  * rz = 1/Z_shifted, wrz = negative_weight * rz (both 0 on padding rows) and
  * loss_sum[0] = sum over valid rows of (logZv + logZt - 2 A_ii)  (double); loss_sum must hold
  * plan->loss_ws_doubles doubles ([1..] are per-block partials, added in index order; afterwards
@@ -179,7 +180,8 @@ int crossclr_backward_finish_w(const crossclr_plan* plan, const float* gbuf,
  * colsum_out[nranks][2][bpad] = for each of those ranks' rows the sum over THIS rank's rows -- the partial row sums
  * that rank needs from this block.  The caller ships colsum_out[i] to rank first_rank+i and feeds what it receives
  * (summed) back with crossclr_forward_add, which makes a launch group out of one ready-made slot (vec == NULL: an empty
- * group).  A step may use up to four launch groups (slot0 = L * fwd_slots, L = 0..3; crossclr_forward_finish:
+ * group).  A step may use up to eight launch groups (slot0 = L * fwd_slots, L = 0..7: local block, one per pair partner or
+ * one for the whole pair range, antipodal rank, received sums; crossclr_forward_finish:
  * nslots = 4 * fwd_slots then).  bf16 register-resident path only (plan->fast_path); sample weights: sw->neg_scale_cols
  * is indexed like xhat_all.                                                                                   */
 int crossclr_forward_pairs(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,

@@ -59,3 +59,16 @@ def test_bench_gpus2_spawns_itself_and_reports_the_global_loss():
     v1, t1 = orc.make_inputs("randn", 32, 32, 1235)
     ref = float(orc.streaming_stats(torch.cat([v0, v1]), torch.cat([t0, t1]), 0.03, 0.8)["loss"])
     assert abs(out["loss"] - ref) < 1e-4
+
+
+def test_bench_gpus8_selftest_with_the_per_peer_exchange():
+    """`bench.py --gpus 8 --selftest-emu` (BASELINE configs 4 / 5's world size): eight gloo ranks, the pair scheme with three pair
+    partners + the antipodal rank, operands exchanged peer by peer (CROSSCLR_EXCHANGE=p2p_each: one launch per partner as its slice
+    lands); the line carries the per-rank diagnostics block and names the exchange."""
+    out = _run(["--gpus", "8", "--selftest-emu", "--rows", "8", "--dim", "16", "--steps", "1", "--warmup", "0", "--prewarm", "0",
+                "--mode", "bf16"], env_extra={"CROSSCLR_EXCHANGE": "p2p_each"}, timeout=1800)
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 64
+    assert len(out["per_rank"]) == 8 and {r["exchange"] for r in out["per_rank"]} == {"p2p_each"}
+    vs, ts = zip(*[orc.make_inputs("randn", 8, 16, 1234 + r) for r in range(8)])
+    ref = float(orc.bf16_operand_model_loss(torch.cat(vs), torch.cat(ts), 0.03, 0.8))
+    assert abs(out["loss"] - ref) < 5e-3 * max(1.0, abs(ref))

@@ -30,6 +30,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         mode, *knobs = mode.split("+")
         if "p2p" in knobs:       # the need-ordered point-to-point operand exchange instead of the all-gather
             os.environ["CROSSCLR_EXCHANGE"] = "p2p"
+        if "each" in knobs:      # one send / receive pair per peer distance, one forward launch per pair partner as its slice lands
+            os.environ["CROSSCLR_EXCHANGE"] = "p2p_each"
         if "nosave" in knobs:    # remote blocks recompute in the backward (reads EVERY rank's slice: also the late p2p ones)
             os.environ["CROSSCLR_DISABLE_REMOTE_SAVE"] = "1"
         if "nopairs" in knobs:   # every rank evaluates all remote blocks itself
@@ -87,7 +89,13 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (4, 24, 16, "bf16+nopairs", 5e-3, 2e-2),
                                                        # 8 ranks (BASELINE configs 4 / 5's world size), tiny shapes: three pairs + the antipode
                                                        (8, 32, 16, "bf16", 5e-3, 2e-2),
-                                                       (8, 32, 16, "bf16+p2p", 5e-3, 2e-2)])
+                                                       (8, 32, 16, "bf16+p2p", 5e-3, 2e-2),
+                                                       # per-peer completion: 4 / 5 / 8 ranks, with the recomputing
+                                                       # remote backward too
+                                                       (4, 24, 16, "bf16+each", 5e-3, 2e-2),
+                                                       (5, 20, 16, "bf16+each", 5e-3, 2e-2),
+                                                       (8, 32, 16, "bf16+each", 5e-3, 2e-2),
+                                                       (5, 20, 16, "bf16+each+nosave", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()
