@@ -91,6 +91,11 @@ _SIGNATURES = {
     "crossclr_backward_finish_p": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long,
                                                   ctypes.c_int, _P, ctypes.c_float, ctypes.POINTER(SampleWeights), _P, _P, _P,
                                                   ctypes.c_long, ctypes.c_long, ctypes.c_int, _P]),
+    # ABI version 3: producer-side fusion (projection head + L2-norm + pack)
+    "crossclr_project_pack": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
+    "crossclr_project_backward_prep": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, _P, _P, _P, _P,
+                                                      ctypes.c_long, _P]),
     # ABI version 3: two-pass soft-max for small temperatures
     "crossclr_needs_row_shift": (ctypes.c_int, [ctypes.c_float, ctypes.c_float]),
     "crossclr_forward_rowmax": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,

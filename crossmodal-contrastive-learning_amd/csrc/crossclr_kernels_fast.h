@@ -784,6 +784,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 }  // namespace crossclr
 #include "crossclr_kernels_sym.h"
 #include "crossclr_kernels_dsl.h"
+#include "crossclr_kernels_project.h"
 namespace crossclr {
 
 // ---------------------------------------------------------------------------------------------

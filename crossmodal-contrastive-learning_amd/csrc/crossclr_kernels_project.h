@@ -1,0 +1,200 @@
+// crossclr_kernels_project.h -- the step BEFORE the loss (reference README.md:24-38: the criterion is fed
+// "features: [bsz, f_dim]" that a projection head produced): linear projection + bias + row L2-normalisation (trainer/loss.py:79-80)
+// + packing into the kernels' operand, in ONE launch -- the separate normalize pass (crossclr_normalize: reads 2 B D fp32, writes
+// the packed operand) and the HBM round trip of the projected features disappear.
+//
+//   project_pack_kernel   Y_m = X_m W_m^T + b_m for both modalities m of the same 64 rows (bf16 MFMA, fp32 accumulate: 64 rows x Dpad
+//                         columns x 2 modalities = 256 accumulator registers per wave), then -- the rows are complete inside the
+//                         block -- ||y||, y / max(||y||, 1e-12), the positive-pair cosine v^_i . t^_i in fp32 (it must NOT come from the
+//                         bf16-rounded operand: its error is multiplied by 1/tau), bf16 pack through LDS, 16-byte coalesced stores.
+//                         HBM-bound (reads 2 b Din inputs once, writes the packed operand once); the weights stay in L2.
+//   project_backward_prep_kernel   the normalise-backward in front of the projection's own backward: from the gradient w.r.t. the unit
+//                         rows (crossclr_backward_finish_p, prenormalized = 1) g_y = (G - y^ (y^ . G)) / ||y||; the two GEMMs that follow
+//                         (dW = g_y^T X, dX = g_y W) are plain library GEMMs on the caller's side.
+#pragma once
+
+namespace crossclr {
+
+// grid = bpad / 64; 4 waves: wave w owns output columns [Dpad/4 * w, Dpad/4 * (w+1)) of all 64 rows and both modalities.
+// DKP = Dpad / 128 = 32-wide column fragments per wave (1..4: Dpad = 128 .. 512).
+template <typename TIN, int DKP>
+__global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, const TIN* xt, long ldv, long ldt, int Din_v, int Din_t,
+                                                              const bf16_t* wv, const bf16_t* wt, int ldw_v, int ldw_t,
+                                                              const float* bias_v, const float* bias_t, Geo g,
+                                                              bf16_t* X, float* inv_norm, float* diag_cos) {
+    constexpr int CF = DKP;                 // column fragments per wave
+    constexpr int DP = DKP * 128;           // Dpad
+    constexpr int KC = 64;                  // K chunk: one 128-byte K-tile row of bf16
+    constexpr int ATILE = 64 * 128;         // 64 rows x 128 bytes
+    constexpr int A0 = 0;                   // [2 buffers][2 modalities][ATILE]
+    constexpr int R0 = 4 * ATILE;           // reduction scratch: [3 quantities][4 waves][64 rows] floats
+    constexpr int LDS_MAIN = R0 + 3 * 4 * 64 * 4;
+    constexpr int OUT_BYTES = 2 * 64 * DP * 2;     // the packed rows of both modalities, staged for coalesced stores
+    constexpr int LDS_BYTES = LDS_MAIN > OUT_BYTES ? LDS_MAIN : OUT_BYTES;
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.x * 64;
+
+    f32x16 acc[2][2][CF];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][rf][cf][r] = 0.f;
+
+    // staging role: row srow, 16 consecutive k from 16 * spair
+    const int srow = tid >> 2, spair = tid & 3;
+    auto stage = [&](int kc, int buf) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const TIN* src = (m == 0 ? xv + (size_t)(row0 + srow) * ldv : xt + (size_t)(row0 + srow) * ldt);
+            struct { bf16_t e[8]; } pk[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {       // 4 x 4 consecutive elements (16-byte loads where the row is fp32 and aligned)
+                double v4[4] = {0.0, 0.0, 0.0, 0.0};
+                if (row0 + srow < g.b) row_load4(src, kc + 16 * spair + 4 * q, m == 0 ? Din_v : Din_t, v4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[q >> 1].e[4 * (q & 1) + j] = f32_to_bf16_bits((float)v4[j]);
+            }
+            unsigned char* tile = lds + A0 + (buf * 2 + m) * ATILE;
+            *reinterpret_cast<u32x4*>(tile + ktile_off(srow, 2 * spair)) = __builtin_bit_cast(u32x4, pk[0]);
+            *reinterpret_cast<u32x4*>(tile + ktile_off(srow, 2 * spair + 1)) = __builtin_bit_cast(u32x4, pk[1]);
+        }
+    };
+    const int nchunks = ((Din_v > Din_t ? Din_v : Din_t) + KC - 1) / KC;     // (the shorter modality multiplies zeros in its last chunks)
+    stage(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage((c + 1) * KC, buf ^ 1);     // (the other buffer: its readers finished before the last barrier)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2][2], b[2][CF];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const unsigned char* tile = lds + A0 + (buf * 2 + m) * ATILE;
+#pragma unroll
+                for (int rf = 0; rf < 2; ++rf) a[m][rf] = Operand<bf16_t>::load(tile, 32 * rf + l31, ks, half);
+                const bf16_t* w = m == 0 ? wv : wt;
+                const int ldw = m == 0 ? ldw_v : ldw_t;
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+                    const int d = CF * 32 * wave + 32 * cf + l31;
+                    const int k = c * KC + 16 * ks + 8 * half;             // (the weights are zero-padded to a multiple of 64 columns)
+                    if (d < g.D && k < ldw) b[m][cf] = *reinterpret_cast<const bf16x8*>(w + (size_t)d * ldw + k);
+                    else b[m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf) acc[m][rf][cf] = mfma_32x32x16_bf16(a[m][rf], b[m][cf], acc[m][rf][cf]);
+        }
+        __syncthreads();
+    }
+    // ---- bias, row statistics: lane (l31, half) holds column d = CF*32*wave + 32 cf + l31 of rows 32 rf + frag_row(r, half) ----
+    float* red = reinterpret_cast<float*>(lds + R0);
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+        float ssv[16], sst[16], dot[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssv[r] = sst[r] = dot[r] = 0.f;
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+            const int d = CF * 32 * wave + 32 * cf + l31;
+            const float bv = (bias_v && d < g.D) ? bias_v[d] : 0.f, bt = (bias_t && d < g.D) ? bias_t[d] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float yv = acc[0][rf][cf][r] + bv, yt = acc[1][rf][cf][r] + bt;
+                acc[0][rf][cf][r] = yv;
+                acc[1][rf][cf][r] = yt;
+                ssv[r] += yv * yv; sst[r] += yt * yt; dot[r] += yv * yt;
+            }
+        }
+        const float sv = halving_sum16(ssv, l31), st = halving_sum16(sst, l31), sd = halving_sum16(dot, l31);
+        if (l31 < 16) {
+            const int row = 32 * rf + frag_row(halving_elem16(l31), half);
+            red[(0 * 4 + wave) * 64 + row] = sv;
+            red[(1 * 4 + wave) * 64 + row] = st;
+            red[(2 * 4 + wave) * 64 + row] = sd;
+        }
+    }
+    __syncthreads();
+    float iv[2][16], it[2][16];
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * rf + frag_row(r, half);
+            const float sv = (red[(0 * 4 + 0) * 64 + row] + red[(0 * 4 + 1) * 64 + row]) + (red[(0 * 4 + 2) * 64 + row] + red[(0 * 4 + 3) * 64 + row]);
+            const float st = (red[(1 * 4 + 0) * 64 + row] + red[(1 * 4 + 1) * 64 + row]) + (red[(1 * 4 + 2) * 64 + row] + red[(1 * 4 + 3) * 64 + row]);
+            const float nv = sqrtf(sv), nt = sqrtf(st);
+            const bool valid = row0 + row < g.b;
+            iv[rf][r] = valid ? 1.f / (nv > 1e-12f ? nv : 1e-12f) : 0.f;     // x / max(||x||, eps), eps = 1e-12 (F.normalize default)
+            it[rf][r] = valid ? 1.f / (nt > 1e-12f ? nt : 1e-12f) : 0.f;
+        }
+    if (wave == 0 && l31 == 0) {      // lanes 0 and 32 of wave 0 cover the 64 rows between them (16 rows per fragment and half)
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rf + frag_row(r, half);
+                const float sd = (red[(2 * 4 + 0) * 64 + row] + red[(2 * 4 + 1) * 64 + row]) + (red[(2 * 4 + 2) * 64 + row] + red[(2 * 4 + 3) * 64 + row]);
+                inv_norm[row0 + row] = iv[rf][r];
+                inv_norm[g.bpad + row0 + row] = it[rf][r];
+                diag_cos[row0 + row] = sd * iv[rf][r] * it[rf][r];
+            }
+    }
+    __syncthreads();     // (the staging area below overlaps the reduction scratch and the A tiles)
+    // ---- unit rows -> bf16 -> LDS [modality][row][Dpad] -> 16-byte coalesced stores ----
+    bf16_t* outl = reinterpret_cast<bf16_t*>(lds);
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+            const int d = CF * 32 * wave + 32 * cf + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rf + frag_row(r, half);
+                outl[(0 * 64 + row) * DP + d] = f32_to_bf16_bits(d < g.D ? acc[0][rf][cf][r] * iv[rf][r] : 0.f);
+                outl[(1 * 64 + row) * DP + d] = f32_to_bf16_bits(d < g.D ? acc[1][rf][cf][r] * it[rf][r] : 0.f);
+            }
+        }
+    __syncthreads();
+    constexpr int PIECES = 2 * 64 * DP * 2 / 16;     // 16-byte pieces of the staged rows
+    for (int i = tid; i < PIECES; i += 256) {
+        const int m = i / (PIECES / 2), rem = i - m * (PIECES / 2);
+        const int row = rem / (DP / 8), pc = rem - row * (DP / 8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + (size_t)i * 16);
+        *reinterpret_cast<u32x4*>(X + ((size_t)m * g.bpad + row0 + row) * g.Dpad + 8 * pc) = v;
+    }
+}
+
+// one wave per row index i (both modalities): g_y = inv_norm (G - y^ (y^ . G)), written as fp32 [b, D] per modality
+__global__ void __launch_bounds__(256) project_backward_prep_kernel(const float* gv, const float* gt, long ldgv, long ldgt, Geo g,
+                                                                    const bf16_t* X, const float* inv_norm, float* ov, float* ot,
+                                                                    long ldo) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= g.b) return;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float* G = m == 0 ? gv + (size_t)i * ldgv : gt + (size_t)i * ldgt;
+        const bf16_t* y = X + ((size_t)m * g.bpad + i) * g.Dpad;
+        float* o = (m == 0 ? ov : ot) + (size_t)i * ldo;
+        double dot = 0.0;
+        for (int d = lane; d < g.D; d += 64) dot += (double)bf16_bits_to_f32(y[d]) * (double)G[d];
+        dot = wave_sum_f64(dot);
+        const float inv = inv_norm[m * g.bpad + i], dt = (float)dot;
+        for (int d = lane; d < g.D; d += 64) o[d] = inv * (G[d] - bf16_bits_to_f32(y[d]) * dt);
+    }
+}
+
+}  // namespace crossclr

@@ -304,11 +304,16 @@ def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
 
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
                   compute_mode: str, group, negative_scale=None, loss_weight=None,
-                  save_for_backward: bool = False, prenormalized: bool = False) -> "tuple[torch.Tensor, _Workspace]":
+                  save_for_backward: bool = False, prenormalized: bool = False, project=None) -> "tuple[torch.Tensor, _Workspace]":
+    """project = (w_video_bf16, w_text_bf16, (ldw_video, ldw_text), bias_video, bias_text, D): `video` / `text` are the projection head's INPUTS
+    [b, Din]; the packed operand comes from crossclr_project_pack (projection + L2-norm + pack in one launch) instead of
+    crossclr_normalize, and the step behaves like prenormalized=True from there on (projection.py)."""
     import torch.distributed as dist
     lib = nat.library()
     dev = video.device
     b, D = video.shape
+    if project is not None:
+        D = int(project[5])
     world = dist.get_world_size(group) if group is not None else 1
     rank = dist.get_rank(group) if group is not None else 0
     # CROSSCLR_FORCE_SHARDED_PATH=1 (test knob): take the multi-rank code path (all-gather, second launch
@@ -351,11 +356,20 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.lw = _pack_pair(loss_weight, b, plan.bpad, dev, "loss_weight")
     ws.k_cols = ws.k_rows
 
-    ws.prenormalized = bool(prenormalized)
-    entry = lib.crossclr_pack if prenormalized else lib.crossclr_normalize    # unit rows are only laid out, not re-normalised
-    with _Range("crossclr.normalize"):
-        nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
-                        _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+    ws.prenormalized = bool(prenormalized) or project is not None
+    if project is not None:
+        if plan.fast_path != 1 or plan.Dpad > 512 or mode != nat.MODE_BF16:
+            raise RuntimeError("the fused projection needs the bf16 register-resident path (embed_dim <= 512)")
+        wv, wt, ldws, bias_v, bias_t, _ = project
+        with _Range("crossclr.project_pack"):
+            nat.check(lib.crossclr_project_pack(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), video.shape[1], text.shape[1],
+                                                ws.in_dtype, _ptr(wv), _ptr(wt), ldws[0], ldws[1], _ptr(bias_v), _ptr(bias_t), _ptr(ws.xhat),
+                                                _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+    else:
+        entry = lib.crossclr_pack if prenormalized else lib.crossclr_normalize    # unit rows are only laid out, not re-normalised
+        with _Range("crossclr.normalize"):
+            nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                            _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
     gather = None
     if sharded:
         # all-gather of the packed operands runs on the collective's own stream (RCCL over xGMI)

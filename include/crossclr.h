@@ -259,6 +259,24 @@ int crossclr_backward_finish_p(const crossclr_plan* plan, const float* gbuf,
                                const double* grad_out, void* grad_video, void* grad_text,
                                long ld_gvideo, long ld_gtext, int prenormalized, void* stream);
 
+/* ---- producer-side fusion: projection head + L2-norm + pack in one launch (bf16 plans, Dpad <= 512) ----
+ * /root/reference/README.md:24-38 feeds the criterion "features: [bsz, f_dim]" that a projection layer produced; this entry point IS
+ * that layer's forward fused with trainer/loss.py:79-80:   y_m = x_m W_m^T + b_m;   xhat_m = y_m / max(||y_m||, 1e-12)
+ *   x_video / x_text  [b, Din_video] / [b, Din_text] row-major (row strides in elements), any supported in_dtype
+ *   w_video / w_text  bf16 [D, ldw_*] row-major = torch.nn.Linear.weight layout, columns zero-padded to ldw_* = a multiple of 64 >= Din_*
+ *   bias_*            fp32 [D] or NULL
+ * writes the packed operand, inv_norm[2][bpad] (= 1 / ||y||) and the fp32 positive-pair cosines diag_cos[bpad] exactly as
+ * crossclr_normalize does -- everything downstream (forward, backward, crossclr_backward_finish_p with prenormalized = 1) is unchanged.
+ * crossclr_project_backward_prep turns the gradient w.r.t. the unit rows (what crossclr_backward_finish_p(prenormalized = 1) returns)
+ * into the gradient w.r.t. y:  g_y = (G - xhat (xhat . G)) / ||y||, fp32 [b, D] per modality; the projection's own backward
+ * (dW = g_y^T x, dx = g_y W, db = column sums) is two plain GEMMs on the caller's side.                                          */
+int crossclr_project_pack(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text, int Din_video,
+                          int Din_text, int in_dtype, const void* w_video, const void* w_text, int ldw_video, int ldw_text, const float* bias_video,
+                          const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream);
+int crossclr_project_backward_prep(const crossclr_plan* plan, const float* g_video, const float* g_text, long ld_gv, long ld_gt,
+                                   const void* xhat, const float* inv_norm, float* gy_video, float* gy_text, long ld_out,
+                                   void* stream);
+
 /* ---- two-pass soft-max for small temperatures (ABI version 3) ------------------------------------------------------
  * The reference's soft-max runs in float64 with a per-row maximum (loss.py:60 after the promotion at :96-100), so it is
  * finite for any temperature; the single common shift of the entry points above covers max |logit| =

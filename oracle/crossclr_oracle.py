@@ -250,6 +250,31 @@ def bf16_operand_model_loss(video: torch.Tensor, text: torch.Tensor, temperature
     return (lzv + lzt - 2 * diag).sum() / (2 * B)
 
 
+def bf16_operand_model_loss_and_grads(video: torch.Tensor, text: torch.Tensor, temperature: float = 0.03,
+                                      negative_weight: float = 0.8):
+    """Loss AND input gradients of the bf16-operand model: the similarity products see the unit rows rounded to bf16, the
+    gradient treats that rounding as the identity (straight-through) -- exactly what the kernels do: the backward's weights and
+    its second operand are the rounded rows, the normalise-backward is exact.  The yardstick for bf16 gradients where the loss
+    (and with it the float64 reference gradient) is nearly zero: aligned pairs."""
+    v = video.double().clone().requires_grad_(True)
+    t = text.double().clone().requires_grad_(True)
+    vh, th = F.normalize(v, dim=1), F.normalize(t, dim=1)
+    vb = vh + (vh.detach().float().bfloat16().double() - vh.detach())
+    tb = th + (th.detach().float().bfloat16().double() - th.detach())
+    it, w = 1.0 / temperature, negative_weight
+    B = video.shape[0]
+    a = vb @ tb.t() * it
+    off = 1.0 - torch.eye(B, dtype=torch.float64)
+    cv = (vb @ vb.t()) * (it * w) * off          # the masked self pair keeps logit 0 (trainer/loss.py:96-97)
+    ct = (tb @ tb.t()) * (it * w) * off
+    lzv = torch.logsumexp(torch.cat([a, cv], 1), 1)
+    lzt = torch.logsumexp(torch.cat([a.t(), ct], 1), 1)
+    diag = (vh * th).sum(1) * it                  # the positive pair's logit comes from the fp32 rows
+    loss = (lzv + lzt - 2 * diag).sum() / (2 * B)
+    loss.backward()
+    return loss.detach(), v.grad, t.grad
+
+
 def make_inputs(kind: str, B: int, D: int, seed: int, dtype: torch.dtype = torch.float32
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Deterministic synthetic inputs shared by goldens, tests and bench.

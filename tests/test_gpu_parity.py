@@ -492,22 +492,8 @@ def test_pair_forward_scheme_equals_single_device(world, B, D, weighted):
     assert abs(loss_pairs - loss1) <= 2e-6 * max(1.0, abs(loss1))
 
 
-@pytest.mark.parametrize("mode,B,D", [("bf16", 2048, 512), ("fp32", 300, 96)])
-def test_prenormalized_entry_equals_the_plain_path(mode, B, D):
-    """unit rows from the producer skip crossclr_normalize (crossclr_pack lays them out); with
-    F.normalize upstream under autograd, loss and input gradients equal the plain path's."""
-    v, t = orc.make_inputs("randn", B, D, 61)
-    m = dict(temperature=0.03, negative_weight=0.8)
-    loss0, gv0, gt0 = run_module(v, t, m, mode)
-    vd = v.cuda().requires_grad_(True)
-    td = t.cuda().requires_grad_(True)
-    loss = crossclr_amd.crossclr_loss(torch.nn.functional.normalize(vd, dim=1), torch.nn.functional.normalize(td, dim=1),
-                                      0.03, 0.8, compute_mode=mode, prenormalized=True)
-    loss.backward()
-    torch.cuda.synchronize()
-    assert abs(loss.item() - loss0.item()) <= 2e-6 * max(1.0, abs(loss0.item()))
-    scale = gv0.abs().max().item()
-    assert (vd.grad - gv0).abs().max().item() <= 1e-4 * scale and (td.grad - gt0).abs().max().item() <= 1e-4 * scale
+# (the caller-side entry points -- prenormalized=True, the fused projection -- are checked against the reference's goldens and the
+#  float64 oracle in tests/test_gpu_projection.py)
 
 
 @pytest.mark.parametrize("world,B,D,weighted", [(2, 512, 128, False), (3, 768, 256, False), (4, 2048, 512, False), (5, 1280, 256, True),
