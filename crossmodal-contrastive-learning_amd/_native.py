@@ -84,6 +84,8 @@ _SIGNATURES = {
                                                   ctypes.c_float, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P, _P]),
     "crossclr_backward_rect_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                     ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    "crossclr_backward_rect_saved_t": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                      ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, _P]),
     "crossclr_backward_ranks": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     # ABI version 3: unit-vector inputs (caller-side fusion)

@@ -6,6 +6,7 @@
 #include "crossclr_kernels_generic.h"
 #ifndef CROSSCLR_NO_FAST
 #include "crossclr_kernels_fast.h"
+#include "crossclr_kernels_project.h"
 #include "crossclr_kernels_saved32.h"
 #endif
 
@@ -536,7 +537,7 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
 #undef CROSSCLR_LS32
         return launch_status("bwd_saved32_kernel");
     }
-    rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, false, stream);
+    rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, 0, stream);
     return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel");
 #endif
 }
@@ -902,8 +903,37 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
     Geo g;
     int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);
     if (rc) return rc;
-    rc = fast_backward_saved(plan, g, xhat_all, stash, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, true, stream);
+    rc = fast_backward_saved(plan, g, xhat_all, stash, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, 1, stream);
     return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel (rect)");
+#endif
+}
+
+// The transpose of one saved rectangular block: what block (this rank x partner) contributes to the PARTNER's gradient buffer.
+extern "C" int crossclr_backward_rect_saved_t(const crossclr_plan* plan, const void* xhat_rows, const void* stash, int first_rank,
+                                              int nranks, int which, float temperature, float negative_weight, const float* rz_rows,
+                                              const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                              const crossclr_sample_weights* sw, float* gpartner, void* stream) {
+    if (!plan || !xhat_rows || !stash || !rz_rows || !wrz_rows || !rz_all || !wrz_all || !gpartner) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved_t needs the register-resident path");
+#else
+    if (!plan->stash_bytes || !plan->fast_path) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
+    if (which < 0 || which >= nranks) return fail(CROSSCLR_E_ARG, "which must be 0 .. nranks-1");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);     // (validates the range; scales)
+    if (rc) return rc;
+    const int partner = (first_rank + which) % plan->world;
+    const size_t n2 = (size_t)2 * plan->bpad;
+    // the kernel sees: rows = the partner's 2 bpad rows (statistics: its segment of the gathered arrays), columns = this rank's own rows
+    g.col_ranks = nranks;        // rank segments per row of the rectangular stash
+    g.skip_rank = which;         // the partner's segment inside a stash row
+    g.col_rank0 = plan->rank; g.col_wrap = 0;
+    g.row_rank = partner;
+    rc = fast_backward_saved(plan, g, xhat_rows, stash, rz_all + partner * n2, wrz_all + partner * n2, rz_rows, wrz_rows, gpartner, 0,
+                             kcols ? kcols + partner * n2 : nullptr, krows, 2, stream);
+    return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel (rect, transposed)");
 #endif
 }
 

@@ -77,7 +77,7 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, bf16x8 a, bf16x8 b) { acc 
 
 // One wave's share of the block (WV = its index, a compile-time constant: the four waves run four copies of the loop whose
 // VMEM instructions sit in DIFFERENT MFMA slots -- see the schedule below -- and whose LDS addresses are immediates).
-template <int DK, bool SW, bool RECT, int XP, int TPRF, int WV>
+template <int DK, bool SW, int MODE, int XP, int TPRF, int WV>
 __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols, const unsigned char* stash, const Geo& g, const float* rz, const float* wrz,
         const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate, int tiles_per_slice, const float* ks, const float* kc) {
     constexpr int RB = DK * 32;            // bytes per row of the (part of the) operand a block multiplies
@@ -100,6 +100,12 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad (per part) in {128, 256, 384, 512}");
     static_assert(PE >= 3, "E / statistics of tile t+2 must be older than the pieces of X(t+1)");
     static_assert(O0 + 3 * 512 <= 160 * 1024, "LDS budget");
+    // MODE 0: the local symmetric block; 1 (RECT): this rank's rows x other ranks' columns, rectangular stash; 2 (TR): the TRANSPOSE of one
+    // rectangular block -- output rows = the partner rank's rows, contraction over THIS rank's rows, every tile read mirrored from
+    // the stash of block (this rank x partner): what the partner would otherwise recompute (crossclr_backward_rect_saved_t).  The host
+    // passes TR launches the local operand / statistics as "columns" and the partner's statistics as "rows"; g.col_ranks = rank
+    // segments per stash row, g.skip_rank = the partner's segment inside it.
+    constexpr bool RECT = MODE == 1, TR = MODE == 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = WV >= 0 ? WV : uniform(tid >> 6);        // WV = -1: one copy of the code for all four waves
     constexpr int WVS = WV >= 0 ? WV : 0;                     // the wave's place in the VMEM schedule
@@ -205,7 +211,9 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     struct EAddr { unsigned R8, wp, m1, b; };
     // known_direct: the caller knows that u >= rb0 (every tile behind a direct one is direct): one addition
     auto eaddr_stage = [&](int stage, int u, EAddr& a, const unsigned char*& out, bool known_direct) {
-        if (RECT || known_direct) {
+        if (TR) {       // stash tile (this rank's row group u, item = partner segment * per_rank + the output row group)
+            if (stage == 2) { unsigned idx = (unsigned)u * (unsigned)(g.col_ranks * per_rank) + (unsigned)(g.skip_rank * per_rank + r32); pin_s(idx); out = stash + (size_t)idx * 2048; }
+        } else if (RECT || known_direct) {
             if (stage == 2) { unsigned idx = Cd + (unsigned)u; pin_s(idx); out = stash + (size_t)idx * 2048; }
         } else if (stage == 0) {
             a.R8 = (unsigned)u & ~(unsigned)(TPR - 1);
@@ -324,7 +332,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     }
 
     if (t < t_end) {
-        const int tm = RECT ? t : (t_end < rb0 ? t_end : rb0);        // tiles [t, tm) are mirrored, [tm, t_end) direct
+        const int tm = RECT ? t : (TR ? t_end : (t_end < rb0 ? t_end : rb0));        // tiles [t, tm) are mirrored, [tm, t_end) direct
         Col cw, cx, ce;    // the next tile to weigh (t+1), to fetch (t+2), to fetch saved exponentials for (t+1+PE)
         ce = col_at(t);
 #pragma unroll
@@ -505,8 +513,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
                     sched_fence();
                     items2(IdxC<s2>{});
                     vmem_items(sc);
-                    if constexpr (s == ADV) {     // nothing of this iteration reads the cursors or the ring stages any more
-                        if constexpr (RECT) { col_next(cw); col_next(cx); col_next(ce); etile_next = eaddr_of(ce.u); }
+                    if constexpr (!RECT && s == ADV) {     // nothing of this iteration reads the cursors or the ring stages any more
                         etile = etile_next;
                         sx = sx + 1 == NSX ? 0 : sx + 1;
                         se = se + 1 == NSE ? 0 : se + 1;
@@ -514,7 +521,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
                         ++t;
                         setup_a();
                     }
-                    if constexpr (s == SETB) setup_b();
+                    if constexpr (!RECT && s == SETB) setup_b();
                 }
                 sched_fence();
             });
@@ -528,6 +535,15 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
 #pragma unroll
             for (int d = 0; d < DI; ++d) { after_wait(B1[d].lo); after_wait(B1[d].hi); B1c[d] = __builtin_bit_cast(bf16x8, B1[d]); }
             // ... X(t+1) has landed (what this iteration issued may still be in flight), for every wave
+            if constexpr (RECT) {   // the segment walk of a rectangular launch branches: only here, where no asm load is in flight
+                col_next(cw); col_next(cx); col_next(ce);
+                etile = eaddr_of(ce.u);
+                sx = sx + 1 == NSX ? 0 : sx + 1;
+                se = se + 1 == NSE ? 0 : se + 1;
+                wslot ^= 1;
+                ++t;
+                setup_a(); setup_b();
+            }
             // (operations issued after X(t+1)'s last piece: the E pieces of the previous iteration and everything of this one; the
             // first iteration's X(t+1) is the last operation of the prologue -- only this iteration's operations follow it)
             if (!(CROSSCLR_DABL & (3 | 4096))) {
@@ -536,9 +552,15 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             first_iter = false;
             if (!(CROSSCLR_DABL & 32)) barrier_keep_dma();
         };
-        while (t + 1 < tm) body(IdxC<true>{}, IdxC<true>{});
-        if (t < tm) body(IdxC<true>{}, IdxC<false>{});
-        while (t < t_end) body(IdxC<false>{}, IdxC<false>{});
+        if constexpr (TR) {            // every tile mirrored (the last iteration weighs a re-fetch of the last tile: never consumed)
+            while (t < t_end) body(IdxC<true>{}, IdxC<true>{});
+        } else {
+            if constexpr (!RECT) {     // (a rectangular block's tiles are all direct)
+                while (t + 1 < tm) body(IdxC<true>{}, IdxC<true>{});
+                if (t < tm) body(IdxC<true>{}, IdxC<false>{});
+            }
+            while (t < t_end) body(IdxC<false>{}, IdxC<false>{});
+        }
         // k-step 1 of the last tile
         static_for<H>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -572,7 +594,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     }
 }
 
-template <int DK, bool SW, bool RECT, int XP = 1, int TPRF = 8>
+template <int DK, bool SW, int MODE, int XP = 1, int TPRF = 8>
 __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
                                                               const float* rz, const float* wrz,
                                                               const float* rz_cols, const float* wrz_cols, float* gbuf,
@@ -610,13 +632,13 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols
     }
     __syncthreads();        // (before any LDS-DMA is in flight: this barrier may drain VMEM)
 #if !CROSSCLR_DSL_STAGGER
-    dsl_wave<DK, SW, RECT, XP, TPRF, -1>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc);
+    dsl_wave<DK, SW, MODE, XP, TPRF, -1>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc);
 #else
     switch (uniform(tid >> 6)) {
-        case 0: dsl_wave<DK, SW, RECT, XP, TPRF, 0>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
-        case 1: dsl_wave<DK, SW, RECT, XP, TPRF, 1>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
-        case 2: dsl_wave<DK, SW, RECT, XP, TPRF, 2>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
-        default: dsl_wave<DK, SW, RECT, XP, TPRF, 3>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
+        case 0: dsl_wave<DK, SW, MODE, XP, TPRF, 0>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
+        case 1: dsl_wave<DK, SW, MODE, XP, TPRF, 1>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
+        case 2: dsl_wave<DK, SW, MODE, XP, TPRF, 2>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
+        default: dsl_wave<DK, SW, MODE, XP, TPRF, 3>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); break;
     }
 #endif
 }

@@ -784,7 +784,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 }  // namespace crossclr
 #include "crossclr_kernels_sym.h"
 #include "crossclr_kernels_dsl.h"
-#include "crossclr_kernels_project.h"
 namespace crossclr {
 
 // ---------------------------------------------------------------------------------------------
@@ -892,11 +891,14 @@ static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const 
     const FwdWork wk = fast_forward_work(p, 1, -1, true);
     return fast_forward_pipe(p, g, wk, x, x, part, colpart, header, 1, ks, ks, stash, stream);
 }
-// rect = false: the symmetric local block (x is both operands).  rect = true: a rectangular block whose forward saved its
-// exponentials (g describes the column ranks; cols / rz_cols / wrz_cols / kc use the column operand's indexing).
+// mode 0: the symmetric local block (x is both operands).  mode 1: a rectangular block whose forward saved its exponentials (g describes
+// the column ranks; cols / rz_cols / wrz_cols / kc use the column operand's indexing).  mode 2: the transpose of ONE rectangular block
+// (crossclr_backward_rect_saved_t): output rows = the partner's, cols / *_cols / kc = this rank's LOCAL operand and statistics,
+// rz / wrz / ks = the partner's statistics; g.col_ranks = rank segments per stash row, g.skip_rank = the partner's segment.
 static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* cols, const void* stash, const float* rz,
                                       const float* wrz, const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
-                                      const float* ks, const float* kc, bool rect, void* stream) {
+                                      const float* ks, const float* kc, int mode, void* stream) {
+    const bool rect = mode == 1;
     const bool skipping = rect && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
     const int ntiles = (rect ? g.col_ranks - (skipping ? 1 : 0) : 1) * (2 * p->bpad / 32);
     if (ntiles <= 0) return CROSSCLR_OK;
@@ -905,44 +907,35 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     const bf16_t* c = (const bf16_t*)cols;
     const unsigned char* st = (const unsigned char*)stash;
 #ifdef CROSSCLR_DSL_MINIMAL   // tuning builds (tools/build_variant.py): only the headline instantiation is compiled (seconds instead of minutes)
-    if (p->Dpad != 512 || ks || rect) return CROSSCLR_E_ARG;
-    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, false>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    if (p->Dpad != 512 || ks || mode != 0) return CROSSCLR_E_ARG;
+    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
     return CROSSCLR_OK;
 #else
+#define CROSSCLR_LB3(DK, SW, XP, TPRF, GRID)                                                                                                   \
+    do {                                                                                                                                        \
+        if (mode == 0) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 0, XP, TPRF>), GRID, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);      \
+        else if (mode == 1) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 1, XP, TPRF>), GRID, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
+        else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 2, XP, TPRF>), GRID, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);                \
+    } while (0)
+#define CROSSCLR_LB(DK, XP, TPRF, GRID) do { if (ks) CROSSCLR_LB3(DK, true, XP, TPRF, GRID); else CROSSCLR_LB3(DK, false, XP, TPRF, GRID); } while (0)
     if (p->Dpad > 512) {   // two column parts of Dpad/2
         dim3 grid2(2 * p->bpad / 128, p->bwd_slices, 2);
-#define CROSSCLR_LBW2(DK, SW, RECT) \
-    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, RECT, 2, 4>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
-#define CROSSCLR_LBW(DK)                                                                             \
-    do {                                                                                              \
-        if (rect) { if (ks) CROSSCLR_LBW2(DK, true, true); else CROSSCLR_LBW2(DK, false, true); }     \
-        else { if (ks) CROSSCLR_LBW2(DK, true, false); else CROSSCLR_LBW2(DK, false, false); }        \
-    } while (0)
         switch (p->Dpad) {
-            case 768: CROSSCLR_LBW(24); break;
-            case 1024: CROSSCLR_LBW(32); break;
+            case 768: CROSSCLR_LB(24, 2, 4, grid2); break;
+            case 1024: CROSSCLR_LB(32, 2, 4, grid2); break;
             default: return CROSSCLR_E_ARG;
         }
-#undef CROSSCLR_LBW
-#undef CROSSCLR_LBW2
         return CROSSCLR_OK;
     }
-#define CROSSCLR_LBS2(DK, SW, RECT) \
-    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, RECT>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc)
-#define CROSSCLR_LBS(DK)                                                              \
-    do {                                                                               \
-        if (rect) { if (ks) CROSSCLR_LBS2(DK, true, true); else CROSSCLR_LBS2(DK, false, true); }    \
-        else { if (ks) CROSSCLR_LBS2(DK, true, false); else CROSSCLR_LBS2(DK, false, false); }        \
-    } while (0)
     switch (p->Dpad) {
-        case 128: CROSSCLR_LBS(8); break;
-        case 256: CROSSCLR_LBS(16); break;
-        case 384: CROSSCLR_LBS(24); break;
-        case 512: CROSSCLR_LBS(32); break;
+        case 128: CROSSCLR_LB(8, 1, 8, grid); break;
+        case 256: CROSSCLR_LB(16, 1, 8, grid); break;
+        case 384: CROSSCLR_LB(24, 1, 8, grid); break;
+        case 512: CROSSCLR_LB(32, 1, 8, grid); break;
         default: return CROSSCLR_E_ARG;
     }
-#undef CROSSCLR_LBS
-#undef CROSSCLR_LBS2
+#undef CROSSCLR_LB
+#undef CROSSCLR_LB3
     return CROSSCLR_OK;
 #endif
 }

@@ -90,7 +90,7 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges", "exchange", "k_work")
+                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers")
 
 
 _plan_cache: dict = {}
@@ -162,10 +162,14 @@ class _OperandExchange:
     Which one wins on a real 8-GPU node is an open measurement: `bench.py --gpus N` reports the exchange it used and the time the
     compute stream spent waiting for it."""
 
-    def __init__(self, xcols, xhat, group, world, rank, first_peers=None, each=False):
+    def __init__(self, xcols, xhat, group, world, rank, first_peers=None, each=False, defer_late=False):
+        """defer_late: the slices no forward block needs (r-K .. r-1) are only requested if somebody asks for them (`wait()`): with
+        partner gradients (crossclr_backward_rect_saved_t) nobody does, and half of the operand traffic never happens.  Every rank
+        must take the same decision (it is derived from the plan and the environment only)."""
         import torch.distributed as dist
         self.mode = "allgather" if first_peers is None else ("p2p_each" if each else "p2p")
         self._first, self._rest, self._peer = [], [], {}
+        self._deferred = None
         if first_peers is None:
             self._first = [dist.all_gather_into_tensor(xcols, xhat, group=group, async_op=True)]
             return
@@ -179,21 +183,32 @@ class _OperandExchange:
         if each:
             # distance d: receive from rank + d, send to rank - d -- every rank posts the distances in the SAME order (the order in
             # which rank r needs rank r + d), so the pairs match up without a deadlock
-            for r in early + late:
-                d = (r - rank) % world
-                ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group),
-                       dist.P2POp(dist.isend, xhat, to_global((rank - d) % world), group)]
-                self._peer[r] = dist.batch_isend_irecv(ops)
+            def post(peers):
+                for r in peers:
+                    d = (r - rank) % world
+                    ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group),
+                           dist.P2POp(dist.isend, xhat, to_global((rank - d) % world), group)]
+                    self._peer[r] = dist.batch_isend_irecv(ops)
+            post(early)
+            if defer_late:
+                self._deferred = lambda: post(late)
+            else:
+                post(late)
             return
         # rank s receives this rank's slice early iff this rank is one of ITS first peers: the offsets are symmetric
         offs_early = {(q - rank) % world for q in early}
         send_early = [(rank - d) % world for d in sorted(offs_early)]
         send_late = [r for r in others if r not in send_early]
-        for recv_from, send_to, works in ((early, send_early, self._first), (late, send_late, self._rest)):
+        def post(recv_from, send_to, works):
             ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group) for r in recv_from]
             ops += [dist.P2POp(dist.isend, xhat, to_global(r), group) for r in send_to]
             if ops:
                 works.extend(dist.batch_isend_irecv(ops))
+        post(early, send_early, self._first)
+        if defer_late:
+            self._deferred = lambda: post(late, send_late, self._rest)
+        else:
+            post(late, send_late, self._rest)
 
     def wait_peer(self, r):
         """The slice of rank r has landed (p2p_each: exactly that; otherwise: the batch it travels in)."""
@@ -206,7 +221,17 @@ class _OperandExchange:
         _traced_wait("operands:forward", self._first)
         self._first = []
 
+    def finish(self):
+        """Everything that was REQUESTED has landed (deferred slices stay unrequested): buffers may be released."""
+        self._deferred, deferred = None, self._deferred
+        self.wait()
+        self._deferred = None
+        del deferred
+
     def wait(self):
+        if self._deferred is not None:      # somebody needs the late slices after all (the recomputing backward): request them now
+            self._deferred()
+            self._deferred = None
         self.wait_forward()
         _traced_wait("operands:late", self._rest)
         self._rest = []
@@ -352,6 +377,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     part = _carve(slab, offs[7], sizes[7], torch.float32)
     nlaunch = 2 if sharded else 1
     pp = ctypes.byref(plan)
+    ws.group, ws.partner_peers = group, None
+    partner_possible = False
     ws.k_rows = _pack_pair(negative_scale, b, plan.bpad, dev, "negative_scale")
     ws.lw = _pack_pair(loss_weight, b, plan.bpad, dev, "loss_weight")
     ws.k_cols = ws.k_rows
@@ -376,13 +403,20 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         # while the local column block is processed on the compute stream
         ws.xcols = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device=dev)
         first_peers = None
+        # Partner gradients (default with the pair scheme and a backward to follow): the rank that evaluated a pair block also forms
+        # that block's contribution to its partner's gradient from the saved exponentials and ships it, instead of the partner
+        # recomputing the block.  Decided from rank-invariant facts only (every rank must agree on what travels).
+        partner_possible = (save_for_backward and world >= 3 and plan.fast_path == 1 and plan.stash_bytes > 0 and not small_tau and
+                            os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1" and os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1" and
+                            os.environ.get("CROSSCLR_PARTNER_GRADS", "1") != "0" and lib.crossclr_rect_stash_bytes(pp, 1) > 0)
         xmode = os.environ.get("CROSSCLR_EXCHANGE", "allgather")
         if (xmode in ("p2p", "p2p_each") and world >= 3 and plan.fast_path == 1 and not small_tau and
                 os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1"):
             first_peers = [(rank + 1 + k) % world for k in range((world - 1) // 2)]     # in the order the forward needs them
             if world % 2 == 0:
                 first_peers.append((rank + world // 2) % world)
-        gather = ws.exchange = _OperandExchange(ws.xcols, ws.xhat, group, world, rank, first_peers, each=(xmode == "p2p_each"))
+        gather = ws.exchange = _OperandExchange(ws.xcols, ws.xhat, group, world, rank, first_peers, each=(xmode == "p2p_each"),
+                                                defer_late=partner_possible)
         global _last_exchange_mode
         _last_exchange_mode = gather.mode
         ws.k_work = None
@@ -408,6 +442,9 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
     # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
     ws.stash = _alloc_stash(plan.stash_bytes, dev) if save_for_backward else None
+    if partner_possible and ws.stash is None:
+        raise RuntimeError("CrossCLR (sharded): could not allocate the saved-exponentials buffer on this rank; the ranks agreed on the "
+                           "partner-gradient scheme, which needs it -- set CROSSCLR_PARTNER_GRADS=0 (or CROSSCLR_DISABLE_SAVE=1) on every rank")
     with _Range("crossclr.forward"):
         if ws.stash is not None:
             nat.check(lib.crossclr_forward_save(pp, _ptr(ws.xhat), ws.temperature, ws.negative_w,
@@ -471,7 +508,10 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                 outbox[out_row[peer]].copy_(cv[k])
             group_of = 2
         if save_remote and npairs:
-            ws.recompute_ranges.append(((rank - npairs) % world, npairs))
+            if partner_possible:
+                ws.partner_peers = peers        # the backward ships these blocks' transposed contributions instead
+            else:
+                ws.recompute_ranges.append(((rank - npairs) % world, npairs))
         if opp is not None:   # both sides evaluate their own rows of the antipodal block
             gather.wait_peer(opp)
             if save_remote:
@@ -517,6 +557,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         loss = (total / (2.0 * b * world)).reshape(())
         if not save_for_backward and ws.exchange is not None:
             ws.exchange.wait()     # nobody will wait later: the late slices' sends / receives must not outlive their buffers
+        elif partner_possible and ws.partner_peers is not None:
+            ws.exchange.finish()   # (deferred late slices are never requested in this scheme)
     else:
         ws.rz_cols, ws.wrz_cols, ws.stats_work = ws.rz, ws.wrz, None
         loss = ws.loss_sum[1]      # = sum / (2 B), written by the finish kernel (a 0-dim view of the 8-byte-per-block loss buffer)
@@ -615,6 +657,28 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
             _traced_wait("statistics", [ws.stats_work])
             ws.wrz_cols = ws.rz_cols * ws.negative_w
         sw_all = _sw(ws.k_rows, ws.k_cols, None)
+        partner_work = None
+        if ws.partner_peers:
+            # Pair blocks, the partner's half first (its transfer then hides behind this rank's own blocks): block (r, s) transposed,
+            # from the exponentials saved for it -> [2 bpad, Dpad] fp32 per partner, shipped with one all-to-all.
+            import torch.distributed as dist
+            n2, npairs = 2 * plan.bpad, len(ws.partner_peers)
+            nel = n2 * plan.Dpad
+            _, _, in_split, out_split, out_row = _pair_exchange_buffers(dev, world, rank, n2, npairs)
+            outg = torch.empty(npairs, nel, dtype=torch.float32, device=dev)
+            ing = torch.empty(npairs, nel, dtype=torch.float32, device=dev)
+            tmp = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
+            for first, n, st in ws.saved_blocks:
+                for which in range(n):
+                    peer = (first + which) % world
+                    if peer not in out_row or peer not in ws.partner_peers:
+                        continue                                # (the antipodal block: both sides own their rows)
+                    nat.check(lib.crossclr_backward_rect_saved_t(pp, _ptr(ws.xhat), _ptr(st), first, n, which, ws.temperature, ws.negative_w,
+                                                                 _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
+                                                                 _ptr(tmp), stream))
+                    torch.sum(tmp.view(-1, nel), 0, out=outg[out_row[peer]])      # the column slices, in index order
+            partner_work = dist.all_to_all_single(ing.view(-1), outg.view(-1), output_split_sizes=[x * plan.Dpad for x in out_split],
+                                                  input_split_sizes=[x * plan.Dpad for x in in_split], group=ws.group, async_op=True)
         for first, n, st in ws.saved_blocks:        # blocks this rank evaluated in the forward: from their saved exponentials
             nat.check(lib.crossclr_backward_rect_saved(pp, _ptr(ws.xcols), _ptr(st), first, n, ws.temperature, ws.negative_w,
                                                        _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
@@ -625,6 +689,11 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
             nat.check(lib.crossclr_backward_ranks(pp, _ptr(ws.xhat), _ptr(ws.xcols), first, n, ws.temperature, ws.negative_w,
                                                   _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
                                                   _ptr(gbuf), 1, stream))
+        if partner_work is not None:
+            _traced_wait("partner gradients", [partner_work])
+            g0 = gbuf[:nel]
+            for k in range(npairs):          # fixed order over the source ranks: deterministic
+                g0 += ing[k]
         ws.saved_blocks = None
     elif ws.sharded and ws.shift is None:
         if ws.wrz_cols is None:

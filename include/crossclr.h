@@ -238,6 +238,17 @@ int crossclr_backward_rect_saved(const crossclr_plan* plan, const void* xhat_all
                                  int first_rank, int nranks, float temperature, float negative_weight,
                                  const float* rz_rows, const float* wrz_rows, const float* rz_all, const float* wrz_all,
                                  const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+/* The other half of a pair block (ABI version 3): the rank that evaluated block (r, s) in the forward holds its exponentials, so it
+ * can also form what that block contributes to rank s's gradient -- sum over r's rows p of W[p][q] xhat_r[p] for every row q of s: the
+ * TRANSPOSE of the block, read from the same stash (8 b^2 D flop) -- instead of rank s recomputing the block (16 b^2 D).
+ * `stash` = the rectangular stash of crossclr_forward_rect_save(first_rank, nranks), `which` = the partner's position in that range;
+ * xhat_rows / rz_rows / wrz_rows = this rank's own operand and statistics, rz_all / wrz_all = the gathered statistics;
+ * gpartner = [plan->bwd_slices][2 bpad][Dpad] fp32 (plan->gbuf_bytes), overwritten: the partner adds the sum of the slices to its own
+ * gradient buffer before crossclr_backward_finish.                                                                              */
+int crossclr_backward_rect_saved_t(const crossclr_plan* plan, const void* xhat_rows, const void* stash, int first_rank, int nranks,
+                                   int which, float temperature, float negative_weight, const float* rz_rows, const float* wrz_rows,
+                                   const float* rz_all, const float* wrz_all, const crossclr_sample_weights* sw, float* gpartner,
+                                   void* stream);
 int crossclr_backward_ranks(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
                             int first_rank, int nranks, float temperature, float negative_weight,
                             const float* rz_rows, const float* wrz_rows, const float* rz_all, const float* wrz_all,

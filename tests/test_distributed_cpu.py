@@ -34,6 +34,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
             os.environ["CROSSCLR_EXCHANGE"] = "p2p_each"
         if "nosave" in knobs:    # remote blocks recompute in the backward (reads EVERY rank's slice: also the late p2p ones)
             os.environ["CROSSCLR_DISABLE_REMOTE_SAVE"] = "1"
+        if "recompute" in knobs:  # the partner of a pair block recomputes it instead of receiving its transposed contribution
+            os.environ["CROSSCLR_PARTNER_GRADS"] = "0"
         if "nopairs" in knobs:   # every rank evaluates all remote blocks itself
             os.environ["CROSSCLR_DISABLE_PAIR_FORWARD"] = "1"
         v, t = orc.make_inputs("randn", B, D, 77)
@@ -95,7 +97,12 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (4, 24, 16, "bf16+each", 5e-3, 2e-2),
                                                        (5, 20, 16, "bf16+each", 5e-3, 2e-2),
                                                        (8, 32, 16, "bf16+each", 5e-3, 2e-2),
-                                                       (5, 20, 16, "bf16+each+nosave", 5e-3, 2e-2)])
+                                                       (5, 20, 16, "bf16+each+nosave", 5e-3, 2e-2),
+                                                       # (the bf16 cases above with >= 3 ranks ship PARTNER GRADIENTS: the evaluator of a
+                                                       #  pair block also forms its transposed contribution; these recompute instead)
+                                                       (4, 24, 16, "bf16+recompute", 5e-3, 2e-2),
+                                                       (5, 20, 16, "bf16+p2p+recompute", 5e-3, 2e-2),
+                                                       (3, 390, 16, "bf16+each", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()

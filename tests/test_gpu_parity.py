@@ -500,7 +500,8 @@ def test_pair_forward_scheme_equals_single_device(world, B, D, weighted):
                                                 (8, 2048, 512, False), (2, 512, 1024, False), (3, 768, 700, True), (8, 2048, 1024, True),
                                                 # BASELINE config 4 at full size: 8 ranks x 8192 rows, every rank played on this GPU
                                                 (8, 65536, 512, False)])
-def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, weighted):
+@pytest.mark.parametrize("partner", [False, True])
+def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, weighted, partner):
     """The sharded step with a backward to follow: pair partners' and the antipodal rank's blocks save their exponentials in the
     forward (crossclr_forward_rect_save) and feed the backward from them (crossclr_backward_rect_saved); the blocks the OTHER
     side of a pair evaluated are recomputed (crossclr_backward_ranks).  One GPU plays every rank through the C-ABI; loss and
@@ -590,7 +591,19 @@ def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, 
         for first, n, st in blocks[r]:
             nat.check(lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, n, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
                                                        sw(r, True, False), p(gbuf), 1, stream))
-        if K:
+        if K and partner:
+            # partner gradients: rank s = r-1-k evaluated block (s, r) and forms its transposed contribution to r's buffer
+            # (crossclr_backward_rect_saved_t, played here by the same GPU); r adds the column slices' sum
+            nel = n2 * pl.Dpad
+            for k in range(K):
+                src = (r - 1 - k) % world
+                xs = xall[src * pl.operand_bytes:(src + 1) * pl.operand_bytes]
+                first, n, st = blocks[src][0]
+                tmp = torch.empty(pl.gbuf_bytes // 4, **f32)
+                nat.check(lib.crossclr_backward_rect_saved_t(ctypes.byref(plans[src]), p(xs), p(st), first, n, k, 0.03, 0.8, p(rz[src]),
+                                                             p(wrz[src]), p(rz), p(wrz), sw(src, True, False), p(tmp), stream))
+                gbuf[:nel] += tmp.view(-1, nel).sum(0)
+        elif K:
             nat.check(lib.crossclr_backward_ranks(pp, p(xr), p(xall), (r - K) % world, K, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
                                                   sw(r, True, False), p(gbuf), 1, stream))
         nat.check(lib.crossclr_backward_finish_w(pp, p(gbuf), p(vd[r * b:]), p(td[r * b:]), vd.stride(0), td.stride(0), nat.IN_F32,

@@ -88,7 +88,22 @@ for world in (1, 2, 4, 8):
     for i, (first, nr, st) in enumerate(saved):
         run(f"bwd_saved[{nr}]" + ("" if i == 0 else "'"), lambda: lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, nr, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc),
                                                                                                    None, p(gbuf), 1, stream))
-    if K:
+    if K and os.environ.get("CROSSCLR_PARTNER_GRADS", "1") != "0":
+        # partner gradients (the default): this rank forms the transposed contribution of each of its K pair blocks for the partner
+        # (crossclr_backward_rect_saved_t), sums the column slices and -- after the exchange, not timed here -- adds what it received
+        tmp = torch.empty(plan.gbuf_bytes // 4, **f32)
+        nel = 2 * plan.bpad * plan.Dpad
+        outg = torch.empty(K, nel, **f32)
+        def partner():
+            rc = 0
+            for k in range(K):
+                rc |= lib.crossclr_backward_rect_saved_t(pp, p(xr), p(st_p), (rank + 1) % world, K, k, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc), None, p(tmp), stream)
+                torch.sum(tmp.view(-1, nel), 0, out=outg[k])
+            for k in range(K):
+                gbuf[:nel] += outg[k]
+            return rc
+        run(f"bwd_partner[{K}] (+slice sums, +adds)", partner)
+    elif K:
         run(f"bwd_recompute[{K}]", lambda: lib.crossclr_backward_ranks(pp, p(xr), p(xall), (rank - K) % world, K, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc),
                                                                        None, p(gbuf), 1, stream))
     run("bwd_finish", lambda: lib.crossclr_backward_finish(pp, p(gbuf), p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(inv), 0.03, p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream))
@@ -96,4 +111,4 @@ for world in (1, 2, 4, 8):
     val = (b * world) ** 2 / (tot * 1e-3)
     base = base or val
     print(f"N={world}: " + " ".join(f"{k}={x:.3f}" for k, x in stages.items()) + f" | compute {tot:.3f} ms/step -> {val:.3e} pairs/s = {val/base:.2f}x of N=1 "
-          f"(all-gather payload in: {(world-1)*plan.operand_bytes/1e6:.0f} MB)")
+          f"(all-gather payload in: {(world-1)*plan.operand_bytes/1e6:.0f} MB" + (f"; partner gradients out: {K * 2 * plan.bpad * plan.Dpad * 4 / 1e6:.0f} MB" if K else "") + ")")
