@@ -208,8 +208,8 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         plan->bwd_slices = sl;
     }
     {
-        int nb = (2 * plan->bpad + 255) / 256;
-        if (nb > 512) nb = 512;
+        int nb = (2 * plan->bpad + 63) / 64;      // finish kernels: 64 rows per block (four lanes per row), grid-stride beyond
+        if (nb > 1024) nb = 1024;
         plan->loss_ws_doubles = 1 + nb;
     }
     plan->fwd_ws_floats = ws_flag_off(plan) + 4 * kLaunchGroups;   // + the launch groups' headers

@@ -488,12 +488,15 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     CROSSCLR_SHARED double red[4];
     const int n = 2 * g.bpad;
     double acc = 0.0;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+    // FOUR lanes per row: lane q of a quad adds the terms k = q, q + 4, ... (independent loads, up to 16 rows of column sums and a
+    // few slots each instead of one chain of ~70), the quad combines in a fixed order -- (s0 + s1) + (s2 + s3) in every lane
+    const int q = threadIdx.x & 3;
+    for (int p = (blockIdx.x * 256 + threadIdx.x) >> 2; p < n; p += gridDim.x * 64) {
         const int mod = p / g.bpad, i = p - mod * g.bpad;
         // shift of this row's sums (natural log): one value for the whole launch, or the row's own maximum (two-pass mode)
         const double shift = (row_shift ? (double)row_shift[p] : (double)g.m2) * (double)kLn2;
         const double self_term = exp(-shift);
-        double s = krows ? self_term * (double)krows[p] : self_term;   // the masked self pair travels with its column
+        double s = 0.0;
         for (int L = 0; L < nlaunch; ++L) {
             const int kind = header[4 * L], tpr = header[4 * L + 1], NT = header[4 * L + 2], per = header[4 * L + 3];
             const float* base = part + (size_t)L * slots_per_launch * n;
@@ -501,29 +504,33 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
             if (kind == 0 && tpr != 0) count = tpr > 0 ? tpr : 0;
             if (kind == 4) {          // generic symmetric launch: every slot is valid; column sums of the row blocks above
                 const int rb = p / (32 * tpr);
-#pragma unroll 8
-                for (int k = 0; k < rb; ++k) s += (double)colpart[(size_t)k * n + p];
+#pragma unroll 4
+                for (int k = q; k < rb; k += 4) s += (double)colpart[(size_t)k * n + p];
             } else if (kind != 0) {
                 const int rb = p / (32 * tpr);
                 count = (fin_prefix(kind, tpr, NT, rb + 1) - 1) / per - fin_prefix(kind, tpr, NT, rb) / per + 1;
                 if (kind == 1) {
-#pragma unroll 8
-                    for (int k = 0; k < rb; ++k) s += (double)colpart[(size_t)k * n + p];   // independent loads, fixed order
+#pragma unroll 4
+                    for (int k = q; k < rb; k += 4) s += (double)colpart[(size_t)k * n + p];   // independent loads, fixed order
                 }
             }
-#pragma unroll 4
-            for (int k = 0; k < count; ++k) s += (double)base[(size_t)k * n + p];
+            for (int k = q; k < count; k += 4) s += (double)base[(size_t)k * n + p];
         }
+        s += wave_xor_f64(s, 1);
+        s += wave_xor_f64(s, 2);
+        s += krows ? self_term * (double)krows[p] : self_term;   // the masked self pair travels with its column
         const bool valid = i < g.b;
         const double lz = shift + log(s);
-        logz[p] = valid ? (float)lz : 0.f;
         const double om = lw ? (double)lw[p] : 1.0;
         const float r = valid ? (float)(om / s) : 0.f;
-        rz[p] = r;
-        wrz[p] = neg_w * r;
-        if (valid) {
-            acc += om * lz;
-            if (mod == 0) acc -= (lw ? om + (double)lw[g.bpad + i] : 2.0) * (double)diag_cos[i] * (double)inv_tau;
+        if (q == 0) {
+            logz[p] = valid ? (float)lz : 0.f;
+            rz[p] = r;
+            wrz[p] = neg_w * r;
+            if (valid) {
+                acc += om * lz;
+                if (mod == 0) acc -= (lw ? om + (double)lw[g.bpad + i] : 2.0) * (double)diag_cos[i] * (double)inv_tau;
+            }
         }
     }
     acc = wave_sum_f64(acc);
