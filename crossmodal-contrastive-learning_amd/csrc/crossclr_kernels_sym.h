@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
 #ifndef CROSSCLR_YABL
 #define CROSSCLR_YABL 0   // timing ablations of this kernel (WRONG results): bit0 every block streams the same 64 column tiles (L2-resident),
                           // bit1 no stash stores, bit2 no column-sum butterfly, bit3 plain epilogue for every tile (no overlap), bit4 no DMA,
-                          // bit5 no epilogue at all, bit6 no barrier
+                          // bit5 no epilogue at all, bit6 no barrier, bit7 every second LDS read of the column tile skipped
 #endif
     const int mt_last = col_segs * per_rank - 1;
     auto tile_of = [&](const Cursor& c) { return (CROSSCLR_YABL & 1) ? (c.mt & 63) : (c.mt < mt_last ? (c.mt < 0 ? 0 : c.mt) : mt_last); };
@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
         u32x4 ring[PF];
         auto fetch = [&](auto ic) {
             constexpr int k = decltype(ic)::value;
+            if ((CROSSCLR_YABL & 128) && (k & 1)) { ring[k % PF] = ring[(k + PF - 1) % PF]; return; }   // (ablation: half the LDS reads)
             ring[k % PF] = lds_read_b128_async<(k >> 3) * 256>(abase[k & 7]);
         };
         // one k-step = two half-slots, each opened by an MFMA (NH == 2: one per row half; NH == 1: the second is empty): wait for
