@@ -1175,3 +1175,14 @@ extern "C" int crossclr_selftest(int which, const void* in, void* out, void* str
     LAUNCH(selftest_kernel, dim3(1), dim3(64), stream, which, in, out);
     return launch_status("selftest_kernel");
 }
+
+#ifdef CROSSCLR_TIMING
+// (variant builds only; not declared in include/crossclr.h) the marks of the most recent pipelined launch: [blocks][8] uint64
+extern "C" int crossclr_debug_timing(unsigned long long* host_out, int nblocks) {
+    if (!host_out || nblocks < 1 || nblocks > 1024) return fail(CROSSCLR_E_ARG, "bad timing request");
+    if (hipDeviceSynchronize() != hipSuccess) return fail(CROSSCLR_E_HIP, "synchronize failed");
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timing), sizeof(unsigned long long) * 8 * (size_t)nblocks) != hipSuccess)
+        return fail(CROSSCLR_E_HIP, "reading the timing marks failed");
+    return CROSSCLR_OK;
+}
+#endif

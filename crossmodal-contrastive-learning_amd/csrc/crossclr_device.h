@@ -86,6 +86,106 @@ template <int MASK> __device__ __forceinline__ float lane_xor(float v) {
     return __builtin_bit_cast(float, r);
 }
 #define CROSSCLR_SHARED __shared__
+
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Work list of the persistent forward, in COST UNITS (shared by the forward kernels, the plan and fwd_finish_kernel).
+// Items = (row block, column tile) pairs, row-block major; a thread block owns the items whose first unit falls into its
+// contiguous range of `per` units.  Rectangular lists (kind 2 / 3): one unit per item.  Symmetric lists (kind 1): the tpr tiles
+// of a row block's diagonal block take the masked, un-overlapped epilogue -- measured at twice a plain tile (tools/timeline.py:
+// the thread block that held the last row blocks' 24 diagonal tiles ran 193 us against a median of 150) -- and loading a row
+// block's fragments costs about one tile: item 0 = 3 units, items 1 .. tpr-1 = 2 units, the rest 1.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int fwdw_items(int kind, int tpr, int NT, int rb) { return kind == 1 ? NT - tpr * rb : NT; }
+__host__ __device__ __forceinline__ int fwdw_item_prefix(int kind, int tpr, int NT, int rb) {      // items before row block rb
+    return kind == 1 ? rb * NT - (tpr / 2) * rb * (rb - 1) : rb * NT;
+}
+__host__ __device__ __forceinline__ int fwdw_unit_prefix(int kind, int tpr, int NT, int rb) {      // units before row block rb
+    return kind == 1 ? rb * (NT + tpr + 1) - (tpr / 2) * rb * (rb - 1) : rb * NT;
+}
+__host__ __device__ __forceinline__ int fwdw_unit_of_item(int kind, int tpr, int j) {              // first unit of item j of its row block
+    return kind != 1 ? j : (j == 0 ? 0 : (j < tpr ? 2 * j + 1 : j + tpr + 1));
+}
+__host__ __device__ __forceinline__ int fwdw_item_at_unit(int kind, int tpr, int u) {              // first item whose first unit is >= u
+    if (kind != 1) return u;
+    if (u <= 0) return 0;
+    int j = u / 2 > 1 ? u / 2 : 1;
+    if (j >= tpr) j = u - tpr - 1 > tpr ? u - tpr - 1 : tpr;
+    return j;
+}
+__host__ __device__ __forceinline__ int fwdw_first_block(int kind, int tpr, int NT, int per, int rb) {
+    return fwdw_unit_prefix(kind, tpr, NT, rb) / per;
+}
+__host__ __device__ __forceinline__ int fwdw_last_block(int kind, int tpr, int NT, int per, int rb) {
+    return (fwdw_unit_prefix(kind, tpr, NT, rb) + fwdw_unit_of_item(kind, tpr, fwdw_items(kind, tpr, NT, rb) - 1)) / per;
+}
+
+struct FwdWork {
+    int kind;   // 1 symmetric, 2 rectangular, 3 rectangular + column sums (0 in the workspace header = dense slots)
+    int tpr;    // 32-column tiles per row block
+    int NB;     // row blocks
+    int NT;     // symmetric: column tiles of the operand; rectangular: usable column tiles
+    int per;    // cost units per thread block
+    int nblk;   // thread blocks
+    int total;  // items
+};
+__host__ __device__ __forceinline__ int fwd_prefix(const FwdWork& w, int rb) { return fwdw_item_prefix(w.kind, w.tpr, w.NT, rb); }
+__host__ __device__ __forceinline__ int fwd_first_block(const FwdWork& w, int rb) { return fwdw_first_block(w.kind, w.tpr, w.NT, w.per, rb); }
+__host__ __device__ __forceinline__ int fwd_last_block(const FwdWork& w, int rb) { return fwdw_last_block(w.kind, w.tpr, w.NT, w.per, rb); }
+// first item of thread block b (= the end of block b - 1's range; `total` past the end of the list)
+__host__ __device__ __forceinline__ int fwd_block_begin(const FwdWork& w, int b) {
+    const int P = b * w.per;
+    if (P >= fwdw_unit_prefix(w.kind, w.tpr, w.NT, w.NB)) return w.total;
+    int rb = 0;
+    while (fwdw_unit_prefix(w.kind, w.tpr, w.NT, rb + 1) <= P) ++rb;
+    const int j = fwdw_item_at_unit(w.kind, w.tpr, P - fwdw_unit_prefix(w.kind, w.tpr, w.NT, rb));
+    return j >= fwdw_items(w.kind, w.tpr, w.NT, rb) ? fwd_prefix(w, rb + 1) : fwd_prefix(w, rb) + j;
+}
+static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, int max_blocks, int tpr) {
+    FwdWork w;
+    w.kind = kind;
+    w.tpr = tpr;
+    w.NB = 2 * bpad / (32 * tpr);
+    w.NT = kind == 1 ? 2 * bpad / 32 : usable_col_tiles;
+    w.total = fwd_prefix(w, w.NB);
+    const int units = fwdw_unit_prefix(kind, tpr, w.NT, w.NB);
+    // every thread block between a row block's first and last one must hold at least one of its items (its slot is summed):
+    // a range is never shorter than the longest item (3 units in a symmetric list)
+    const int min_per = kind == 1 ? 3 : 2;
+    int nb = units / min_per;
+    if (nb > max_blocks) nb = max_blocks;
+    if (nb < 1) nb = 1;
+    w.per = (units + nb - 1) / nb;
+    if (w.per < min_per) w.per = min_per;
+    w.nblk = (units + w.per - 1) / w.per;
+    return w;
+}
+static inline int fwd_max_slots(const FwdWork& w) {
+    int m = 1;
+    for (int rb = 0; rb < w.NB; ++rb) {
+        const int n = fwd_last_block(w, rb) - fwd_first_block(w, rb) + 1;
+        if (n > m) m = n;
+    }
+    return m;
+}
+
+// Timeline instrumentation of the two pipelined kernels (variant builds only: tools/build_variant.py NAME -DCROSSCLR_TIMING;
+// read back with crossclr_debug_timing, tools/timeline.py): thread 0 of every block stamps the constant 100 MHz counter
+// (s_memrealtime) and the shader-clock counter (s_memtime) at a few marks -- block start / first tile ready / main loop done /
+// exit -- which shows the dispatch ramp, the tail, and the clock the kernel actually ran at.
+#if defined(CROSSCLR_TIMING) && !defined(CROSSCLR_EMU)
+__device__ unsigned long long g_timing[1024 * 8];
+__device__ __forceinline__ void timing_mark(int slot) {
+    if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 1024) {
+        unsigned long long* t = g_timing + (blockIdx.x + gridDim.x * blockIdx.y) * 8;
+        t[slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 0) { t[4] = __builtin_amdgcn_s_memtime(); t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+        if (slot == 3) t[5] = __builtin_amdgcn_s_memtime();
+    }
+}
+#else
+__device__ __forceinline__ void timing_mark(int) {}
 #endif
 
 __device__ __forceinline__ bf16_t f32_to_bf16_bits(float f) {

@@ -171,6 +171,10 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     int t = blockIdx.y * tiles_per_slice;
     int t_end = t + tiles_per_slice;
     if (t_end > NT) t_end = NT;
+    // (Equal-length slices on purpose.  A mirrored tile takes ~8-13 % longer than a direct one, so the slice-0 blocks of the upper half of the row
+    // blocks run longest; cutting the slices at equal cost instead levelled the block times (tools/timeline.py) and changed the
+    // launch time by nothing measurable (profiles/r03_timeline_*.txt): under the package power limit the blocks still running speed up
+    // as the others retire.)
     auto clampt = [&](int u) { return u < t_end ? u : t_end - 1; };   // past the end: re-fetch the last tile (fixed VMEM count)
     struct Col { int u, mt, seg, in_seg; };
     auto col_seg_start = [&](Col& c) {
@@ -374,6 +378,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
         col_next(cw);
         if (!(CROSSCLR_DABL & 3)) wait_dma_keep<(NSX - 2) * NXO>();     // X(t) (and every E piece: they were issued first)
         barrier_keep_dma();
+        timing_mark(1);
         int sx = 0, se = 1 % NSE, wslot = 0;
         bool first_iter = true;
         int sx_free = 0, se_free = 0, ue_next = 0;
@@ -568,6 +573,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
         });
         wait_dma();   // the re-fetches past the end must not outlive the block's LDS
     }
+    timing_mark(2);
     // G[row][d]: lane holds column d = 32 (DI wave + di) + l31 of fragment (pi, di) and 16 rows; buffer addressing (one per-lane offset, the row / fragment part as a scalar)
     constexpr unsigned GP = XP * DK * 16 * 4;           // bytes per gradient row
     const BufRsrc rs_g = make_rsrc(gbuf + (size_t)blockIdx.y * 2 * g.bpad * (XP * DK * 16) + (size_t)row0b * (XP * DK * 16) + part * (DK * 16),
@@ -592,6 +598,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             sched_fence();
         }
     }
+    timing_mark(3);
 }
 
 template <int DK, bool SW, int MODE, int XP = 1, int TPRF = 8>
@@ -623,6 +630,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[O0 + 3 * 512];
     const int tid = threadIdx.x;
     const int row0b = blockIdx.x * 128;
+    timing_mark(0);
     // the block's own statistics (mirrored tiles read them as COLUMN statistics)
     if (tid < 128) {
         float* own = reinterpret_cast<float*>(lds + O0);

@@ -254,49 +254,14 @@ __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, un
 
 
 // ---------------------------------------------------------------------------------------------
-// Work list of the persistent forward.  Row block I = 32*tpr rows of the stacked operand (tpr = 8: eight
-// waves per block, Dpad <= 512; tpr = 4: four waves, Dpad <= 1024); column tile t = 32 columns.
+// Work list of the persistent forward.  Row block I = 32*tpr rows of the stacked operand (tpr = 8: 256-row blocks,
+// Dpad <= 512; tpr = 4: 128-row blocks, Dpad <= 1024); column tile t = 32 columns.
 // kind 1 (symmetric: rows and columns are the same operand): row block I owns tiles tpr*I .. NT-1;  kind 2 (rectangular): every row block owns all NC column tiles that are not in the
-// skipped rank.  The (I, t) pairs, row-block major, form a flat list of `total` items that is cut
-// into `nblk` equal contiguous ranges of `per` items -- one persistent thread block each.
+// skipped rank.  The (I, t) pairs, row-block major, form a flat list of `total` items; the list is cut into `nblk` contiguous
+// ranges of equal COST (`per` units each: fwdw_* in crossclr_device.h) -- one persistent thread block each.
 // A row block's partial row sums land in slot (block - first block touching that row block).
 // ---------------------------------------------------------------------------------------------
-struct FwdWork {
-    int kind;   // 1 symmetric, 2 rectangular, 3 rectangular + column sums (0 in the workspace header = dense slots)
-    int tpr;    // 32-column tiles per row block (= waves per thread block)
-    int NB;     // row blocks
-    int NT;     // symmetric: column tiles of the operand; rectangular: usable column tiles
-    int per;    // items per thread block
-    int nblk;   // thread blocks
-    int total;
-};
-__host__ __device__ __forceinline__ int fwd_prefix(const FwdWork& w, int rb) {  // items before row block rb
-    return w.kind == 1 ? rb * w.NT - (w.tpr / 2) * rb * (rb - 1) : rb * w.NT;
-}
-__host__ __device__ __forceinline__ int fwd_first_block(const FwdWork& w, int rb) { return fwd_prefix(w, rb) / w.per; }
-__host__ __device__ __forceinline__ int fwd_last_block(const FwdWork& w, int rb) { return (fwd_prefix(w, rb + 1) - 1) / w.per; }
-static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, int max_blocks, int tpr) {
-    FwdWork w;
-    w.kind = kind;
-    w.tpr = tpr;
-    w.NB = 2 * bpad / (32 * tpr);
-    w.NT = kind == 1 ? 2 * bpad / 32 : usable_col_tiles;
-    w.total = fwd_prefix(w, w.NB);
-    int nb = w.total / 2;                     // at least ~2 tiles per block
-    if (nb > max_blocks) nb = max_blocks;
-    if (nb < 1) nb = 1;
-    w.per = (w.total + nb - 1) / nb;
-    w.nblk = (w.total + w.per - 1) / w.per;
-    return w;
-}
-static inline int fwd_max_slots(const FwdWork& w) {
-    int m = 1;
-    for (int rb = 0; rb < w.NB; ++rb) {
-        const int n = fwd_last_block(w, rb) - fwd_first_block(w, rb) + 1;
-        if (n > m) m = n;
-    }
-    return m;
-}
+// (FwdWork, fwd_make_work, fwd_block_begin, fwd_max_slots: crossclr_device.h -- pure integer code, unit-tested on the host)
 
 // ---------------------------------------------------------------------------------------------
 // The persistent forward itself is fast_fwd_pipe_kernel (crossclr_kernels_sym.h); what it shares with the backward kernels

@@ -475,11 +475,9 @@ __global__ void __launch_bounds__(256) rowmax_combine_kernel(const float* part, 
 // (tpr = 32-column tiles = 32-row groups per row block: row block I = p / (32*tpr)).
 //   kind 0: dense -- header[1] = 0: all `slots_per_launch` slots of the launch are valid for every row;
 //           header[1] = c > 0: the first c slots; header[1] < 0: none (an unused launch group)
-//   kind 1/2: persistent fast forward (symmetric / rectangular): row block I owns slots
-//             0 .. last_block(I) - first_block(I); kind 1 additionally has column sums colpart[I' < I][p]
-__device__ __forceinline__ int fin_prefix(int kind, int tpr, int NT, int rb) {
-    return kind == 1 ? rb * NT - (tpr / 2) * rb * (rb - 1) : rb * NT;
-}
+//   kind 1/2/3: persistent fast forward (symmetric / rectangular / pairs): row block I owns slots
+//             0 .. last_block(I) - first_block(I) (fwdw_*: crossclr_device.h, per = cost units per thread block);
+//             kind 1 additionally has column sums colpart[I' < I][p]
 __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int nlaunch, int slots_per_launch, Geo g,
                                                          const float* diag_cos, float inv_tau, float neg_w, float* logz,
                                                          float* rz, float* wrz, double* loss_ws, const float* colpart,
@@ -508,7 +506,7 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
                 for (int k = q; k < rb; k += 4) s += (double)colpart[(size_t)k * n + p];
             } else if (kind != 0) {
                 const int rb = p / (32 * tpr);
-                count = (fin_prefix(kind, tpr, NT, rb + 1) - 1) / per - fin_prefix(kind, tpr, NT, rb) / per + 1;
+                count = fwdw_last_block(kind, tpr, NT, per, rb) - fwdw_first_block(kind, tpr, NT, per, rb) + 1;
                 if (kind == 1) {
 #pragma unroll 4
                     for (int k = q; k < rb; k += 4) s += (double)colpart[(size_t)k * n + p];   // independent loads, fixed order

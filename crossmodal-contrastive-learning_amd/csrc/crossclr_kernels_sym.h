@@ -46,14 +46,15 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
+    timing_mark(0);
     if (blockIdx.x == 0 && tid == 0) { header[0] = wk.kind; header[1] = TPR; header[2] = wk.NT; header[3] = wk.per; }
     const int NT = wk.NT;                      // KIND 1: column tiles of the operand; KIND 2/3: usable column tiles
     const int per_rank = 2 * g.bpad / QT, per_mod = g.bpad / QT;
     const int skip_seg = (KIND == 2 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
 
-    int w = blockIdx.x * wk.per;
-    int w_end = w + wk.per;
-    if (w_end > wk.total) w_end = wk.total;
+    int w = fwd_block_begin(wk, blockIdx.x);                // (ranges of equal cost, not of equal length: FwdWork)
+    const int w_end = fwd_block_begin(wk, blockIdx.x + 1);
+    if (w >= w_end) return;                                 // (a trailing range that holds no item's first unit)
     // item = (row block rb, index j inside its tile list); mt = the tile's index inside the column operand (DMA / statistics
     // address), seg / in_seg = its rank segment and position inside the segment (modality, ragged test) -- tracked
     // incrementally: no division per tile
@@ -242,6 +243,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     };
 
     int stage = 0;
+    timing_mark(1);
     while (w < w_end) {
         if (cq[0].rb != my_rb) {   // (re)load this wave's 64 rows as MFMA B fragments; first settle what is owed to the old rows
             if (prev.valid) {   // (SW tiles never stay owed: see below)
@@ -423,6 +425,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
         for (int k = 0; k < NST - 1; ++k) cq[k] = cq[k + 1];
         advance(cq[NST - 1]);
     }
+    timing_mark(2);
     wait_dma();      // (the clamped re-fetches past the end of the work list)
     __syncthreads();
     if (pending) { flush(); pending = false; }
@@ -430,6 +433,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     __syncthreads();
     if (pending) flush();
     if (my_rb >= 0) store_rows();
+    timing_mark(3);
 }
 
 }  // namespace crossclr

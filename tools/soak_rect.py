@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch-to-launch bit-identity of the sharded step's kernels through the C-ABI (one GPU plays rank `world // 2`): the pairs /
-antipode forwards with saved exponentials, the rectangular saved backward, the recomputing backward over a rank range."""
+antipode forwards with saved exponentials, the rectangular saved backward and its transposed (partner-gradient) form, the recomputing backward over a rank range."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,6 +32,7 @@ for world, b, D in ((4, 512, 128), (4, 512, 256), (4, 1024, 512), (5, 512, 384),
         stp = torch.zeros(lib.crossclr_rect_stash_bytes(pp, max(K, 1)), dtype=torch.uint8, device="cuda")
         sta = torch.zeros(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device="cuda")
         gbuf = torch.zeros(plan.gbuf_bytes // 4, **f32)
+        gpart = torch.zeros(max(K, 1) * (plan.gbuf_bytes // 4), **f32)
         if K:
             nat.check(lib.crossclr_forward_rect_save(pp, p(xr), p(xall), (rank + 1) % world, K, 1, 0.05, 0.8, None, p(part), plan.fwd_slots, p(colsum), p(stp), st))
         opp = (rank + world // 2) % world
@@ -39,15 +40,18 @@ for world, b, D in ((4, 512, 128), (4, 512, 256), (4, 1024, 512), (5, 512, 384),
             nat.check(lib.crossclr_forward_rect_save(pp, p(xr), p(xall), opp, 1, 0, 0.05, 0.8, None, p(part), 2 * plan.fwd_slots, None, p(sta), st))
         if K:
             nat.check(lib.crossclr_backward_rect_saved(pp, p(xall), p(stp), (rank + 1) % world, K, 0.05, 0.8, p(rzl), p(wrzl), p(rz), p(wrz), None, p(gbuf), 0, st))
+            for u in range(K):      # the partners' halves of the pair blocks, from the same stash
+                nat.check(lib.crossclr_backward_rect_saved_t(pp, p(xr), p(stp), (rank + 1) % world, K, u, 0.05, 0.8, p(rzl), p(wrzl), p(rz), p(wrz), None,
+                                                             p(gpart[u * (plan.gbuf_bytes // 4):]), st))
             nat.check(lib.crossclr_backward_ranks(pp, p(xr), p(xall), (rank - K) % world, K, 0.05, 0.8, p(rzl), p(wrzl), p(rz), p(wrz), None, p(gbuf), 1, st))
         if world % 2 == 0:
             nat.check(lib.crossclr_backward_rect_saved(pp, p(xall), p(sta), opp, 1, 0.05, 0.8, p(rzl), p(wrzl), p(rz), p(wrz), None, p(gbuf), 1, st))
         torch.cuda.synchronize()
         # (slots of the launch groups that ran; the workspace beyond them is never read)
-        cur = (part[plan.fwd_slots * n2: 3 * plan.fwd_slots * n2].clone(), colsum, stp, sta, gbuf)
+        cur = (part[plan.fwd_slots * n2: 3 * plan.fwd_slots * n2].clone(), colsum, stp, sta, gbuf, gpart)
         if ref is None: ref = cur
         else:
-            for name, a, c in zip(("part", "colsum", "stash_pairs", "stash_antipode", "gbuf"), cur, ref):
+            for name, a, c in zip(("part", "colsum", "stash_pairs", "stash_antipode", "gbuf", "gpartner"), cur, ref):
                 if not torch.equal(a, c):
                     bad += 1
                     if bad <= 3: print(f"  world={world} b={b} D={D} iteration {it}: {name} differs in {(a != c).sum().item()} elements")
