@@ -60,12 +60,13 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // tuning knobs from the environment, read ONCE per process (not per call: crossclr_make_plan sits on the step's host path)
 struct EnvKnobs {
-    bool disable_fast, disable_symmetric, disable_save;
+    bool disable_fast, disable_symmetric, disable_save, bwd_dc256;
     int bwd_kernel, fwd_blocks, bwd_slices;
     EnvKnobs() {
         disable_fast = getenv("CROSSCLR_DISABLE_FAST") != nullptr;
         disable_symmetric = getenv("CROSSCLR_DISABLE_SYMMETRIC") != nullptr;
         disable_save = getenv("CROSSCLR_DISABLE_SAVE") != nullptr;
+        bwd_dc256 = getenv("CROSSCLR_BWD_DC256") != nullptr;    // generic backward: D slices of 256 columns even where 512 divides Dpad (A/B)
         const char* e = getenv("CROSSCLR_BWD_KERNEL");
         bwd_kernel = e ? atoi(e) : 0;
         e = getenv("CROSSCLR_FWD_BLOCKS");
@@ -772,7 +773,8 @@ static int backward_generic(const crossclr_plan* p, const Geo& g, const void* ro
         if (shift_rows) { if (krows) CROSSCLR_LB2(DC, true, true); else CROSSCLR_LB2(DC, false, true); }   \
         else { if (krows) CROSSCLR_LB2(DC, true, false); else CROSSCLR_LB2(DC, false, false); }            \
     } while (0)
-    if (p->Dpad % 256 == 0) CROSSCLR_LB(256);
+    if (p->Dpad % 512 == 0 && !env_knobs().bwd_dc256) CROSSCLR_LB(512);
+    else if (p->Dpad % 256 == 0) CROSSCLR_LB(256);
     else if (p->Dpad % 128 == 0) CROSSCLR_LB(128);
     else CROSSCLR_LB(64);
 #undef CROSSCLR_LB
@@ -969,6 +971,11 @@ static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const vo
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((2 * p->b + 3) / 4), block(256);
+    if (p->D <= 256 * kRowCache) {      // row pairs: each raw row read once
+        LAUNCH((bwd_finish_pair_kernel<TIN>), dim3((p->b + 3) / 4), block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+               inv_norm, 1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw, prenormalized);
+        return launch_status("bwd_finish_pair_kernel");
+    }
     LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,
            1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw, prenormalized);
     return launch_status("bwd_finish_kernel");

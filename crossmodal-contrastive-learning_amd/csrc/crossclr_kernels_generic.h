@@ -568,6 +568,8 @@ __global__ void __launch_bounds__(64) fwd_finish_reduce_kernel(double* loss_ws, 
 //   phase C  G[p][d]  += W[p][:] . xhat_Q[:, d]   (MFMA, contraction over the 64 columns q;
 //            the q-contiguous operand comes from ds_read_b64_tr_b16 for bf16, plain ds_read_b32 for fp32)
 // grid = (2*bpad/64, Dpad/DC, column slices).  Accumulators: 64 x DC fp32 per block (64 VGPRs per lane at DC=256).
+// Phase A is repeated by every D slice: 8 + 16 Dpad/DC flop per pair and embedding column, so DC = 512 (the whole row at
+// Dpad = 512: 16 B^2 D executed instead of 24; fp32: the column slice alone fills 128 KiB of the CU's 160 KiB of LDS) where Dpad allows.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DC> struct BwdLds {
     static constexpr int kTileP = 0;
@@ -584,6 +586,7 @@ template <typename T, int DC> __device__ __forceinline__ int xq_off(int q, int d
 template <> __device__ __forceinline__ int xq_off<float, 64>(int q, int d) { return (q * 64 + d) * 4; }
 template <> __device__ __forceinline__ int xq_off<float, 128>(int q, int d) { return (q * 128 + d) * 4; }
 template <> __device__ __forceinline__ int xq_off<float, 256>(int q, int d) { return (q * 256 + d) * 4; }
+template <> __device__ __forceinline__ int xq_off<float, 512>(int q, int d) { return (q * 512 + d) * 4; }
 // bf16: 16-byte chunks XOR-swizzled by (q&3)<<2 so the four rows a transpose-read touches land in
 // four different 64-byte bank groups (needs >= 16 chunks per row, i.e. DC >= 128)
 template <int DC> __device__ __forceinline__ int xq_off_bf16(int q, int d) {
@@ -594,6 +597,7 @@ template <int DC> __device__ __forceinline__ int xq_off_bf16(int q, int d) {
 template <> __device__ __forceinline__ int xq_off<bf16_t, 64>(int q, int d) { return xq_off_bf16<64>(q, d); }
 template <> __device__ __forceinline__ int xq_off<bf16_t, 128>(int q, int d) { return xq_off_bf16<128>(q, d); }
 template <> __device__ __forceinline__ int xq_off<bf16_t, 256>(int q, int d) { return xq_off_bf16<256>(q, d); }
+template <> __device__ __forceinline__ int xq_off<bf16_t, 512>(int q, int d) { return xq_off_bf16<512>(q, d); }
 
 // phase B store of 4 consecutive-q weights of row p (q0 multiple of 4)
 __device__ __forceinline__ void w_store4(unsigned char* wt, int p, int q0, f32x4 w, float*) {
@@ -879,6 +883,73 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
         double x = in_load(own, d) * io;
         double v = clamped ? ghd : (ghd - x * dot);
         in_store(out, d, v * io * go);
+    }
+}
+
+// Rows of at most 256 * kRowCache elements: ONE wave finishes the video row i AND the text row i (each is the other's positive
+// pair), so both raw rows are read from HBM once instead of twice (as own row and as partner): 134 MB instead of 168 MB per
+// launch at B = 8192, D = 512.  Same arithmetic, term by term, as bwd_finish_kernel above.
+template <typename TIN>
+__global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf, int nslices, const TIN* video, const TIN* text, long ldv,
+                                                              long ldt, Geo g, const float* inv_norm, float inv_tau,
+                                                              int Bglobal, const double* grad_out, TIN* gvideo,
+                                                              TIN* gtext, long ldgv, long ldgt, const float* lw, int prenormalized) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;  // 0 .. b-1
+    if (i >= g.b) return;
+    const TIN* pv = video + (size_t)i * ldv;
+    const TIN* pt = text + (size_t)i * ldt;
+    const double iv = (double)inv_norm[i], it = (double)inv_norm[g.bpad + i];
+    const float* grv = gbuf + (size_t)i * g.Dpad;
+    const float* grt = gbuf + ((size_t)g.bpad + i) * g.Dpad;
+    const size_t slice = (size_t)2 * g.bpad * g.Dpad;
+    const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
+    const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
+    const bool clamped_v = iv >= 9.99e11 || prenormalized != 0, clamped_t = it >= 9.99e11 || prenormalized != 0;
+    const double go = grad_out[0];
+    double ghv[kRowCache][4], ght[kRowCache][4], xv[kRowCache][4], xt[kRowCache][4];
+    double dotv = 0.0, dott = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRowCache; ++k) {
+        const int d = 4 * lane + 256 * k;
+        if (d < g.D) {
+            f32x4 sv = *reinterpret_cast<const f32x4*>(grv + d), st = *reinterpret_cast<const f32x4*>(grt + d);
+            for (int sl = 1; sl < nslices; ++sl) {
+                sv += *reinterpret_cast<const f32x4*>(grv + sl * slice + d);
+                st += *reinterpret_cast<const f32x4*>(grt + sl * slice + d);
+            }
+            double a[4], c[4];
+            row_load4(pv, d, g.D, a);
+            row_load4(pt, d, g.D, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = d + j < g.D;
+                ghv[k][j] = in ? ((double)sv[j] * sc - c[j] * it * pc) : 0.0;
+                ght[k][j] = in ? ((double)st[j] * sc - a[j] * iv * pc) : 0.0;
+                xv[k][j] = a[j] * iv;
+                xt[k][j] = c[j] * it;
+                dotv += xv[k][j] * ghv[k][j];
+                dott += xt[k][j] * ght[k][j];
+            }
+        }
+    }
+    dotv = wave_sum_f64(dotv);
+    dott = wave_sum_f64(dott);
+    TIN* ov = gvideo + (size_t)i * ldgv;
+    TIN* ot = gtext + (size_t)i * ldgt;
+#pragma unroll
+    for (int k = 0; k < kRowCache; ++k) {
+        const int d = 4 * lane + 256 * k;
+        if (d < g.D) {
+            double a[4], c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (clamped_v ? ghv[k][j] : (ghv[k][j] - xv[k][j] * dotv)) * iv * go;
+                c[j] = (clamped_t ? ght[k][j] : (ght[k][j] - xt[k][j] * dott)) * it * go;
+            }
+            row_store4(ov, d, g.D, a);
+            row_store4(ot, d, g.D, c);
+        }
     }
 }
 
