@@ -61,7 +61,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(b, d, mode, kernel_substr):
+def measured_traffic(b, d, mode, kernel_substr, kernel_suffix=None):
     """HBM bytes per launch of a kernel from the newest committed PMC summary under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes).
     bench.py cannot run the profiler on itself; None when no summary matches this workload."""
@@ -76,7 +76,7 @@ def measured_traffic(b, d, mode, kernel_substr):
         if (c.get("B"), c.get("D"), c.get("mode")) != (b, d, mode):
             continue
         for name, e in j.get("kernels", {}).items():
-            if kernel_substr in name:
+            if kernel_substr in name and (kernel_suffix is None or name.endswith(kernel_suffix)):
                 best = {"bytes": e["hbm_bytes_corrected"], "source": os.path.relpath(path, ROOT), "csrc_sha": j.get("csrc_sha")}
     return best
 
@@ -375,9 +375,12 @@ def main():
     # algorithmic flops per launch: forward 6*b*b*D, backward 8*b*b*D for the local block
     # forward_save / backward_saved are what a training step launches when the plan has the save-for-backward pair
     # (forward / backward are the recomputing entry points, timed for comparison)
-    alg = {"forward": 6.0 * b * b * d, "backward": 8.0 * b * b * d, "forward_save": 6.0 * b * b * d, "backward_saved": 8.0 * b * b * d}
+    alg = {"forward": 6.0 * b * b * d, "backward": 8.0 * b * b * d, "forward_save": 6.0 * b * b * d, "backward_saved": 8.0 * b * b * d,
+           "backward_saved_lds": 8.0 * b * b * d}
     kernels = {}
-    for k in ("normalize", "forward", "forward_save", "forward_finish", "backward", "backward_saved", "backward_finish"):
+    # (normalize_plain / backward_saved_lds: the pair without the fragment-major operand copy, timed beside the one the step runs)
+    for k in ("normalize", "normalize_plain", "forward", "forward_save", "forward_finish", "backward", "backward_saved", "backward_saved_lds",
+              "backward_finish"):
         if k not in st:
             continue
         kernels[k] = {"ms": round(st[k], 4)}
@@ -392,7 +395,15 @@ def main():
         dom_kernel = (("fast_bwd_dsl_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
                       else ("fast_bwd" if st["fast_path"] else "bwd_kernel"))
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
-    traffic = measured_traffic(b, d, args.mode, dom_kernel) if world == 1 and not args.influential else None
+    # the saved backward has two instantiations per width: column tiles staged through LDS (..., false>) or loaded straight into MFMA
+    # fragments from the fragment-major operand copy (..., true>: what the step runs when stage_times reports xf_path)
+    dom_suffix = None
+    if dom_kernel == "fast_bwd_dsl_kernel":
+        dom_suffix = ", true>" if st.get("xf_path") else ", false>"
+        dom_kernel_label = dom_kernel + ("<..., XF>: column tiles as MFMA fragments from the fragment-major operand" if st.get("xf_path") else "")
+    else:
+        dom_kernel_label = dom_kernel
+    traffic = measured_traffic(b, d, args.mode, dom_kernel, dom_suffix) if world == 1 and not args.influential else None
     step_tf = (6.0 if args.fwd_only else 14.0) * b * B * d / t_step / 1e12  # per-GPU algorithmic flops over the whole step
     out = {
         "metric": f"contrastive-pairs/sec ({what})", "value": B * B / t_step, "unit": "pairs/s",
@@ -411,7 +422,7 @@ def main():
                    "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather of packed operands" if world > 1 else ""),
                    "fast_path": bool(st["fast_path"]), "save_for_backward": saved and not args.fwd_only},
         "loss": loss_val,
-        "roofline": {"bound": "mfma", "kernel": f"{dom_kernel} (crossclr_{dom}; dominant kernel)",
+        "roofline": {"bound": "mfma", "kernel": f"{dom_kernel_label} (crossclr_{dom}{'_xf' if st.get('xf_path') and dom == 'backward_saved' else ''}; dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
                      "source": "HIP events in this process (torch's current stream = the launch stream), average of 10 launches "
                                "after the timed region; the rocprofv3 figure of the same command is under profiles/",

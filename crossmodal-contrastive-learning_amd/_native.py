@@ -19,7 +19,7 @@ HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcro
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
-ABI_VERSION = 3
+ABI_VERSION = 4
 LAUNCH_GROUPS = 8      # CROSSCLR_LAUNCH_GROUPS of include/crossclr.h
 
 
@@ -30,7 +30,8 @@ class Plan(ctypes.Structure):
                 ("fwd_ws_floats", ctypes.c_size_t),
                 ("bwd_slices", ctypes.c_int),
                 ("loss_ws_doubles", ctypes.c_int),
-                ("operand_bytes", ctypes.c_size_t), ("gbuf_bytes", ctypes.c_size_t), ("stash_bytes", ctypes.c_size_t)]
+                ("operand_bytes", ctypes.c_size_t), ("gbuf_bytes", ctypes.c_size_t), ("stash_bytes", ctypes.c_size_t),
+                ("xf_bytes", ctypes.c_size_t)]
 
 
 class SampleWeights(ctypes.Structure):
@@ -78,6 +79,12 @@ _SIGNATURES = {
                                              ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P]),
     "crossclr_backward_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
                                                ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    # ABI version 4: the fragment-major operand copy (column tiles of the saved backward straight into MFMA fragments)
+    "crossclr_normalize_xf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                             _P, _P, _P, _P, _P]),
+    "crossclr_pack_xf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, _P, _P, _P, _P, _P]),
+    "crossclr_backward_saved_xf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
+                                                  ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     # ABI version 3: rectangular blocks with saved exponentials
     "crossclr_rect_stash_bytes": (ctypes.c_size_t, [ctypes.POINTER(Plan), ctypes.c_int]),
     "crossclr_forward_rect_save": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
@@ -132,6 +139,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib: Optional[ctypes.CDLL] = None
 _lib_path: Optional[str] = None
+_injected = False
 
 
 def _bind(path: str) -> ctypes.CDLL:
@@ -169,11 +177,16 @@ def library() -> ctypes.CDLL:
 def use_library_for_testing(path: Optional[str]) -> None:
     """TESTS ONLY: route the binding to another build of the same C-ABI (the host emulation build
     under tests/emu/), or back to the HIP library with None."""
-    global _lib, _lib_path
+    global _lib, _lib_path, _injected
     if path is None:
-        _lib, _lib_path = None, None
+        _lib, _lib_path, _injected = None, None, False
     else:
-        _lib, _lib_path = _bind(path), path
+        _lib, _lib_path, _injected = _bind(path), path, True
+
+
+def injected_for_testing() -> bool:
+    """True while use_library_for_testing() has routed the binding elsewhere (the tests' build re-reads its tuning variables per call)."""
+    return _injected
 
 
 def backend() -> str:

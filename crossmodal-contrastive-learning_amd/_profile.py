@@ -35,17 +35,26 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
     t, w = ws.temperature, ws.negative_w
 
     stash = ws.stash   # None when the plan has no save-for-backward path
+    xf = ws.xf         # None when the plan has no fragment-major operand (then the saved backward stages column tiles through LDS)
     stages = {
-        "normalize": lambda: lib.crossclr_normalize(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
-                                                    p(ws.xhat), p(ws.inv_norm), p(ws.diag), stream),
+        "normalize": (lambda: lib.crossclr_normalize_xf(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                                        p(ws.xhat), p(xf), p(ws.inv_norm), p(ws.diag), stream)) if xf is not None else
+                     (lambda: lib.crossclr_normalize(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                                     p(ws.xhat), p(ws.inv_norm), p(ws.diag), stream)),
+        "normalize_plain": (lambda: lib.crossclr_normalize(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                                           p(ws.xhat), p(ws.inv_norm), p(ws.diag), stream)) if xf is not None else None,
         "forward": lambda: lib.crossclr_forward_w(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, sw_k, p(part), 0, stream),
         "forward_finish": lambda: lib.crossclr_forward_finish_w(pp, p(part), plan.fwd_slots, p(ws.diag), t, w, sw_all,
                                                                 p(ws.logz), p(ws.rz), p(ws.wrz), p(ws.loss_sum), stream),
         "backward": lambda: lib.crossclr_backward_w(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(ws.rz), p(ws.wrz),
                                                     p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream),
         "forward_save": (lambda: lib.crossclr_forward_save(pp, p(ws.xhat), t, w, sw_k, p(part), 0, p(stash), stream)) if stash is not None else None,
-        "backward_saved": (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
-                                                               p(gbuf), 0, stream)) if stash is not None else None,
+        "backward_saved": ((lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream))
+                           if xf is not None else
+                           (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
+                                                                p(gbuf), 0, stream))) if stash is not None else None,
+        "backward_saved_lds": (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
+                                                                   p(gbuf), 0, stream)) if (stash is not None and xf is not None) else None,
         "backward_finish": lambda: lib.crossclr_backward_finish_w(pp, p(gbuf), p(video), p(text), video.stride(0),
                                                                   text.stride(0), ws.in_dtype, p(ws.inv_norm), t, sw_lw,
                                                                   p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
@@ -66,6 +75,7 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
         out[name] = sum(a.elapsed_time(b) for a, b in zip(e0, e1)) / iters
     out["fast_path"] = float(plan.fast_path)
     out["saved_path"] = float(stash is not None)
+    out["xf_path"] = float(xf is not None)
     # the stages a training step actually runs
     out["step_forward"] = out.get("forward_save", out["forward"])
     out["step_backward"] = out.get("backward_saved", out["backward"])

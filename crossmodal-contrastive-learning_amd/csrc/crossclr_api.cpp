@@ -60,12 +60,13 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // tuning knobs from the environment, read ONCE per process (not per call: crossclr_make_plan sits on the step's host path)
 struct EnvKnobs {
-    bool disable_fast, disable_symmetric, disable_save, bwd_dc256;
+    bool disable_fast, disable_symmetric, disable_save, bwd_dc256, disable_xf;
     int bwd_kernel, fwd_blocks, bwd_slices;
     EnvKnobs() {
         disable_fast = getenv("CROSSCLR_DISABLE_FAST") != nullptr;
         disable_symmetric = getenv("CROSSCLR_DISABLE_SYMMETRIC") != nullptr;
         disable_save = getenv("CROSSCLR_DISABLE_SAVE") != nullptr;
+        disable_xf = getenv("CROSSCLR_DISABLE_XF") != nullptr;  // no fragment-major operand copy: the saved backward stages the column tiles through LDS
         bwd_dc256 = getenv("CROSSCLR_BWD_DC256") != nullptr;    // generic backward: D slices of 256 columns even where 512 divides Dpad (A/B)
         const char* e = getenv("CROSSCLR_BWD_KERNEL");
         bwd_kernel = e ? atoi(e) : 0;
@@ -225,6 +226,11 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         const size_t sb = (size_t)2 * plan->bpad * (size_t)2 * plan->bpad * 4;
         if (sb <= ((size_t)16 << 30)) plan->stash_bytes = sb;
     }
+    // the fragment-major copy of the bf16 operand (crossclr_normalize_xf -> crossclr_backward_saved_xf): local block, Dpad <= 512
+    plan->xf_bytes = 0;
+    if (plan->fast_path && plan->fast_bwd && plan->stash_bytes && plan->Dpad <= 512 && !env.disable_xf) plan->xf_bytes = plan->operand_bytes;
+#else
+    plan->xf_bytes = 0;
 #endif
     return CROSSCLR_OK;
 }
@@ -290,6 +296,44 @@ static int normalize_any(const crossclr_plan* plan, const void* video, const voi
         case CROSSCLR_IN_BF16: return normalize_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
     }
     return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
+#ifndef CROSSCLR_NO_FAST
+template <typename TIN, bool NORM>
+static int normalize_xf_t(const crossclr_plan* p, const void* v, const void* t, long ldv, long ldt, void* xhat, void* xf,
+                          float* inv_norm, float* diag, void* stream) {
+    Geo g; memset(&g, 0, sizeof(g));
+    g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
+    LAUNCH((normalize_xf_kernel<TIN, NORM>), dim3(p->bpad / 16), dim3(512), stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+           (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag);
+    return launch_status("normalize_xf_kernel");
+}
+#endif
+template <bool NORM>
+static int normalize_xf_any(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                            void* xhat, void* xf, float* inv_norm, float* diag_cos, void* stream) {
+    if (!plan || !video || !text || !xhat || !xf || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (ld_video < plan->D || ld_text < plan->D) return fail(CROSSCLR_E_ARG, "row stride smaller than D");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "the fragment-major operand needs the register-resident path");
+#else
+    if (!plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major operand (xf_bytes == 0): use crossclr_normalize / crossclr_pack");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return normalize_xf_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F64: return normalize_xf_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F16: return normalize_xf_t<in_f16, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_BF16: return normalize_xf_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+#endif
+}
+extern "C" int crossclr_normalize_xf(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text,
+                                     int in_dtype, void* xhat, void* xhat_xf, float* inv_norm, float* diag_cos, void* stream) {
+    return normalize_xf_any<true>(plan, video, text, ld_video, ld_text, in_dtype, xhat, xhat_xf, inv_norm, diag_cos, stream);
+}
+extern "C" int crossclr_pack_xf(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video, long ld_text,
+                                int in_dtype, void* xhat, void* xhat_xf, float* inv_norm, float* diag_cos, void* stream) {
+    return normalize_xf_any<false>(plan, video_hat, text_hat, ld_video, ld_text, in_dtype, xhat, xhat_xf, inv_norm, diag_cos, stream);
 }
 
 extern "C" int crossclr_pack(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video,
@@ -540,6 +584,25 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
     }
     rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, 0, stream);
     return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel");
+#endif
+}
+
+extern "C" int crossclr_backward_saved_xf(const crossclr_plan* plan, const void* xhat_xf, const void* stash, float temperature,
+                                          float negative_weight, const float* rz, const float* wrz,
+                                          const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat_xf || !stash || !rz || !wrz || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_saved_xf needs the register-resident path");
+#else
+    if (!plan->stash_bytes || !plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major saved backward (stash_bytes / xf_bytes == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    if (krows != kcols) return fail(CROSSCLR_E_ARG, "the local block's row and column negative scales are the same array");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
+    if (rc) return rc;
+    rc = fast_backward_saved(plan, g, xhat_xf, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, 3, stream);
+    return rc ? fail(rc, "fast_backward_saved (xf): unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel (xf)");
 #endif
 }
 

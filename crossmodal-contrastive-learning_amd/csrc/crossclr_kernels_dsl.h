@@ -64,7 +64,35 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, bf16x8 a, bf16x8 b) {
     if (CROSSCLR_DABL & 128) { asm volatile("" : "+a"(acc) : "v"(a), "v"(b)); return; }
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// XF: an MFMA B fragment straight from global memory into VGPRs (buffer_load_dwordx4 ... offen: wave-uniform descriptor in SGPRs,
+// per-lane byte offset, scalar byte offset, 12-bit immediate).  Asm for the same reason as the LDS reads: hipcc's wait-count pass
+// drains the LDS-DMA ring (vmcnt(0)) in front of the first use of an ordinary load; this one it does not see -- its completion is
+// counted by hand (s_waitcnt vmcnt(N): VMEM returns in order) and after_wait() orders every use behind that wait.
+struct RawRsrc { u32x4 v; };
+__device__ __forceinline__ RawRsrc make_raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    RawRsrc r;
+    r.v[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.v[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.v[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
+    r.v[3] = 0x00020000u;      // (the flags word __builtin_amdgcn_make_buffer_rsrc is given everywhere else in this library)
+    return r;
+}
+template <int OFF> __device__ __forceinline__ u32x4 buf_load_b128_async(const RawRsrc& rs, unsigned voff, unsigned soff) {
+    static_assert(OFF >= 0 && OFF < 4096, "12-bit immediate");
+    u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(rs.v), "s"(soff), "n"(OFF));
+    return r;
+}
 #else
+struct RawRsrc { const unsigned char* base; unsigned bytes; };
+__device__ __forceinline__ RawRsrc make_raw_rsrc(const void* base, unsigned bytes) { return RawRsrc{static_cast<const unsigned char*>(base), bytes}; }
+template <int OFF> __device__ __forceinline__ u32x4 buf_load_b128_async(const RawRsrc& rs, unsigned voff, unsigned soff) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    const size_t o = (size_t)voff + soff + OFF;
+    if (o + 16 <= rs.bytes) memcpy(&r, rs.base + o, 16);
+    return r;
+}
 template <int OFF> __device__ __forceinline__ unsigned lds_read_b32_async(unsigned long addr) {
     return *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(addr) + OFF);
 }
@@ -77,7 +105,7 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, bf16x8 a, bf16x8 b) { acc 
 
 // One wave's share of the block (WV = its index, a compile-time constant: the four waves run four copies of the loop whose
 // VMEM instructions sit in DIFFERENT MFMA slots -- see the schedule below -- and whose LDS addresses are immediates).
-template <int DK, bool SW, int MODE, int XP, int TPRF, int WV>
+template <int DK, bool SW, int MODE, int XP, int TPRF, int WV, bool XF = false>
 __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols, const unsigned char* stash, const Geo& g, const float* rz, const float* wrz,
         const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate, int tiles_per_slice, const float* ks, const float* kc) {
     constexpr int RB = DK * 32;            // bytes per row of the (part of the) operand a block multiplies
@@ -87,19 +115,30 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     constexpr int RBG = XP * RB;           // bytes per operand row in memory
     constexpr int DI = DK / 8;             // 32-wide output fragments per wave (its column slice)
     constexpr int H = 4 * DI;              // MFMAs per k-step: 4 row groups x DI fragments
-    constexpr int NSX = 3;                 // column-tile ring
-    constexpr int PE = CROSSCLR_DSL_PE;
+    constexpr int NSX = XF ? 0 : 3;        // column-tile ring (XF: the column tile never touches LDS)
+    constexpr int PE = XF ? 2 : CROSSCLR_DSL_PE;
     constexpr int NSE = PE + 1;            // saved-exponential + statistics rings (private to a wave)
     constexpr int ESTG = 4 * 2048;         // one stage of the E ring: [4 waves][2 KiB]
     constexpr int SSTG = 4 * 256;          // one stage of a statistics ring: [4 waves][64 floats] (the tile's 32 + 32 spare)
-    constexpr int NXO = DK / 4;            // VMEM operations per wave and tile: column-tile pieces ...
+    constexpr int NXO = DK / 4;            // VMEM operations per wave and tile: column-tile pieces (XF: 2 DI fragment loads -- the same number) ...
     constexpr int NEO = 3 + (SW ? 1 : 0);  // ... saved-exponential pieces + statistics
     constexpr int WBUF = 4 * 2048;         // one W slot: [4 row groups][2 KiB]
     constexpr int W0 = NSX * TILE, E0 = W0 + 2 * WBUF, S0 = E0 + NSE * ESTG, K0 = S0 + NSE * SSTG;
     constexpr int O0 = K0 + (SW ? NSE * SSTG : 0);      // the block's own statistics: rz[128] | wrz[128] | k[128]
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad (per part) in {128, 256, 384, 512}");
-    static_assert(PE >= 3, "E / statistics of tile t+2 must be older than the pieces of X(t+1)");
+    static_assert(XF || PE >= 3, "E / statistics of tile t+2 must be older than the pieces of X(t+1)");
+    static_assert(!XF || (MODE == 0 && WV < 0 && NXO == 2 * DI), "XF: the local symmetric block, one copy of the loop");
     static_assert(O0 + 3 * 512 <= 160 * 1024, "LDS budget");
+    // XF ("fragment-major" column operand, crossclr_normalize_xf): `cols` is not the row-major packed operand but XF[tile u = 32 stacked
+    // rows][dt = Dpad/32 column fragments][k-step][lane][8 bf16] -- 1 KiB per (u, dt, k-step), inside it lane (n = lane & 31, kg = lane >> 5)
+    // holds X[32 u + 16 ks + 8 kg + 0..7][32 dt + n]: exactly the B fragment of v_mfma_f32_32x32x16_bf16 for G += W X.  A wave loads the
+    // 2 DI fragments of ITS column slice with 2 DI fully coalesced buffer_load_dwordx4 straight into VGPRs: no LDS-DMA of the column
+    // tile (NXO pieces per wave and tile), no transpose reads (2 DI pairs), 96 KiB of LDS less, and the k-step skew keeps working on
+    // registers.  Two register sets (tile parity): set par holds tile t, set par^1 tile t-1 whose k-step-1 half is multiplied in the
+    // first half of iteration t (fragment-major MFMA order: fragment di is dead after its 4 MFMAs) while tile t+1 lands in it --
+    // k-step-0 fragments from slot 0, the k-step-1 fragment di from slot 4 (di + 1).  Every load completes inside the iteration that
+    // issues it (s_waitcnt vmcnt(NEO) at its end: only the saved-exponential pieces issued behind the last load stay in flight), so no
+    // asm-loaded register is ever live across a branch; the loop is unrolled by two for the static register naming.
     // MODE 0: the local symmetric block; 1 (RECT): this rank's rows x other ranks' columns, rectangular stash; 2 (TR): the TRANSPOSE of one
     // rectangular block -- output rows = the partner rank's rows, contraction over THIS rank's rows, every tile read mirrored from
     // the stash of block (this rank x partner): what the partner would otherwise recompute (crossclr_backward_rect_saved_t).  The host
@@ -153,6 +192,17 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
         const int row = L / RB, slot = (L - row * RB) >> 4;
         voffx[k] = (unsigned)(row * RBG + part * RB + (swz_slot(slot, row) << 4));
     }
+    // XF: fragment (dt = 4 DI part + DI wave + di, k-step ks) of tile u at u * QT * RBG + (2 dt + ks) * 1024 + 16 lane
+    const RawRsrc rs_xf = make_raw_rsrc(cols, (unsigned)((size_t)2 * g.bpad * RBG));
+    const unsigned xfv0 = (unsigned)((4 * DI * part + DI * wave) * 2048 + lane * 16), xfv1 = xfv0 + 4096u;
+    u32x4 BS[2][DI][2];          // [tile parity][fragment][k-step]
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int di = 0; di < DI; ++di) { BS[a][di][0] = z; BS[a][di][1] = z; }
+    }
     const unsigned stat_bytes = (unsigned)((size_t)col_segs * 2 * g.bpad * 4);
     const BufRsrc rs_rz = make_rsrc(rz_cols, stat_bytes), rs_wrz = make_rsrc(wrz_cols, stat_bytes);
     const BufRsrc rs_k = make_rsrc(SW ? kc : rz_cols, stat_bytes);
@@ -205,6 +255,20 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     auto issue_x_piece = [&](const Col& c, int stage, int k) {
         if (CROSSCLR_DABL & 2) return;
         lds_dma16_buf(rs_x, voffx[k], (unsigned)((CROSSCLR_DABL & 512) ? (c.mt & 7) : c.mt) * (unsigned)(QT * RBG), lds + stage * TILE + (wave + 4 * k) * 1024);
+    };
+    // XF: fragment (di, ks) of column tile c into register set `setc`
+    auto load_xf = [&](auto setc, auto dic, auto ksc, const Col& c) {
+        constexpr int S = decltype(setc)::value, di = decltype(dic)::value, ks = decltype(ksc)::value;
+        if (CROSSCLR_DABL & 2) return;
+        constexpr int off = (2 * di + ks) * 1024;
+        unsigned so = (unsigned)((CROSSCLR_DABL & 512) ? (c.mt & 7) : c.mt) * (unsigned)(QT * RBG);
+        pin_s(so);
+        BS[S][di][ks] = buf_load_b128_async<(off & 4095)>(rs_xf, off >= 4096 ? xfv1 : xfv0, so);
+    };
+    auto xf_landed = [&](auto setc) {      // (the caller has waited)
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int di = 0; di < DI; ++di) { after_wait(BS[S][di][0]); after_wait(BS[S][di][1]); }
     };
     // Stash tile of this wave for column tile u: (r32, u) where the forward evaluated it for these rows (u >= rb0: index Cd + u),
     // (u, r32) left of that (mirrored).  stash_tile_index in 32-bit scalar arithmetic (the host refuses plans with 2^31 tiles or
@@ -337,7 +401,11 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
 
     if (t < t_end) {
         const int tm = RECT ? t : (TR ? t_end : (t_end < rb0 ? t_end : rb0));        // tiles [t, tm) are mirrored, [tm, t_end) direct
-        Col cw, cx, ce;    // the next tile to weigh (t+1), to fetch (t+2), to fetch saved exponentials for (t+1+PE)
+        Col cw, cx, ce;    // the next tile to weigh (t+1), to fetch (t+2; XF: t+1), to fetch saved exponentials for (t+1+PE)
+        if constexpr (XF) {     // X(t) first: the wait for E(t) below then covers it, and E(t+1) / E(t+2) stay in flight behind both
+            cx = col_at(t);
+            static_for<NXO>([&](auto jc) { constexpr int j = decltype(jc)::value; load_xf(IdxC<0>{}, IdxC<j / 2>{}, IdxC<j % 2>{}, cx); });
+        }
         ce = col_at(t);
 #pragma unroll
         for (int k = 0; k < NSE; ++k) {
@@ -347,15 +415,18 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             col_next(ce);
         }
         const unsigned char* etile = eaddr_of(ce.u);      // stash tile of the E DMA the first iteration issues
-        cx = col_at(t);
+        if constexpr (!XF) {
+            cx = col_at(t);
 #pragma unroll
-        for (int k = 0; k < NSX - 1; ++k) {
+            for (int k = 0; k < NSX - 1; ++k) {
 #pragma unroll
-            for (int j = 0; j < NXO; ++j) issue_x_piece(cx, k, j);
-            col_next(cx);
+                for (int j = 0; j < NXO; ++j) issue_x_piece(cx, k, j);
+                col_next(cx);
+            }
         }
         cw = col_at(t);
-        if (!(CROSSCLR_DABL & 3)) wait_dma_keep<(NSE - 1) * NEO + (NSX - 1) * NXO>();   // E / statistics of the first tile
+        if (!(CROSSCLR_DABL & 3)) wait_dma_keep<(NSE - 1) * NEO + (XF ? 0 : (NSX - 1) * NXO)>();   // E / statistics of the first tile (XF: and X(t))
+        if constexpr (XF) xf_landed(IdxC<0>{});
         {
             Bits8 pk[2];
             Staged st;
@@ -376,7 +447,8 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             }
         }
         col_next(cw);
-        if (!(CROSSCLR_DABL & 3)) wait_dma_keep<(NSX - 2) * NXO>();     // X(t) (and every E piece: they were issued first)
+        if constexpr (XF) { if (!(CROSSCLR_DABL & 3)) wait_dma_keep<(NSE - 2) * NEO>(); }     // E(t+1): the first iteration stages it at once
+        else if (!(CROSSCLR_DABL & 3)) wait_dma_keep<(NSX - 2) * NXO>();     // X(t) (and every E piece: they were issued first)
         barrier_keep_dma();
         timing_mark(1);
         int sx = 0, se = 1 % NSE, wslot = 0;
@@ -384,7 +456,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
         int sx_free = 0, se_free = 0, ue_next = 0;
         decltype(lds_addr(lds)) xa = 0, wa_dir = 0, wa_mir = 0;
         auto setup_a = [&]() {     // cursors and ring stages of iteration t
-            if constexpr (!RECT) { cw = col_of(t + 1); cx = col_of(t + 2); ce = col_of(t + 1 + PE); }
+            if constexpr (!RECT) { cw = col_of(t + 1); cx = col_of(XF ? t + 1 : t + 2); ce = col_of(t + 1 + PE); }
             sx_free = sx == 0 ? NSX - 1 : sx - 1;        // stage of tile t-1 = stage of tile t+2
             se_free = se == 0 ? NSE - 1 : se - 1;        // stage of tile t (weighed an iteration ago) = stage of tile t+1+PE
             ue_next = RECT ? 0 : clampt(t + 2 + PE);     // (RECT: the cursor itself is advanced, see below)
@@ -405,8 +477,9 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
         //               pieces of X(t+2); its last slot waits for the reads (issued many MFMAs earlier: a formality)
         //   second half (k-step 0 of tile t): reads of k-step 1 of tile t (carried across the barrier), the 56 VALU of W(t+1), the
         //               next E address, the W write; the last slot moves the cursors and rotates the rings
-        auto body = [&](auto mc_, auto mn_) {
+        auto body = [&](auto mc_, auto mn_, auto par_) {
             constexpr bool MC = decltype(mc_)::value, MN = decltype(mn_)::value;
+            constexpr int PAR = decltype(par_)::value;       // XF: register set of tile t (the other one: tile t-1, then tile t+1)
             // (sx_free, se_free, xa, wa_dir / wa_mir, ue_next and the cursors of THIS iteration were set in the last two slots of the
             // previous one -- setup_a / setup_b below -- so that no address arithmetic sits between the barrier and the first MFMA)
             const auto wa = MC ? wa_mir : wa_dir;
@@ -456,7 +529,17 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
                 constexpr int s = decltype(sc)::value;
                 static_for<NV>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    if constexpr ((WV >= 0 ? ((NV * WVS + j) * ADV) / (4 * NV) : (j * ADV) / NV) == s) {
+                    if constexpr (XF) {
+                        // fragment loads of tile t+1 into the set of tile t-1: k-step 0 (dead since the last iteration) from slot 0, k-step 1 of
+                        // fragment di right behind its last MFMA (slot 4 di + 3); the saved-exponential pieces behind ALL of them, up to slot ADV
+                        if constexpr (j < NXO) {
+                            constexpr int di = j >> 1, ks = j & 1;
+                            if constexpr ((ks == 0 ? di : 4 * (di + 1)) == s) load_xf(IdxC<PAR ^ 1>{}, IdxC<di>{}, IdxC<ks>{}, cx);
+                        } else {
+                            constexpr int je = j - NXO;
+                            if constexpr (H + 1 + (je * (ADV - H - 1)) / (NEO - 1) == s) issue_e_piece(ce, etile, se_free, je);
+                        }
+                    } else if constexpr ((WV >= 0 ? ((NV * WVS + j) * ADV) / (4 * NV) : (j * ADV) / NV) == s) {
                         if constexpr (j < NXO) issue_x_piece(cx, sx_free, j);
                         else issue_e_piece(ce, etile, se_free, j - NXO);
                     }
@@ -464,7 +547,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             };
             // ---- first half: LDS items, one per slot from slot 0 (the last one well ahead of the wait in slot H-1) ----
             constexpr int NS1 = 2 + (SW ? 1 : 0);                    // staged reads, in two or three instalments
-            constexpr int N1 = NS1 + 4 + DI;
+            constexpr int N1 = NS1 + 4 + (XF ? 0 : DI);
             constexpr int L1 = (2 * H) / 3 > 0 ? (2 * H) / 3 : 1;    // slots that carry them
             auto item1 = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -478,7 +561,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             };
             // ---- second half: reads of k-step 1 from its first slot on, the half-quads of W(t+1) one slot behind, then the write and the
             // next E address; the last slots carry nothing that the closing lgkmcnt(0) would have to wait for ----
-            constexpr int NR = 4 + DI;
+            constexpr int NR = 4 + (XF ? 0 : DI);
             auto items2 = [&](auto sc) {
                 constexpr int s2 = decltype(sc)::value;
                 static_for<NR>([&](auto ic) {
@@ -498,8 +581,9 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             static_for<2 * H>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (s < H) {
-                    constexpr int pi = s / DI, di = s % DI;
-                    mfma_acc(acc[pi][di], A1c[pi], B1c[di]);
+                    constexpr int pi = XF ? s % 4 : s / DI, di = XF ? s / 4 : s % DI;     // XF: fragment-major (see vmem_items)
+                    if constexpr (XF) mfma_acc(acc[pi][di], A1c[pi], __builtin_bit_cast(bf16x8, BS[PAR ^ 1][di][1]));
+                    else mfma_acc(acc[pi][di], A1c[pi], B1c[di]);
                     sched_fence();
                     items1(sc);
                     vmem_items(sc);
@@ -508,13 +592,15 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
                         staged_landed(IdxC<MN>{}, st);
 #pragma unroll
                         for (int p = 0; p < 4; ++p) { if (MC) { after_wait(Am0[p].lo); after_wait(Am0[p].hi); } else after_wait(Ad0[p]); }
+                        if constexpr (!XF) {
 #pragma unroll
-                        for (int d = 0; d < DI; ++d) { after_wait(B0[d].lo); after_wait(B0[d].hi); }
+                            for (int d = 0; d < DI; ++d) { after_wait(B0[d].lo); after_wait(B0[d].hi); }
+                        }
                     }
                 } else {
                     constexpr int s2 = s - H, pi = s2 / DI, di = s2 % DI;
                     mfma_acc(acc[pi][di], MC ? __builtin_bit_cast(bf16x8, Am0[pi]) : __builtin_bit_cast(bf16x8, Ad0[pi]),
-                             __builtin_bit_cast(bf16x8, B0[di]));
+                             XF ? __builtin_bit_cast(bf16x8, BS[PAR][di][0]) : __builtin_bit_cast(bf16x8, B0[di]));
                     sched_fence();
                     items2(IdxC<s2>{});
                     vmem_items(sc);
@@ -537,8 +623,10 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
                 if (MC) { after_wait(Am1[p].lo); after_wait(Am1[p].hi); A1c[p] = __builtin_bit_cast(bf16x8, Am1[p]); }
                 else { after_wait(Ad1[p]); A1c[p] = __builtin_bit_cast(bf16x8, Ad1[p]); }
             }
+            if constexpr (!XF) {
 #pragma unroll
-            for (int d = 0; d < DI; ++d) { after_wait(B1[d].lo); after_wait(B1[d].hi); B1c[d] = __builtin_bit_cast(bf16x8, B1[d]); }
+                for (int d = 0; d < DI; ++d) { after_wait(B1[d].lo); after_wait(B1[d].hi); B1c[d] = __builtin_bit_cast(bf16x8, B1[d]); }
+            }
             // ... X(t+1) has landed (what this iteration issued may still be in flight), for every wave
             if constexpr (RECT) {   // the segment walk of a rectangular launch branches: only here, where no asm load is in flight
                 col_next(cw); col_next(cx); col_next(ce);
@@ -551,26 +639,58 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
             }
             // (operations issued after X(t+1)'s last piece: the E pieces of the previous iteration and everything of this one; the
             // first iteration's X(t+1) is the last operation of the prologue -- only this iteration's operations follow it)
-            if (!(CROSSCLR_DABL & (3 | 4096))) {
+            if constexpr (XF) {      // tile t+1's fragments have landed: only this iteration's NEO pieces were issued behind the last of them
+                if (!(CROSSCLR_DABL & (3 | 4096))) wait_dma_keep<NEO>();
+                xf_landed(IdxC<PAR ^ 1>{});
+            } else if (!(CROSSCLR_DABL & (3 | 4096))) {
                 if (first_iter) wait_dma_keep<NXO + NEO>(); else wait_dma_keep<NXO + 2 * NEO>();
             }
             first_iter = false;
             if (!(CROSSCLR_DABL & 32)) barrier_keep_dma();
         };
+        if constexpr (XF) {
+            // The loop unrolled by two: iteration parity = register set of its tile.  Every phase (M->M, M->D, D->D) starts on set 0; a phase
+            // that ends after an odd number of iterations swaps the two sets (twice per block at most) -- a dispatch on a run-time parity
+            // instead (six bodies reachable from each other) made hipcc split the accumulators' live ranges and spill.
+            auto swap_sets = [&]() {
+#pragma unroll
+                for (int di = 0; di < DI; ++di)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) { const u32x4 x = BS[0][di][ks]; BS[0][di][ks] = BS[1][di][ks]; BS[1][di][ks] = x; }
+            };
+            // (an odd iteration is peeled off IN FRONT of each loop: a second exit in the middle of the unrolled loop made hipcc split the
+            // accumulators' live ranges as well)
+            const int n_mm = tm - 1 - t > 0 ? tm - 1 - t : 0;
+            if (n_mm & 1) { body(IdxC<true>{}, IdxC<true>{}, IdxC<0>{}); swap_sets(); }
+            for (int k = n_mm >> 1; k > 0; --k) {
+                body(IdxC<true>{}, IdxC<true>{}, IdxC<0>{});
+                body(IdxC<true>{}, IdxC<true>{}, IdxC<1>{});
+            }
+            if (t < tm) { body(IdxC<true>{}, IdxC<false>{}, IdxC<0>{}); swap_sets(); }
+            const int n_dd = t_end - t;
+            if (n_dd & 1) { body(IdxC<false>{}, IdxC<false>{}, IdxC<0>{}); swap_sets(); }
+            for (int k = n_dd >> 1; k > 0; --k) {
+                body(IdxC<false>{}, IdxC<false>{}, IdxC<0>{});
+                body(IdxC<false>{}, IdxC<false>{}, IdxC<1>{});
+            }
+            // k-step 1 of the last tile: after the swaps the next tile would use set 0, the last one sits in set 1
+            static_for<H>([&](auto sc) { constexpr int s = decltype(sc)::value; mfma_acc(acc[s % 4][s / 4], A1c[s % 4], __builtin_bit_cast(bf16x8, BS[1][s / 4][1])); });
+        } else {
         if constexpr (TR) {            // every tile mirrored (the last iteration weighs a re-fetch of the last tile: never consumed)
-            while (t < t_end) body(IdxC<true>{}, IdxC<true>{});
+            while (t < t_end) body(IdxC<true>{}, IdxC<true>{}, IdxC<0>{});
         } else {
             if constexpr (!RECT) {     // (a rectangular block's tiles are all direct)
-                while (t + 1 < tm) body(IdxC<true>{}, IdxC<true>{});
-                if (t < tm) body(IdxC<true>{}, IdxC<false>{});
+                while (t + 1 < tm) body(IdxC<true>{}, IdxC<true>{}, IdxC<0>{});
+                if (t < tm) body(IdxC<true>{}, IdxC<false>{}, IdxC<0>{});
             }
-            while (t < t_end) body(IdxC<false>{}, IdxC<false>{});
+            while (t < t_end) body(IdxC<false>{}, IdxC<false>{}, IdxC<0>{});
         }
         // k-step 1 of the last tile
         static_for<H>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             mfma_acc(acc[s / DI][s % DI], A1c[s / DI], B1c[s % DI]);
         });
+        }
         wait_dma();   // the re-fetches past the end must not outlive the block's LDS
     }
     timing_mark(2);
@@ -601,7 +721,7 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
     timing_mark(3);
 }
 
-template <int DK, bool SW, int MODE, int XP = 1, int TPRF = 8>
+template <int DK, bool SW, int MODE, int XP = 1, int TPRF = 8, bool XF = false>
 __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols, const unsigned char* stash, Geo g,
                                                               const float* rz, const float* wrz,
                                                               const float* rz_cols, const float* wrz_cols, float* gbuf,
@@ -614,8 +734,8 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols
     constexpr int RBG = XP * RB;           // bytes per operand row in memory
     constexpr int DI = DK / 8;             // 32-wide output fragments per wave (its column slice)
     constexpr int H = 4 * DI;              // MFMAs per k-step: 4 row groups x DI fragments
-    constexpr int NSX = 3;                 // column-tile ring
-    constexpr int PE = CROSSCLR_DSL_PE;
+    constexpr int NSX = XF ? 0 : 3;        // column-tile ring
+    constexpr int PE = XF ? 2 : CROSSCLR_DSL_PE;
     constexpr int NSE = PE + 1;            // saved-exponential + statistics rings (private to a wave)
     constexpr int ESTG = 4 * 2048;         // one stage of the E ring: [4 waves][2 KiB]
     constexpr int SSTG = 4 * 256;          // one stage of a statistics ring: [4 waves][64 floats] (the tile's 32 + 32 spare)
@@ -625,7 +745,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols
     constexpr int W0 = NSX * TILE, E0 = W0 + 2 * WBUF, S0 = E0 + NSE * ESTG, K0 = S0 + NSE * SSTG;
     constexpr int O0 = K0 + (SW ? NSE * SSTG : 0);      // the block's own statistics: rz[128] | wrz[128] | k[128]
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad (per part) in {128, 256, 384, 512}");
-    static_assert(PE >= 3, "E / statistics of tile t+2 must be older than the pieces of X(t+1)");
+    static_assert(XF || PE >= 3, "E / statistics of tile t+2 must be older than the pieces of X(t+1)");
     static_assert(O0 + 3 * 512 <= 160 * 1024, "LDS budget");
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[O0 + 3 * 512];
     const int tid = threadIdx.x;
@@ -640,6 +760,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_dsl_kernel(const bf16_t* cols
     }
     __syncthreads();        // (before any LDS-DMA is in flight: this barrier may drain VMEM)
 #if !CROSSCLR_DSL_STAGGER
+    if constexpr (XF) { dsl_wave<DK, SW, MODE, XP, TPRF, -1, true>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc); return; }
     dsl_wave<DK, SW, MODE, XP, TPRF, -1>(lds, cols, stash, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tiles_per_slice, ks, kc);
 #else
     switch (uniform(tid >> 6)) {

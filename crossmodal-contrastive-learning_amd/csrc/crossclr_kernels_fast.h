@@ -863,6 +863,8 @@ static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const 
 static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* cols, const void* stash, const float* rz,
                                       const float* wrz, const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
                                       const float* ks, const float* kc, int mode, void* stream) {
+    const bool xf = mode == 3;      // mode 3 = mode 0 with `cols` in the fragment-major layout (crossclr_normalize_xf; Dpad <= 512)
+    if (xf) mode = 0;
     const bool rect = mode == 1;
     const bool skipping = rect && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
     const int ntiles = (rect ? g.col_ranks - (skipping ? 1 : 0) : 1) * (2 * p->bpad / 32);
@@ -873,9 +875,23 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     const unsigned char* st = (const unsigned char*)stash;
 #ifdef CROSSCLR_DSL_MINIMAL   // tuning builds (tools/build_variant.py): only the headline instantiation is compiled (seconds instead of minutes)
     if (p->Dpad != 512 || ks || mode != 0) return CROSSCLR_E_ARG;
-    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    if (xf) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
     return CROSSCLR_OK;
 #else
+    if (xf) {
+#define CROSSCLR_LBX(DK) do { if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
+                              else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
+        switch (p->Dpad) {
+            case 128: CROSSCLR_LBX(8); break;
+            case 256: CROSSCLR_LBX(16); break;
+            case 384: CROSSCLR_LBX(24); break;
+            case 512: CROSSCLR_LBX(32); break;
+            default: return CROSSCLR_E_ARG;
+        }
+#undef CROSSCLR_LBX
+        return CROSSCLR_OK;
+    }
 #define CROSSCLR_LB3(DK, SW, XP, TPRF, GRID)                                                                                                   \
     do {                                                                                                                                        \
         if (mode == 0) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 0, XP, TPRF>), GRID, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);      \

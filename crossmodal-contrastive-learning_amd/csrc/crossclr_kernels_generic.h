@@ -163,6 +163,74 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
     }
 }
 
+// K0x: the same normalisation (term by term) that ALSO leaves the bf16 unit rows in the fragment-major layout the XF backward loads
+// straight into MFMA B fragments (crossclr_kernels_dsl.h):
+//   XF[u = stacked row / 32][dt = column / 32][ks][lane = 32 h + n][e = 0..7] = xhat[32 u + 16 ks + 8 (e >> 2) + 4 h + (e & 3)][32 dt + n]
+// (1 KiB per (u, dt, ks); the row order inside a lane is the k <-> q permutation of the saved exponentials' A fragments).
+// A block = 16 row pairs (one k-step of a tile, two per wave, 8 waves): the 32 unit rows pass through LDS once and leave as 16-byte
+// chunks -- 8 rows x 1 column -- in runs of 512 bytes.  Dpad <= 512 (bf16 fast path); +16 MiB written at B = 8192, D = 512.
+template <typename TIN, bool NORM>
+__global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, const TIN* text, long ldv, long ldt, Geo g, bf16_t* X,
+                                                           unsigned char* XF, float* inv_norm, float* diag_cos) {
+    CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[2][16][512];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * 16;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {     // (unrolled: the second pair's loads are in flight while the first pair is reduced)
+        const int r = 2 * wave + rr, i = i0 + r;     // (bpad is a multiple of 128: every i < bpad)
+        bf16_t* xv = X + (size_t)i * g.Dpad;
+        bf16_t* xt = X + ((size_t)g.bpad + i) * g.Dpad;
+        double cv[2][4], ct[2][4];
+        double ssv = 0, sst = 0, dot = 0;
+        const bool valid = i < g.b;
+        const TIN* pv = video + (size_t)(valid ? i : 0) * ldv;
+        const TIN* pt = text + (size_t)(valid ? i : 0) * ldt;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 4 * lane + 256 * k;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cv[k][j] = 0.0; ct[k][j] = 0.0; }
+            if (valid && d < g.D) {
+                row_load4(pv, d, g.D, cv[k]);
+                row_load4(pt, d, g.D, ct[k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ssv += cv[k][j] * cv[k][j]; sst += ct[k][j] * ct[k][j]; dot += cv[k][j] * ct[k][j]; }
+            }
+        }
+        ssv = wave_sum_f64(ssv); sst = wave_sum_f64(sst); dot = wave_sum_f64(dot);
+        double nv = sqrt(ssv), nt = sqrt(sst);
+        double iv = 1.0 / (nv > 1e-12 ? nv : 1e-12), it = 1.0 / (nt > 1e-12 ? nt : 1e-12);
+        if (!NORM) iv = it = 1.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.Dpad) {
+                float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+                if (valid && d < g.D) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[j] = (float)(cv[k][j] * iv); c[j] = (float)(ct[k][j] * it); }
+                }
+                op_store4(xv, d, a); op_store4(xt, d, c);
+                op_store4(&sh[0][r][0], d, a); op_store4(&sh[1][r][0], d, c);
+            }
+        }
+        if (lane == 0) {
+            inv_norm[i] = valid ? (float)iv : 0.f; inv_norm[g.bpad + i] = valid ? (float)it : 0.f;
+            diag_cos[i] = valid ? (float)(dot * iv * it) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nfr = g.Dpad / 32, ks = (i0 >> 4) & 1;
+    for (int c = threadIdx.x; c < 4 * g.Dpad; c += 512) {
+        const int m = c / (2 * g.Dpad), rest = c - m * 2 * g.Dpad, h = rest / g.Dpad, d = rest - h * g.Dpad;
+        struct { bf16_t e[8]; } v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = sh[m][8 * (e >> 2) + 4 * h + (e & 3)][d];
+        const size_t u = ((size_t)m * g.bpad + i0) >> 5;
+        *reinterpret_cast<u32x4*>(XF + ((u * nfr + (d >> 5)) * 2 + ks) * 1024 + (32 * h + (d & 31)) * 16) = __builtin_bit_cast(u32x4, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: forward denominators, generic tiled version.
 //   block = 256 threads (4 waves as 2x2), tile = 128 rows x 128 columns, K-chunks of 128 bytes.
@@ -913,10 +981,12 @@ __global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf,
     for (int k = 0; k < kRowCache; ++k) {
         const int d = 4 * lane + 256 * k;
         if (d < g.D) {
-            f32x4 sv = *reinterpret_cast<const f32x4*>(grv + d), st = *reinterpret_cast<const f32x4*>(grt + d);
+            // (the slices are read exactly once: streaming loads)
+            f32x4 sv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + d));
+            f32x4 st = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + d));
             for (int sl = 1; sl < nslices; ++sl) {
-                sv += *reinterpret_cast<const f32x4*>(grv + sl * slice + d);
-                st += *reinterpret_cast<const f32x4*>(grt + sl * slice + d);
+                sv += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + sl * slice + d));
+                st += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + sl * slice + d));
             }
             double a[4], c[4];
             row_load4(pv, d, g.D, a);

@@ -90,7 +90,7 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers")
+                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf")
 
 
 _plan_cache: dict = {}
@@ -99,6 +99,8 @@ _checked_shapes: set = set()
 
 def _plan_for(b: int, D: int, world: int, rank: int, mode: int):
     """crossclr_make_plan is pure in its arguments (and in tuning variables the library reads once): cache it."""
+    if nat.injected_for_testing():
+        return nat.make_plan(b, D, world, rank, mode)     # the CPU tests flip tuning variables between calls: their build re-reads them
     key = (b, D, world, rank, mode, nat.library_path())
     plan = _plan_cache.get(key)
     if plan is None:
@@ -310,6 +312,22 @@ def _pack_pair(pair, b: int, bpad: int, dev, what: str) -> Optional[torch.Tensor
 _MAX_STASH_BYTES = int(float(os.environ.get("CROSSCLR_MAX_STASH_GB", "8")) * (1 << 30))
 
 
+# Embedding widths (padded) at which the step takes the fragment-major saved backward (crossclr_backward_saved_xf) instead of the
+# LDS-staged one.  The library offers it for every Dpad <= 512 (plan.xf_bytes); measured on the MI355X (profiles/r03_xf_widths.txt) it
+# wins at 512 only (B = 2048 / 8192 / 16384: -6 / -3 / -1 %), ties at 384 and loses at 256 / 128 (+14 / +21 % at B = 8192: with short
+# tiles the saved exponentials' HBM latency is no longer covered -- the fragment loads must complete inside their iteration, which
+# caps the exponentials' prefetch distance at one tile), so the default is {512}.
+# CROSSCLR_XF_WIDTHS="128,256,384,512" (or "" for none) overrides (tuning / tests).
+_XF_WIDTHS_DEFAULT = frozenset((512,))
+
+
+def _xf_widths():
+    e = os.environ.get("CROSSCLR_XF_WIDTHS")
+    if e is None:
+        return _XF_WIDTHS_DEFAULT
+    return frozenset(int(x) for x in e.split(",") if x.strip())
+
+
 def _alloc_stash(nbytes: int, dev) -> Optional[torch.Tensor]:
     if nbytes <= 0 or nbytes > _MAX_STASH_BYTES:
         return None
@@ -384,6 +402,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.k_cols = ws.k_rows
 
     ws.prenormalized = bool(prenormalized) or project is not None
+    ws.xf = None
     if project is not None:
         if plan.fast_path != 1 or plan.Dpad > 512 or mode != nat.MODE_BF16:
             raise RuntimeError("the fused projection needs the bf16 register-resident path (embed_dim <= 512)")
@@ -393,10 +412,19 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                                                 ws.in_dtype, _ptr(wv), _ptr(wt), ldws[0], ldws[1], _ptr(bias_v), _ptr(bias_t), _ptr(ws.xhat),
                                                 _ptr(ws.inv_norm), _ptr(ws.diag), stream))
     else:
-        entry = lib.crossclr_pack if prenormalized else lib.crossclr_normalize    # unit rows are only laid out, not re-normalised
+        # With a saved backward to follow (plan.xf_bytes > 0: bf16 register-resident path, D <= 512) the same launch also leaves the
+        # unit rows in the fragment-major layout that backward loads straight into MFMA fragments (crossclr_backward_saved_xf).
+        use_xf = save_for_backward and plan.xf_bytes > 0 and plan.stash_bytes > 0 and not small_tau and plan.Dpad in _xf_widths()
+        ws.xf = torch.empty(plan.xf_bytes, dtype=torch.uint8, device=dev) if use_xf else None
         with _Range("crossclr.normalize"):
-            nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
-                            _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+            if ws.xf is not None:
+                entry = lib.crossclr_pack_xf if prenormalized else lib.crossclr_normalize_xf
+                nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                _ptr(ws.xhat), _ptr(ws.xf), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+            else:
+                entry = lib.crossclr_pack if prenormalized else lib.crossclr_normalize    # unit rows are only laid out, not re-normalised
+                nat.check(entry(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                _ptr(ws.xhat), _ptr(ws.inv_norm), _ptr(ws.diag), stream))
     gather = None
     if sharded:
         # all-gather of the packed operands runs on the collective's own stream (RCCL over xGMI)
@@ -442,6 +470,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
     # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
     ws.stash = _alloc_stash(plan.stash_bytes, dev) if save_for_backward else None
+    if ws.stash is None:
+        ws.xf = None      # (no saved backward after all: the recomputing one reads the row-major operand)
     if partner_possible and ws.stash is None:
         raise RuntimeError("CrossCLR (sharded): could not allocate the saved-exponentials buffer on this rank; the ranks agreed on the "
                            "partner-gradient scheme, which needs it -- set CROSSCLR_PARTNER_GRADS=0 (or CROSSCLR_DISABLE_SAVE=1) on every rank")
@@ -644,10 +674,16 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
                                               _sw(ws.k_rows, ws.k_cols, None), _ptr(ws.shift), _ptr(ws.shift_cols), _ptr(gbuf), 1, stream))
     elif ws.stash is not None:
         with _Range("crossclr.backward"):
-            nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
-                                                  _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
-                                                  stream))
+            if ws.xf is not None:
+                nat.check(lib.crossclr_backward_saved_xf(pp, _ptr(ws.xf), _ptr(ws.stash), ws.temperature, ws.negative_w,
+                                                         _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
+                                                         stream))
+            else:
+                nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
+                                                      _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
+                                                      stream))
         ws.stash = None   # consumed: give the 0.27 GB back to the allocator as soon as the launch is queued
+        ws.xf = None
     else:
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                           _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define CROSSCLR_LAUNCH_GROUPS 8   /* launch groups the forward workspace has room for */
-#define CROSSCLR_ABI_VERSION 3
+#define CROSSCLR_ABI_VERSION 4
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
 #define CROSSCLR_IN_F32 0
@@ -75,6 +75,8 @@ typedef struct crossclr_plan {
     size_t gbuf_bytes;      /* fp32 d(loss)/d(xhat) accumulator [bwd_slices][2][bpad][Dpad] */
     size_t stash_bytes;     /* ABI 3: bytes of the saved-exponentials buffer of crossclr_forward_save (0: not available
                                for this plan -- use crossclr_forward / crossclr_backward, which recompute) */
+    size_t xf_bytes;        /* ABI 4: bytes of the fragment-major copy of the packed operand that crossclr_normalize_xf / crossclr_pack_xf
+                               write and crossclr_backward_saved_xf reads (0: not available -- Dpad > 512, fp32 plans) */
 } crossclr_plan;
 
 int crossclr_abi_version(void);
@@ -206,6 +208,21 @@ int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float tem
 int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash,
                             float temperature, float negative_weight, const float* rz, const float* wrz,
                             const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+/* ABI 4 -- the fragment-major operand (plan->xf_bytes > 0: bf16 register-resident path, Dpad <= 512, local block).
+ * crossclr_normalize_xf / crossclr_pack_xf are crossclr_normalize (loss.py:79-80) / crossclr_pack that ALSO write the bf16 unit rows
+ * a second time, to `xhat_xf` (plan->xf_bytes bytes, caller-owned), laid out as the MFMA B fragments of the gradient product
+ *   xhat_xf[stacked row / 32][column / 32][k-step][lane][8]   (1 KiB per fragment; crossclr_kernels_generic.h: normalize_xf_kernel)
+ * and crossclr_backward_saved_xf is crossclr_backward_saved (autograd of loss.py:83-112 from the saved exponentials) that loads those
+ * fragments straight into registers instead of staging the row-major column tile through LDS: same arguments, same result bits
+ * are NOT guaranteed between the two (different summation grouping inside a tile is not used -- the MFMA order is the same -- but
+ * callers should not mix them within one reproducibility domain).  The row-major `xhat` is still what every forward reads.           */
+int crossclr_normalize_xf(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text,
+                          int in_dtype, void* xhat, void* xhat_xf, float* inv_norm, float* diag_cos, void* stream);
+int crossclr_pack_xf(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video, long ld_text,
+                     int in_dtype, void* xhat, void* xhat_xf, float* inv_norm, float* diag_cos, void* stream);
+int crossclr_backward_saved_xf(const crossclr_plan* plan, const void* xhat_xf, const void* stash,
+                               float temperature, float negative_weight, const float* rz, const float* wrz,
+                               const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
 /* Two-pass regime, save-for-backward pair (exact-fp32 plans, local block; ABI 3): the second pass also leaves
  * U[p][q] = exp2(x_pq - shift_p) and Ut[p][q] = U[q][p] behind (crossclr_stash_bytes_s = twice plan->stash_bytes, 0 = not
  * available), and the backward forms the weights U rz_p + Ut rz_q from them instead of recomputing the similarity product

@@ -26,6 +26,9 @@ template __global__ void fast_bwd_dsl_kernel<8, false, 2> BSIG;      // transpos
 template __global__ void fast_bwd_dsl_kernel<16, true, 0> BSIG;
 template __global__ void fast_bwd_dsl_kernel<32, false, 0> BSIG;     // the headline instantiation
 template __global__ void fast_bwd_dsl_kernel<32, false, 0, 2, 4> BSIG;   // two column parts (D = 1024)
+template __global__ void fast_bwd_dsl_kernel<32, false, 0, 1, 8, true> BSIG;   // XF: B fragments by asm buffer loads into VGPRs (the headline backward)
+template __global__ void fast_bwd_dsl_kernel<8, true, 0, 1, 8, true> BSIG;     // XF, one fragment per wave, sample weights
+template __global__ void fast_bwd_dsl_kernel<24, false, 0, 1, 8, true> BSIG;
 template __global__ void fast_fwd_pipe_kernel<8, 1, false, true> FSIG;
 template __global__ void fast_fwd_pipe_kernel<8, 3, true, true> FSIG;
 template __global__ void fast_fwd_pipe_kernel<32, 1, false, true> FSIG;  // the headline forward
@@ -42,10 +45,11 @@ def test_no_asm_loaded_register_is_read_before_its_wait(tmp_path):
                            "-DCROSSCLR_KERNELS_ONLY", "-I", CSRC, str(src), "-o", str(asm)], stderr=subprocess.DEVNULL)
     text = asm.read_text()
     kernels = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", text, re.M)
-    assert len(kernels) == 10, kernels
+    assert len(kernels) == 13, kernels
     scratch = [int(x) for x in re.findall(r";\s*ScratchSize:\s*(\d+)", text)]
-    assert len(scratch) >= 10 and all(s == 0 for s in scratch), scratch
+    assert len(scratch) >= 13 and all(s == 0 for s in scratch), scratch
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py"), str(asm)], capture_output=True, text=True)
     assert r.returncode == 0 and "flagged: 0" in r.stdout, r.stdout[-2000:]
     # and the audit itself must be able to see the loads it is meant to guard
     assert text.count("ds_read_b64_tr_b16") > 100 and text.count("ds_read_b128") > 100
+    assert len(re.findall(r"buffer_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\], s\d+ offen", text)) > 100

@@ -329,6 +329,53 @@ def test_saved_backward_with_mirrored_tiles(B, D, weighted, monkeypatch):
         assert (gts.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, True), (150, 200, False), (140, 300, True), (130, 420, False)])
+def test_fragment_major_backward_is_bit_identical_to_the_lds_staged_one(B, D, weighted, monkeypatch):
+    """plan.xf_bytes > 0: crossclr_normalize_xf also writes the operand as MFMA B fragments and crossclr_backward_saved_xf
+    (fast_bwd_dsl_kernel<..., XF>) loads them straight into registers -- two register sets, loop unrolled by two, every load
+    complete inside its iteration.  Every accumulator receives the same MFMA sequence as in the LDS-staged kernel, so the gradients
+    must agree BIT FOR BIT (DK = 8 / 16 / 24 / 32, mirrored and direct tiles, with and without sample weights)."""
+    plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
+    assert plan.fast_path == 1 and plan.stash_bytes > 0 and plan.xf_bytes == plan.operand_bytes and plan.bpad >= 256
+    monkeypatch.setenv("CROSSCLR_XF_WIDTHS", "128,256,384,512")     # (the module's default policy takes this path at 128 and 512 only)
+    seen = []
+    lib = nat.library()
+    real = lib.crossclr_backward_saved_xf
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xf", lambda *a: (seen.append(1), real(*a))[1])
+    v, t = orc.make_inputs("randn", B, D, 31)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(6)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    lx, gvx, gtx = step()
+    monkeypatch.setenv("CROSSCLR_DISABLE_XF", "1")
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).xf_bytes == 0
+    assert len(seen) == 1
+    ll, gvl, gtl = step()
+    assert len(seen) == 1      # (this one went through crossclr_backward_saved)
+    assert lx == ll and torch.equal(gvx, gvl) and torch.equal(gtx, gtl)
+    monkeypatch.delenv("CROSSCLR_DISABLE_XF")
+    # the XF entry point refuses a plan without the layout, and the prenormalized path (crossclr_pack_xf) agrees too
+    vn, tn = torch.nn.functional.normalize(v, dim=1), torch.nn.functional.normalize(t, dim=1)
+
+    def pstep():
+        vv, tt = vn.clone().requires_grad_(True), tn.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", prenormalized=True, **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    a = pstep()
+    monkeypatch.setenv("CROSSCLR_DISABLE_XF", "1")
+    b_ = pstep()
+    assert a[0] == b_[0] and torch.equal(a[1], b_[1]) and torch.equal(a[2], b_[2])
+
+
 @pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, False), (150, 24, True), (70, 16, False)])
 def test_generic_forward_only_evaluates_the_upper_triangle(B, D, weighted, monkeypatch):
     """compute_mode="fp32" under no_grad (BASELINE config 2's shape of call): fwd_sums_kernel<..., SYM> evaluates the column
