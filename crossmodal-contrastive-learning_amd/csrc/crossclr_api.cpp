@@ -226,9 +226,9 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         const size_t sb = (size_t)2 * plan->bpad * (size_t)2 * plan->bpad * 4;
         if (sb <= ((size_t)16 << 30)) plan->stash_bytes = sb;
     }
-    // the fragment-major copy of the bf16 operand (crossclr_normalize_xf -> crossclr_backward_saved_xf): local block, Dpad <= 512
+    // the fragment-major copy of the bf16 operand (crossclr_normalize_xf -> crossclr_backward_saved_xf): local block, Dpad <= 1024
     plan->xf_bytes = 0;
-    if (plan->fast_path && plan->fast_bwd && plan->stash_bytes && plan->Dpad <= 512 && !env.disable_xf) plan->xf_bytes = plan->operand_bytes;
+    if (plan->fast_path && plan->fast_bwd && plan->stash_bytes && plan->Dpad <= 1024 && !env.disable_xf) plan->xf_bytes = plan->operand_bytes;
 #else
     plan->xf_bytes = 0;
 #endif
@@ -304,8 +304,12 @@ static int normalize_xf_t(const crossclr_plan* p, const void* v, const void* t, 
                           float* inv_norm, float* diag, void* stream) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
-    LAUNCH((normalize_xf_kernel<TIN, NORM>), dim3(p->bpad / 16), dim3(512), stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
-           (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag);
+    if (p->Dpad <= 512)
+        LAUNCH((normalize_xf_kernel<TIN, NORM, 2>), dim3(p->bpad / 16), dim3(512), stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+               (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag);
+    else
+        LAUNCH((normalize_xf_kernel<TIN, NORM, 4>), dim3(p->bpad / 16), dim3(512), stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
+               (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag);
     return launch_status("normalize_xf_kernel");
 }
 #endif

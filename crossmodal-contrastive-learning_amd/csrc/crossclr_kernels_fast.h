@@ -880,6 +880,9 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     return CROSSCLR_OK;
 #else
     if (xf) {
+#define CROSSCLR_LBX2(DK) do { dim3 grid2(2 * p->bpad / 128, p->bwd_slices, 2);                                                                  \
+                               if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, 2, 4, true>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
+                               else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, 2, 4, true>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
 #define CROSSCLR_LBX(DK) do { if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
                               else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
         switch (p->Dpad) {
@@ -887,9 +890,12 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
             case 256: CROSSCLR_LBX(16); break;
             case 384: CROSSCLR_LBX(24); break;
             case 512: CROSSCLR_LBX(32); break;
+            case 768: CROSSCLR_LBX2(24); break;      // two column parts of Dpad / 2 (blockIdx.z), like the LDS-staged launch
+            case 1024: CROSSCLR_LBX2(32); break;
             default: return CROSSCLR_E_ARG;
         }
 #undef CROSSCLR_LBX
+#undef CROSSCLR_LBX2
         return CROSSCLR_OK;
     }
 #define CROSSCLR_LB3(DK, SW, XP, TPRF, GRID)                                                                                                   \

@@ -168,11 +168,12 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 //   XF[u = stacked row / 32][dt = column / 32][ks][lane = 32 h + n][e = 0..7] = xhat[32 u + 16 ks + 8 (e >> 2) + 4 h + (e & 3)][32 dt + n]
 // (1 KiB per (u, dt, ks); the row order inside a lane is the k <-> q permutation of the saved exponentials' A fragments).
 // A block = 16 row pairs (one k-step of a tile, two per wave, 8 waves): the 32 unit rows pass through LDS once and leave as 16-byte
-// chunks -- 8 rows x 1 column -- in runs of 512 bytes.  Dpad <= 512 (bf16 fast path); +16 MiB written at B = 8192, D = 512.
-template <typename TIN, bool NORM>
+// chunks -- 8 rows x 1 column -- in runs of 512 bytes.  Dpad <= 256 KC (KC = 2: Dpad <= 512, KC = 4: the wide operands up to 1024);
+// +16 MiB written at B = 8192, D = 512.
+template <typename TIN, bool NORM, int KC>
 __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, const TIN* text, long ldv, long ldt, Geo g, bf16_t* X,
                                                            unsigned char* XF, float* inv_norm, float* diag_cos) {
-    CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[2][16][512];
+    CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[2][16][256 * KC];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 16;
 #pragma unroll
@@ -180,13 +181,13 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
         const int r = 2 * wave + rr, i = i0 + r;     // (bpad is a multiple of 128: every i < bpad)
         bf16_t* xv = X + (size_t)i * g.Dpad;
         bf16_t* xt = X + ((size_t)g.bpad + i) * g.Dpad;
-        double cv[2][4], ct[2][4];
+        double cv[KC][4], ct[KC][4];
         double ssv = 0, sst = 0, dot = 0;
         const bool valid = i < g.b;
         const TIN* pv = video + (size_t)(valid ? i : 0) * ldv;
         const TIN* pt = text + (size_t)(valid ? i : 0) * ldt;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < KC; ++k) {
             const int d = 4 * lane + 256 * k;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cv[k][j] = 0.0; ct[k][j] = 0.0; }
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
         double iv = 1.0 / (nv > 1e-12 ? nv : 1e-12), it = 1.0 / (nt > 1e-12 ? nt : 1e-12);
         if (!NORM) iv = it = 1.0;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < KC; ++k) {
             const int d = 4 * lane + 256 * k;
             if (d < g.Dpad) {
                 float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};

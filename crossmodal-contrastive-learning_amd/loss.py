@@ -313,19 +313,21 @@ _MAX_STASH_BYTES = int(float(os.environ.get("CROSSCLR_MAX_STASH_GB", "8")) * (1 
 
 
 # Embedding widths (padded) at which the step takes the fragment-major saved backward (crossclr_backward_saved_xf) instead of the
-# LDS-staged one.  The library offers it for every Dpad <= 512 (plan.xf_bytes); measured on the MI355X (profiles/r03_xf_widths.txt) it
-# wins at 512 only (B = 2048 / 8192 / 16384: -6 / -3 / -1 %), ties at 384 and loses at 256 / 128 (+14 / +21 % at B = 8192: with short
-# tiles the saved exponentials' HBM latency is no longer covered -- the fragment loads must complete inside their iteration, which
-# caps the exponentials' prefetch distance at one tile), so the default is {512}.
-# CROSSCLR_XF_WIDTHS="128,256,384,512" (or "" for none) overrides (tuning / tests).
-_XF_WIDTHS_DEFAULT = frozenset((512,))
+# LDS-staged one.  The library offers it for every Dpad <= 1024 (plan.xf_bytes); measured on the MI355X (profiles/r03_xf_widths.txt) it
+# wins from 512 up (D = 512, B = 2048 / 8192 / 16384: -6 / -3 ... -9 / -1 %; D = 768 / 1024 at B = 8192: -2 / -4 %), ties at 384 and
+# loses at 256 / 128 (+14 / +21 % at B = 8192: with short tiles the saved exponentials' HBM latency is no longer covered -- the fragment
+# loads must complete inside their iteration, which caps the exponentials' prefetch distance at about one tile).  The second copy costs
+# crossclr_normalize_xf +1.5 us at D = 512 and +5 us at D = 1024 (+8 at B = 2048, where its 16-row blocks no longer fill the chip), so small
+# batches keep the plain pair: default = Dpad in {512, 768, 1024} with at least 2048 (D <= 512) / 4096 (wider) padded rows.
+# CROSSCLR_XF_WIDTHS="128,256,384,512" (or "" for none) overrides the widths and drops the row floor (tuning / tests).
+_XF_WIDTHS_DEFAULT = frozenset((512, 768, 1024))
 
 
-def _xf_widths():
+def _use_xf(plan) -> bool:
     e = os.environ.get("CROSSCLR_XF_WIDTHS")
     if e is None:
-        return _XF_WIDTHS_DEFAULT
-    return frozenset(int(x) for x in e.split(",") if x.strip())
+        return plan.Dpad in _XF_WIDTHS_DEFAULT and plan.bpad >= (2048 if plan.Dpad <= 512 else 4096)
+    return plan.Dpad in frozenset(int(x) for x in e.split(",") if x.strip())
 
 
 def _alloc_stash(nbytes: int, dev) -> Optional[torch.Tensor]:
@@ -414,7 +416,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     else:
         # With a saved backward to follow (plan.xf_bytes > 0: bf16 register-resident path, D <= 512) the same launch also leaves the
         # unit rows in the fragment-major layout that backward loads straight into MFMA fragments (crossclr_backward_saved_xf).
-        use_xf = save_for_backward and plan.xf_bytes > 0 and plan.stash_bytes > 0 and not small_tau and plan.Dpad in _xf_widths()
+        use_xf = save_for_backward and plan.xf_bytes > 0 and plan.stash_bytes > 0 and not small_tau and _use_xf(plan)
         ws.xf = torch.empty(plan.xf_bytes, dtype=torch.uint8, device=dev) if use_xf else None
         with _Range("crossclr.normalize"):
             if ws.xf is not None:

@@ -76,7 +76,7 @@ typedef struct crossclr_plan {
     size_t stash_bytes;     /* ABI 3: bytes of the saved-exponentials buffer of crossclr_forward_save (0: not available
                                for this plan -- use crossclr_forward / crossclr_backward, which recompute) */
     size_t xf_bytes;        /* ABI 4: bytes of the fragment-major copy of the packed operand that crossclr_normalize_xf / crossclr_pack_xf
-                               write and crossclr_backward_saved_xf reads (0: not available -- Dpad > 512, fp32 plans) */
+                               write and crossclr_backward_saved_xf reads (0: not available -- Dpad > 1024, fp32 plans) */
 } crossclr_plan;
 
 int crossclr_abi_version(void);
@@ -208,7 +208,7 @@ int crossclr_forward_save(const crossclr_plan* plan, const void* xhat, float tem
 int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const void* stash,
                             float temperature, float negative_weight, const float* rz, const float* wrz,
                             const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
-/* ABI 4 -- the fragment-major operand (plan->xf_bytes > 0: bf16 register-resident path, Dpad <= 512, local block).
+/* ABI 4 -- the fragment-major operand (plan->xf_bytes > 0: bf16 register-resident path, Dpad <= 1024, local block).
  * crossclr_normalize_xf / crossclr_pack_xf are crossclr_normalize (loss.py:79-80) / crossclr_pack that ALSO write the bf16 unit rows
  * a second time, to `xhat_xf` (plan->xf_bytes bytes, caller-owned), laid out as the MFMA B fragments of the gradient product
  *   xhat_xf[stacked row / 32][column / 32][k-step][lane][8]   (1 KiB per fragment; crossclr_kernels_generic.h: normalize_xf_kernel)

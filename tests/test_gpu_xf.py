@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,D,weighted", [(2048, 128, False), (2048, 256, True), (1536, 384, False), (8192, 512, False), (3000, 500, True),
-                                          (300, 40, False), (130, 512, False)])
+                                          (300, 40, False), (130, 512, False), (1024, 1024, True), (1536, 768, False), (8192, 1024, False)])
 def test_fragment_major_backward_equals_the_lds_staged_one_bit_for_bit(B, D, weighted):
     lib = nat.library()
     g = torch.Generator().manual_seed(B + D)
@@ -57,7 +57,7 @@ def test_fragment_major_backward_equals_the_lds_staged_one_bit_for_bit(B, D, wei
 
 def test_the_fragment_major_copy_is_the_packed_operand_rearranged():
     """xhat_xf[u][dt][ks][32 h + n][e] = xhat[32 u + 16 ks + 8 (e >> 2) + 4 h + (e & 3)][32 dt + n]  (include/crossclr.h)"""
-    B, D = 1000, 500
+    B, D = 2500, 500      # (the module's policy takes the fragment-major pair from 2048 padded rows on)
     g = torch.Generator().manual_seed(3)
     v, t = torch.randn(B, D, generator=g).cuda(), torch.randn(B, D, generator=g).cuda()
     for pre in (False, True):

@@ -329,15 +329,16 @@ def test_saved_backward_with_mirrored_tiles(B, D, weighted, monkeypatch):
         assert (gts.double() - ref["grad_t"]).abs().max().item() <= 2e-2 * scale
 
 
-@pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, True), (150, 200, False), (140, 300, True), (130, 420, False)])
+@pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, True), (150, 200, False), (140, 300, True), (130, 420, False),
+                                          (130, 600, True)])
 def test_fragment_major_backward_is_bit_identical_to_the_lds_staged_one(B, D, weighted, monkeypatch):
     """plan.xf_bytes > 0: crossclr_normalize_xf also writes the operand as MFMA B fragments and crossclr_backward_saved_xf
     (fast_bwd_dsl_kernel<..., XF>) loads them straight into registers -- two register sets, loop unrolled by two, every load
     complete inside its iteration.  Every accumulator receives the same MFMA sequence as in the LDS-staged kernel, so the gradients
-    must agree BIT FOR BIT (DK = 8 / 16 / 24 / 32, mirrored and direct tiles, with and without sample weights)."""
+    must agree BIT FOR BIT (DK = 8 / 16 / 24 / 32, two column parts at D = 600, mirrored and direct tiles, with and without sample weights)."""
     plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
     assert plan.fast_path == 1 and plan.stash_bytes > 0 and plan.xf_bytes == plan.operand_bytes and plan.bpad >= 256
-    monkeypatch.setenv("CROSSCLR_XF_WIDTHS", "128,256,384,512")     # (the module's default policy takes this path at 128 and 512 only)
+    monkeypatch.setenv("CROSSCLR_XF_WIDTHS", "128,256,384,512,768,1024")     # (the module's default policy takes this path at 128 and 512 only)
     seen = []
     lib = nat.library()
     real = lib.crossclr_backward_saved_xf

@@ -48,8 +48,13 @@ for world in (1, 2, 4, 8):
         for _ in range(5): nat.check(fn())
         e1.record(); torch.cuda.synchronize()
         stages[name] = e0.elapsed_time(e1) / 5
-    run("normalize", lambda: lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xr), p(inv), p(diag), stream))
     stash = torch.empty(plan.stash_bytes, dtype=torch.uint8, device="cuda") if plan.stash_bytes else None
+    # the local block takes the fragment-major pair where the module does (loss._use_xf)
+    xf = torch.empty(plan.xf_bytes, dtype=torch.uint8, device="cuda") if (stash is not None and plan.xf_bytes and L._use_xf(plan)) else None
+    if xf is not None:
+        run("normalize(xf)", lambda: lib.crossclr_normalize_xf(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xr), p(xf), p(inv), p(diag), stream))
+    else:
+        run("normalize", lambda: lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xr), p(inv), p(diag), stream))
     if stash is not None:   # the local block takes the save-for-backward pair, like the module does when a backward follows
         run("fwd_local(save)", lambda: lib.crossclr_forward_save(pp, p(xr), 0.03, 0.8, None, p(part), 0, p(stash), stream))
     else:
@@ -81,7 +86,9 @@ for world in (1, 2, 4, 8):
     for r in range(world):
         rzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = rz
         wrzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = wrz
-    if stash is not None:
+    if xf is not None:
+        run("bwd_local(saved, xf)", lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(gbuf), 0, stream))
+    elif stash is not None:
         run("bwd_local(saved)", lambda: lib.crossclr_backward_saved(pp, p(xr), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(gbuf), 0, stream))
     else:
         run("bwd_local", lambda: lib.crossclr_backward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(rz), p(wrz), p(rz), p(wrz), p(gbuf), 0, stream))
