@@ -38,6 +38,11 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
             os.environ["CROSSCLR_PARTNER_GRADS"] = "0"
         if "nopairs" in knobs:   # every rank evaluates all remote blocks itself
             os.environ["CROSSCLR_DISABLE_PAIR_FORWARD"] = "1"
+        if "xf" in knobs:        # the LOCAL block on the fragment-major pair (crossclr_normalize_xf + crossclr_backward_saved_xf), which the
+            os.environ["CROSSCLR_XF_WIDTHS"] = "128,256,384,512,768,1024"     # module's policy only takes from 2048 rows and D = 512 on
+            calls = []
+            real = nat.library().crossclr_backward_saved_xf
+            nat.library().crossclr_backward_saved_xf = lambda *a: (calls.append(1), real(*a))[1]
         v, t = orc.make_inputs("randn", B, D, 77)
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
@@ -45,6 +50,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         crit = crossclr_amd.CrossCLR_onlyIntraModality(tau, 0.7, compute_mode=mode, process_group=dist.group.WORLD)
         loss = crit(vl, tl)
         loss.backward()
+        if "xf" in knobs:
+            assert len(calls) == 1, "the local block did not take the fragment-major backward"
         # forward only (no_grad): nothing is saved, no statistics gather; point-to-point exchange: nobody waits for the late
         # slices in a backward, the forward itself must; generic kernels: the local block takes the symmetric evaluation
         with torch.no_grad():
@@ -93,6 +100,13 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (5, 20, 16, "bf16+p2p+recompute", 5e-3, 2e-2),
                                                        (4, 24, 16, "bf16+p2p+nosave", 5e-3, 2e-2),
                                                        (4, 24, 16, "bf16+nopairs", 5e-3, 2e-2),
+                                                       # the local block on the fragment-major operand copy while the remote blocks read the
+                                                       # gathered row-major one: all-gather + saved remote block (2 ranks), pairs + partner
+                                                       # gradients (4 ranks), per-peer exchange (5 ranks), wide operands
+                                                       (2, 40, 48, "bf16+xf", 5e-3, 2e-2),
+                                                       (4, 24, 16, "bf16+xf", 5e-3, 2e-2),
+                                                       (5, 20, 16, "bf16+each+xf", 5e-3, 2e-2),
+                                                       (3, 24, 530, "bf16+xf", 5e-3, 2e-2),
                                                        # 8 ranks (BASELINE configs 4 / 5's world size), tiny shapes: three pairs + the antipode
                                                        (8, 32, 16, "bf16", 5e-3, 2e-2),
                                                        (8, 32, 16, "bf16+each", 5e-3, 2e-2)])
