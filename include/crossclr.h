@@ -213,9 +213,9 @@ int crossclr_backward_saved(const crossclr_plan* plan, const void* xhat, const v
  * a second time, to `xhat_xf` (plan->xf_bytes bytes, caller-owned), laid out as the MFMA B fragments of the gradient product
  *   xhat_xf[stacked row / 32][column / 32][k-step][lane][8]   (1 KiB per fragment; crossclr_kernels_generic.h: normalize_xf_kernel)
  * and crossclr_backward_saved_xf is crossclr_backward_saved (autograd of loss.py:83-112 from the saved exponentials) that loads those
- * fragments straight into registers instead of staging the row-major column tile through LDS: same arguments, same result bits
- * are NOT guaranteed between the two (different summation grouping inside a tile is not used -- the MFMA order is the same -- but
- * callers should not mix them within one reproducibility domain).  The row-major `xhat` is still what every forward reads.           */
+ * fragments straight into registers instead of staging the row-major column tile through LDS: same arguments otherwise, and the SAME
+ * RESULT BITS (every accumulator receives the same MFMA sequence; tests/test_gpu_xf.py, tools/soak_xf.py).  Faster from D = 512 up
+ * (DESIGN.md 3.7), slower below; the row-major `xhat` is still what every forward and every cross-rank block reads.                  */
 int crossclr_normalize_xf(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text,
                           int in_dtype, void* xhat, void* xhat_xf, float* inv_norm, float* diag_cos, void* stream);
 int crossclr_pack_xf(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video, long ld_text,
