@@ -81,3 +81,41 @@ def test_the_fragment_major_copy_is_the_packed_operand_rearranged():
                         L._stream_for(a)))
         torch.cuda.synchronize()
         assert torch.equal(xh2, ws.xhat) and torch.equal(inv, ws.inv_norm) and torch.equal(dg, ws.diag)
+
+
+def test_the_module_verifies_the_fragment_major_backward_once_per_process_and_falls_back(monkeypatch):
+    """loss._saved_backward_kernel: the first step at a kernel instantiation runs both saved backwards and compares them bit for bit;
+    agreement -> the fragment-major one from then on; a difference (simulated here by feeding it a zeroed operand copy) -> a warning, the
+    LDS-staged kernel for the rest of the process, and correct gradients on that very step."""
+    import warnings
+    lib = nat.library()
+    B, D = 2304, 512
+    g = torch.Generator().manual_seed(11)
+    v0, t0 = torch.randn(B, D, generator=g).cuda(), torch.randn(B, D, generator=g).cuda()
+
+    def step():
+        v, t = v0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+        crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="bf16").backward()
+        return v.grad, t.grad
+    calls = {"xf": 0, "lds": 0}
+    real_xf, real_lds = lib.crossclr_backward_saved_xf, lib.crossclr_backward_saved
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xf", lambda *a: (calls.__setitem__("xf", calls["xf"] + 1), real_xf(*a))[1])
+    monkeypatch.setattr(lib, "crossclr_backward_saved", lambda *a: (calls.__setitem__("lds", calls["lds"] + 1), real_lds(*a))[1])
+    monkeypatch.setattr(L, "_xf_verified", {})
+    gv, gt = step()
+    assert calls == {"xf": 1, "lds": 1} and list(L._xf_verified.values()) == [True]
+    gv2, gt2 = step()
+    assert calls == {"xf": 2, "lds": 1} and torch.equal(gv, gv2) and torch.equal(gt, gt2)
+    # a build whose fragment-major kernel is wrong
+    zeros = torch.zeros(nat.make_plan(B, D, 1, 0, nat.MODE_BF16).xf_bytes, dtype=torch.uint8, device="cuda")
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xf",
+                        lambda pp, xf, *rest: (calls.__setitem__("xf", calls["xf"] + 1), real_xf(pp, ctypes.c_void_p(zeros.data_ptr()), *rest))[1])
+    monkeypatch.setattr(L, "_xf_verified", {})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        gv3, gt3 = step()
+    assert any("fragment-major" in str(x.message) for x in w) and list(L._xf_verified.values()) == [False]
+    assert torch.equal(gv3, gv) and torch.equal(gt3, gt)
+    before = dict(calls)
+    gv4, _ = step()
+    assert calls["xf"] == before["xf"] and calls["lds"] == before["lds"] + 1 and torch.equal(gv4, gv)
