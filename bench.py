@@ -115,7 +115,8 @@ def cpu_baseline(b, d, fwd_only=False):
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - budget_t0 > 25 and i >= 1:
             break
-    best = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    rest = sorted(times[1:] or times)
+    best = rest[(len(rest) - 1) // 2]      # median of the post-warm-up samples (the lower middle one of an even count)
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -124,11 +125,58 @@ def cpu_baseline(b, d, fwd_only=False):
         pass
     return {"value": bb * bb / best, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": cpu_model,
-            "samples_per_s": bb / best, "seconds_per_step": best, "host_cpus": os.cpu_count(),
-            "loss": float(loss),
+            "samples_per_s": bb / best, "seconds_per_step": best, "seconds_all_steps": [round(x, 4) for x in times],
+            "host_cpus": os.cpu_count(),
+            "loss": float(loss.detach()),
             "sample": f"oracle.eager_loss{'' if fwd_only else '_and_grads'} (op-for-op reference restatement) "
                       f"{'fwd' if fwd_only else 'fwd+bwd'}, fp32 inputs, "
                       f"B={bb} D={d}, {len(times)} steps (first = warm-up), median of the rest"}
+
+
+def sustained_mfma(dev):
+    """What a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on THIS device in THIS run (crossclr_mfma_sustained: 256 blocks x 4
+    waves x 16 independent chains; pseudo-random operands = toggling data, and all-zero operands beside it): the package power
+    limit, not the schedule, sets this rate.  HIP events, median of 5 launches of ~1.3 ms after 3 settle launches."""
+    from crossclr_amd import _native as nat
+    lib = nat.library()
+    blocks, iters = 256, 4096
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    flop = blocks * 4.0 * iters * 16 * 32768
+    res = {}
+    for name, zero in (("random_operands", 0), ("zero_operands", 1)):
+        for _ in range(3):
+            nat.check(lib.crossclr_mfma_sustained(out.data_ptr(), blocks, iters, 12345, zero, stream))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for i, (a, z) in enumerate(ev):
+            a.record()
+            nat.check(lib.crossclr_mfma_sustained(out.data_ptr(), blocks, iters, 777 + i, zero, stream))
+            z.record()
+        torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(z) for a, z in ev)
+        res[name] = {"tflops": round(flop / (ms[2] * 1e-3) / 1e12, 1), "ms_per_launch": round(ms[2], 4)}
+    res["kernel"] = "mfma_sustained_kernel (crossclr_mfma_sustained): 256 blocks x 4 waves x 4096 x 16 MFMAs, 16 accumulator chains"
+    return res
+
+
+def sustained_series(step, dev, nsteps, chunk=100):
+    """`nsteps` more steps of the same workload, HIP events around every `chunk` steps: does the step time hold for a second or
+    more on a part that runs at its package power limit?"""
+    n = max(1, nsteps // chunk)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev[0].record()
+    for c in range(n):
+        for _ in range(chunk):
+            step()
+        ev[c + 1].record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    per = [ev[c].elapsed_time(ev[c + 1]) / chunk for c in range(n)]
+    return {"steps": n * chunk, "ms_per_step": round(wall * 1e3 / (n * chunk), 5), "first_100": round(per[0], 5), "last_100": round(per[-1], 5),
+            "min_chunk": round(min(per), 5), "max_chunk": round(max(per), 5), "chunk_steps": chunk,
+            "note": "wall clock over all steps; first/last/min/max = HIP-event time per step of a 100-step chunk"}
 
 
 def secondary_lines(dev):
@@ -178,7 +226,7 @@ def secondary_lines(dev):
         dom = "step_forward" if fwd_only else "step_backward"
         flops = (6.0 if fwd_only else 8.0) * rows * rows * dim
         tf = flops / (st[dom] * 1e-3) / 1e12
-        out[name] = {"ms_per_step_event_median": round(ms, 4), "pairs_per_s": rows * rows / (ms * 1e-3), "loss": float(loss),
+        out[name] = {"ms_per_step_event_median": round(ms, 4), "pairs_per_s": rows * rows / (ms * 1e-3), "loss": float(loss.detach()),
                      "loss_delta_vs_reference": abs(float(loss) - golden) if golden is not None else None,
                      "dominant_kernel": ("forward" if fwd_only else "backward") + (" (saved exponentials)" if st.get("saved_path") and not fwd_only else ""),
                      "dominant_kernel_ms": round(st[dom], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
@@ -204,6 +252,9 @@ def main():
                          "only after ~20-50 steps: 0.79 -> 0.72 ms/step); reported in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary measurements (fp32, config 2, D = 1024)")
+    ap.add_argument("--sustained-steps", type=int, default=2000,
+                    help="extra untimed-by-the-contract steps AFTER the timed region whose time series (per 100 steps) is reported "
+                         "as `sustained` (about one second at the default workload); 0 = skip")
     ap.add_argument("--fwd-only", action="store_true", help="forward under no_grad only (BASELINE configs[1])")
     ap.add_argument("--selftest-emu", action="store_true",
                     help="TESTS ONLY (tests/test_bench_cpu.py): CPU tensors, gloo, the host-emulation build of the kernels -- "
@@ -290,63 +341,87 @@ def main():
         if not emu:
             torch.cuda.synchronize(dev)
 
+    from crossclr_amd import loss as L
+
+    def timed_run():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize fences (max over ranks), HIP events around
+        every step; with several ranks a few extra diagnostic steps with events around every wait on a collective."""
+        for _ in range(args.warmup):
+            loss = step()
+        # HIP events on the compute stream around every timed step (they cost ~1 us each and do not synchronise)
+        ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if ev:
+                ev[i][0].record()
+            loss = step()
+            if ev:
+                ev[i][1].record()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = tmax.item()
+        ev_ms = sorted(a.elapsed_time(z) for a, z in ev) if ev else []
+        # ---- multi-rank diagnostics (untimed, after the measured region): per rank, the HIP-event time of a step and how much of it
+        # the compute stream spent WAITING for collectives (events around every wait: communication not hidden behind compute) ----
+        per_rank = None
+        if world > 1:
+            diag_steps = 0 if emu else 5
+            waits, steps_ms = [], []
+            for _ in range(diag_steps):
+                L._comm_trace = []
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                step()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                steps_ms.append(e0.elapsed_time(e1))
+                by_tag = {}
+                for tag, a, z in L._comm_trace:
+                    by_tag[tag] = by_tag.get(tag, 0.0) + a.elapsed_time(z)
+                waits.append(by_tag)
+            L._comm_trace = None
+            mine = {"rank": rank, "exchange": L._last_exchange_mode,
+                    "step_ms_event_median": sorted(steps_ms)[len(steps_ms) // 2] if steps_ms else None,
+                    "timed_step_ms_event_median": ev_ms[len(ev_ms) // 2] if ev_ms else None}
+            if waits:
+                tags = sorted({k for w in waits for k in w})
+                med = lambda xs: sorted(xs)[len(xs) // 2]
+                mine["exposed_comm_ms_by_wait"] = {k: round(med([w.get(k, 0.0) for w in waits]), 4) for k in tags}
+                mine["exposed_comm_ms"] = round(med([sum(w.values()) for w in waits]), 4)
+                mine["compute_ms"] = round(mine["step_ms_event_median"] - mine["exposed_comm_ms"], 4)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            per_rank = gathered
+        return {"t_step": elapsed / args.steps, "loss": float(loss.item()), "ev_ms": ev_ms, "per_rank": per_rank}
+
     for _ in range(max(0, args.prewarm)):
         step()
-    for _ in range(args.warmup):
-        loss = step()
-    # HIP events on the compute stream around every timed step (they cost ~1 us each and do not synchronise)
-    ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if ev:
-            ev[i][0].record()
-        loss = step()
-        if ev:
-            ev[i][1].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-    t_step = elapsed / args.steps
+    # From 3 ranks on the packed operands can travel three ways (loss._OperandExchange); which one wins is a property of the node, so the
+    # timed region is run once per form, back to back (each with its own warm-up), and the line reports all three: `value` / `ms_per_step`
+    # are the fastest form's K steps, `per_exchange` the table.  CROSSCLR_EXCHANGE pins one form (then only that one is run).
+    per_exchange = None
+    if world >= 3 and args.mode == "bf16" and os.environ.get("CROSSCLR_EXCHANGE") is None and not args.fwd_only:
+        per_exchange, runs = {}, {}
+        for xm in ("allgather", "p2p", "p2p_each"):
+            L.set_exchange_for_benchmark(xm)
+            r = runs[xm] = timed_run()
+            exposed = [pr.get("exposed_comm_ms") for pr in (r["per_rank"] or []) if pr.get("exposed_comm_ms") is not None]
+            per_exchange[xm] = {"ms_per_step": round(r["t_step"] * 1e3, 5),
+                                "ms_per_step_event_median_rank0": round(r["ev_ms"][len(r["ev_ms"]) // 2], 5) if r["ev_ms"] else None,
+                                "exposed_comm_ms_max_over_ranks": max(exposed) if exposed else None}
+        best = min(per_exchange, key=lambda k: per_exchange[k]["ms_per_step"])
+        L.set_exchange_for_benchmark(best)      # (the secondary / sustained measurements below run the winner)
+        run = runs[best]
+        for k in per_exchange:
+            per_exchange[k]["winner"] = k == best
+    else:
+        run = timed_run()
+    t_step, loss_val, ev_ms, per_rank = run["t_step"], run["loss"], run["ev_ms"], run["per_rank"]
     B = b * world
-    loss_val = float(loss.item())
-    ev_ms = sorted(a.elapsed_time(z) for a, z in ev) if ev else []
-
-    # ---- multi-rank diagnostics (untimed, after the measured region): per rank, the HIP-event time of a step and how much of it the
-    # compute stream spent WAITING for collectives (events around every wait: communication not hidden behind compute) ----
-    per_rank = None
-    if world > 1:
-        from crossclr_amd import loss as L
-        diag_steps = 0 if emu else 5
-        waits, steps_ms = [], []
-        for _ in range(diag_steps):
-            L._comm_trace = []
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            step()
-            e1.record()
-            torch.cuda.synchronize(dev)
-            steps_ms.append(e0.elapsed_time(e1))
-            by_tag = {}
-            for tag, a, z in L._comm_trace:
-                by_tag[tag] = by_tag.get(tag, 0.0) + a.elapsed_time(z)
-            waits.append(by_tag)
-        L._comm_trace = None
-        mine = {"rank": rank, "exchange": L._last_exchange_mode,
-                "step_ms_event_median": sorted(steps_ms)[len(steps_ms) // 2] if steps_ms else None,
-                "timed_step_ms_event_median": ev_ms[len(ev_ms) // 2] if ev_ms else None}
-        if waits:
-            tags = sorted({k for w in waits for k in w})
-            med = lambda xs: sorted(xs)[len(xs) // 2]
-            mine["exposed_comm_ms_by_wait"] = {k: round(med([w.get(k, 0.0) for w in waits]), 4) for k in tags}
-            mine["exposed_comm_ms"] = round(med([sum(w.values()) for w in waits]), 4)
-            mine["compute_ms"] = round(mine["step_ms_event_median"] - mine["exposed_comm_ms"], 4)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        per_rank = gathered
 
     if rank != 0:
         if world > 1:
@@ -360,7 +435,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "SELFTEST on the host emulation of the kernels (not a measurement)", "global_batch": B},
-               "loss": loss_val, "per_rank": per_rank}
+               "loss": loss_val, "per_rank": per_rank, "per_exchange": per_exchange}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         if world > 1:
             dist.barrier()
@@ -376,11 +451,12 @@ def main():
     # forward_save / backward_saved are what a training step launches when the plan has the save-for-backward pair
     # (forward / backward are the recomputing entry points, timed for comparison)
     alg = {"forward": 6.0 * b * b * d, "backward": 8.0 * b * b * d, "forward_save": 6.0 * b * b * d, "backward_saved": 8.0 * b * b * d,
-           "backward_saved_lds": 8.0 * b * b * d}
+           "backward_saved_lds": 8.0 * b * b * d, "backward_saved_xf1": 8.0 * b * b * d}
     kernels = {}
     # (normalize_plain / backward_saved_lds: the pair without the fragment-major operand copy, timed beside the one the step runs)
-    for k in ("normalize", "normalize_plain", "forward", "forward_save", "forward_finish", "backward", "backward_saved", "backward_saved_lds",
-              "backward_finish"):
+    # (backward_saved_xf1 / backward_saved_lds: the one-tile-per-barrier fragment-major kernel and the LDS-staged one, beside the step's)
+    for k in ("normalize", "normalize_plain", "forward", "forward_save", "forward_finish", "backward", "backward_saved", "backward_saved_xf1",
+              "backward_saved_lds", "backward_finish"):
         if k not in st:
             continue
         kernels[k] = {"ms": round(st[k], 4)}
@@ -395,12 +471,19 @@ def main():
         dom_kernel = (("fast_bwd_dsl_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
                       else ("fast_bwd" if st["fast_path"] else "bwd_kernel"))
     dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
-    # the saved backward has two instantiations per width: column tiles staged through LDS (..., false>) or loaded straight into MFMA
-    # fragments from the fragment-major operand copy (..., true>: what the step runs when stage_times reports xf_path)
+    # the saved backward of the local block has three kernels per width: the pair kernel on the fragment-major operand (fast_bwd_xfp_kernel:
+    # what the step runs when stage_times reports xfp_path), the one-tile-per-barrier kernel on the same operand (fast_bwd_dsl_kernel<...,
+    # true>) and the one that stages the column tiles through LDS (..., false>)
     dom_suffix = None
-    if dom_kernel == "fast_bwd_dsl_kernel":
+    entry_suffix = ""
+    if dom_kernel == "fast_bwd_dsl_kernel" and st.get("xfp_path"):
+        dom_kernel = "fast_bwd_xfp_kernel"
+        dom_kernel_label = "fast_bwd_xfp_kernel: column tiles as MFMA fragments from the fragment-major operand, two tiles per barrier interval"
+        entry_suffix = "_xfp"
+    elif dom_kernel == "fast_bwd_dsl_kernel":
         dom_suffix = ", true>" if st.get("xf_path") else ", false>"
         dom_kernel_label = dom_kernel + ("<..., XF>: column tiles as MFMA fragments from the fragment-major operand" if st.get("xf_path") else "")
+        entry_suffix = "_xf" if st.get("xf_path") else ""
     else:
         dom_kernel_label = dom_kernel
     traffic = measured_traffic(b, d, args.mode, dom_kernel, dom_suffix) if world == 1 and not args.influential else None
@@ -422,7 +505,7 @@ def main():
                    "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather of packed operands" if world > 1 else ""),
                    "fast_path": bool(st["fast_path"]), "save_for_backward": saved and not args.fwd_only},
         "loss": loss_val,
-        "roofline": {"bound": "mfma", "kernel": f"{dom_kernel_label} (crossclr_{dom}{'_xf' if st.get('xf_path') and dom == 'backward_saved' else ''}; dominant kernel)",
+        "roofline": {"bound": "mfma", "kernel": f"{dom_kernel_label} (crossclr_{dom}{entry_suffix if dom == 'backward_saved' else ''}; dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
                      "source": "HIP events in this process (torch's current stream = the launch stream), average of 10 launches "
                                "after the timed region; the rocprofv3 figure of the same command is under profiles/",
@@ -436,17 +519,25 @@ def main():
                      "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
                      "whole_step_algorithmic_tflops_per_gpu": round(step_tf, 2),
                      "whole_step_frac": round(step_tf / peak, 4),
-                     # what a loop of nothing but MFMAs sustains on this pool's MI355X (tools/micro/mfma_chains.hip,
-                     # profiles/r02c_micro.txt): the package sits at its 1400 W limit with toggling operands
-                     "sustained_mfma_tflops_random_operands": 1650.0 if args.mode == "bf16" else None,
-                     "frac_of_sustained": round(dom_tf / 1650.0, 4) if args.mode == "bf16" else None},
+                     },
         "kernels": kernels,
     }
+    if args.mode == "bf16":
+        # what a loop of nothing but MFMAs sustains on this device, measured NOW (the package sits at its power limit with toggling
+        # operands: DESIGN.md 3.1) -- not a constant carried over from an earlier round
+        sm = sustained_mfma(dev)
+        out["roofline"]["sustained_mfma"] = sm
+        out["roofline"]["frac_of_sustained_random_operands"] = round(dom_tf / sm["random_operands"]["tflops"], 4)
+    if world == 1 and args.sustained_steps > 0:
+        out["sustained"] = sustained_series(step, dev, args.sustained_steps)
     if per_rank is not None:
         # (the waits are measured on a handful of extra steps with events around every collective wait: `exposed_comm_ms` is
         #  communication the compute stream had to sit out, `compute_ms` the rest of that step)
         out["per_rank"] = per_rank
         out["config"]["operand_exchange"] = per_rank[0].get("exchange")
+        if per_exchange is not None:
+            # (three timed regions were run, one per way the operands can travel; `value` is the fastest one's)
+            out["per_exchange"] = per_exchange
     if args.influential:
         out["config"]["pruned_fraction"] = [round(1.0 - float(k.mean()), 4) for k in sw[0]]
     if world == 1 and b == B_PER_GPU and d == DIM and not args.influential:

@@ -19,7 +19,7 @@ HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcro
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
-ABI_VERSION = 4
+ABI_VERSION = 5
 LAUNCH_GROUPS = 8      # CROSSCLR_LAUNCH_GROUPS of include/crossclr.h
 
 
@@ -85,6 +85,8 @@ _SIGNATURES = {
     "crossclr_pack_xf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, _P, _P, _P, _P, _P]),
     "crossclr_backward_saved_xf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
                                                   ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    "crossclr_backward_saved_xfp": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, ctypes.c_float, _P, _P,
+                                                  ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     # ABI version 3: rectangular blocks with saved exponentials
     "crossclr_rect_stash_bytes": (ctypes.c_size_t, [ctypes.POINTER(Plan), ctypes.c_int]),
     "crossclr_forward_rect_save": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
@@ -92,6 +94,12 @@ _SIGNATURES = {
     "crossclr_backward_rect_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                     ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     "crossclr_backward_rect_saved_t": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                      ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, _P]),
+    # ABI version 5: remote blocks on the fragment-major operand (pair kernel), the copy made from received slices
+    "crossclr_pack_xf_from_packed": (ctypes.c_int, [ctypes.POINTER(Plan), _P, ctypes.c_int, _P, _P]),
+    "crossclr_backward_rect_saved_xfp": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                    ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    "crossclr_backward_rect_saved_t_xfp": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                       ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, _P]),
     "crossclr_backward_ranks": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
@@ -133,6 +141,8 @@ _SIGNATURES = {
     "crossclr_maxmargin_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P]),
     "crossclr_maxmargin_backward_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                                           _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P]),
+    # measurement aid (bench.py: the matrix pipe's sustained rate on this device, in the run that quotes it)
+    "crossclr_mfma_sustained": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, _P]),
 }
 INFL_BLOCKS = 256
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

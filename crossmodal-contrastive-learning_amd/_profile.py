@@ -36,6 +36,8 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
 
     stash = ws.stash   # None when the plan has no save-for-backward path
     xf = ws.xf         # None when the plan has no fragment-major operand (then the saved backward stages column tiles through LDS)
+    xf_name = L._saved_backward_entry(ws, plan, dev) if (xf is not None and stash is not None) else "crossclr_backward_saved"
+    xf_entry = getattr(lib, xf_name)
     stages = {
         "normalize": (lambda: lib.crossclr_normalize_xf(pp, p(video), p(text), video.stride(0), text.stride(0), ws.in_dtype,
                                                         p(ws.xhat), p(xf), p(ws.inv_norm), p(ws.diag), stream)) if xf is not None else
@@ -49,10 +51,13 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
         "backward": lambda: lib.crossclr_backward_w(pp, p(ws.xhat), p(ws.xhat), 1, 0, -1, t, w, p(ws.rz), p(ws.wrz),
                                                     p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream),
         "forward_save": (lambda: lib.crossclr_forward_save(pp, p(ws.xhat), t, w, sw_k, p(part), 0, p(stash), stream)) if stash is not None else None,
-        "backward_saved": ((lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream))
+        "backward_saved": ((lambda: xf_entry(pp, p(xf if xf_name != "crossclr_backward_saved" else ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream))
                            if xf is not None else
                            (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
                                                                 p(gbuf), 0, stream))) if stash is not None else None,
+        # (the fragment-major kernel with one tile per barrier interval, beside the pair kernel the step runs)
+        "backward_saved_xf1": (lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream))
+                              if (stash is not None and xf is not None and xf_name != "crossclr_backward_saved_xf") else None,
         "backward_saved_lds": (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
                                                                    p(gbuf), 0, stream)) if (stash is not None and xf is not None) else None,
         "backward_finish": lambda: lib.crossclr_backward_finish_w(pp, p(gbuf), p(video), p(text), video.stride(0),
@@ -75,7 +80,8 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
         out[name] = sum(a.elapsed_time(b) for a, b in zip(e0, e1)) / iters
     out["fast_path"] = float(plan.fast_path)
     out["saved_path"] = float(stash is not None)
-    out["xf_path"] = float(xf is not None)
+    out["xf_path"] = float(xf is not None and xf_name != "crossclr_backward_saved")
+    out["xfp_path"] = float(xf_name == "crossclr_backward_saved_xfp")
     # the stages a training step actually runs
     out["step_forward"] = out.get("forward_save", out["forward"])
     out["step_backward"] = out.get("backward_saved", out["backward"])

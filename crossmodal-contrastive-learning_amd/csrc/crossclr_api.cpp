@@ -610,6 +610,27 @@ extern "C" int crossclr_backward_saved_xf(const crossclr_plan* plan, const void*
 #endif
 }
 
+extern "C" int crossclr_backward_saved_xfp(const crossclr_plan* plan, const void* xhat_xf, const void* stash, float temperature,
+                                           float negative_weight, const float* rz, const float* wrz,
+                                           const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat_xf || !stash || !rz || !wrz || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_saved_xfp needs the register-resident path");
+#else
+    if (!plan->stash_bytes || !plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major saved backward (stash_bytes / xf_bytes == 0)");
+    if (plan->stash_bytes >= ((size_t)1 << 32))
+        return fail(CROSSCLR_E_ARG, "crossclr_backward_saved_xfp addresses the saved exponentials with 32-bit offsets (stash of %zu bytes): use crossclr_backward_saved_xf", plan->stash_bytes);
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    if (krows != kcols) return fail(CROSSCLR_E_ARG, "the local block's row and column negative scales are the same array");
+    Geo g;
+    int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
+    if (rc) return rc;
+    rc = fast_backward_saved(plan, g, xhat_xf, stash, rz, wrz, rz, wrz, gbuf, accumulate, krows, krows, 4, stream);
+    return rc ? fail(rc, "fast_backward_saved (xfp): unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_xfp_kernel");
+#endif
+}
+
 extern "C" int crossclr_forward_pairs(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank,
                                       int nranks, float temperature, float negative_weight,
                                       const crossclr_sample_weights* sw, float* part, int slot0, float* colsum_out,
@@ -977,6 +998,73 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
 #endif
 }
 
+// The fragment-major copy of `nranks` consecutive packed operands (the slices of a gathered operand a rank received): what the pair
+// kernel's rectangular launches read their column tiles from.
+extern "C" int crossclr_pack_xf_from_packed(const crossclr_plan* plan, const void* xhat_packed, int nranks, void* xhat_xf, void* stream) {
+    if (!plan || !xhat_packed || !xhat_xf || nranks < 1) return fail(CROSSCLR_E_ARG, "bad arguments");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_pack_xf_from_packed needs the register-resident path");
+#else
+    if (!plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major operand (xf_bytes == 0)");
+    const size_t tiles = (size_t)nranks * 2 * plan->bpad / 32;
+    if (tiles > 0x7fffffffull) return fail(CROSSCLR_E_ARG, "too many rows");
+    LAUNCH(xf_from_packed_kernel, dim3((unsigned)tiles), dim3(256), stream, (const bf16_t*)xhat_packed, (unsigned char*)xhat_xf, plan->Dpad);
+    return launch_status("xf_from_packed_kernel");
+#endif
+}
+
+// crossclr_backward_rect_saved on the fragment-major copy of the gathered operand, with the pair kernel (two tiles per barrier interval).
+extern "C" int crossclr_backward_rect_saved_xfp(const crossclr_plan* plan, const void* xf_all, const void* stash, int first_rank,
+                                                int nranks, float temperature, float negative_weight, const float* rz_rows,
+                                                const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                                const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xf_all || !stash || !rz_rows || !wrz_rows || !rz_all || !wrz_all || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved_xfp needs the register-resident path");
+#else
+    if (!plan->stash_bytes || !plan->fast_path || !plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major saved backward for remote blocks");
+    if ((size_t)plan->world * plan->operand_bytes >= ((size_t)1 << 32) || fast_stash_bytes_rect(plan->bpad, plan->Dpad, nranks) >= ((size_t)1 << 32))
+        return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved_xfp uses 32-bit offsets (operand / stash of 4 GiB or more): use crossclr_backward_rect_saved");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);
+    if (rc) return rc;
+    rc = fast_backward_saved(plan, g, xf_all, stash, rz_rows, wrz_rows, rz_all, wrz_all, gbuf, accumulate, krows, kcols, 5, stream);
+    return rc ? fail(rc, "fast_backward_saved (xfp, rect): unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_xfp_kernel (rect)");
+#endif
+}
+
+// crossclr_backward_rect_saved_t on this rank's LOCAL fragment-major operand (what crossclr_normalize_xf wrote), with the pair kernel.
+extern "C" int crossclr_backward_rect_saved_t_xfp(const crossclr_plan* plan, const void* xf_rows, const void* stash, int first_rank,
+                                                  int nranks, int which, float temperature, float negative_weight, const float* rz_rows,
+                                                  const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                                  const crossclr_sample_weights* sw, float* gpartner, void* stream) {
+    if (!plan || !xf_rows || !stash || !rz_rows || !wrz_rows || !rz_all || !wrz_all || !gpartner) return fail(CROSSCLR_E_ARG, "NULL argument");
+#ifdef CROSSCLR_NO_FAST
+    return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved_t_xfp needs the register-resident path");
+#else
+    if (!plan->stash_bytes || !plan->fast_path || !plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major saved backward for remote blocks");
+    if (which < 0 || which >= nranks) return fail(CROSSCLR_E_ARG, "which must be 0 .. nranks-1");
+    if (fast_stash_bytes_rect(plan->bpad, plan->Dpad, nranks) >= ((size_t)1 << 32))
+        return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved_t_xfp uses 32-bit offsets (stash of 4 GiB or more): use crossclr_backward_rect_saved_t");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g);     // (validates the range; scales)
+    if (rc) return rc;
+    const int partner = (first_rank + which) % plan->world;
+    const size_t n2 = (size_t)2 * plan->bpad;
+    g.col_ranks = nranks;        // rank segments per row of the rectangular stash
+    g.skip_rank = which;         // the partner's segment inside a stash row
+    g.col_rank0 = plan->rank; g.col_wrap = 0;
+    g.row_rank = partner;
+    rc = fast_backward_saved(plan, g, xf_rows, stash, rz_all + partner * n2, wrz_all + partner * n2, rz_rows, wrz_rows, gpartner, 0,
+                             kcols ? kcols + partner * n2 : nullptr, krows, 6, stream);
+    return rc ? fail(rc, "fast_backward_saved (xfp, transposed): unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_xfp_kernel (rect, transposed)");
+#endif
+}
+
 // The transpose of one saved rectangular block: what block (this rank x partner) contributes to the PARTNER's gradient buffer.
 extern "C" int crossclr_backward_rect_saved_t(const crossclr_plan* plan, const void* xhat_rows, const void* stash, int first_rank,
                                               int nranks, int which, float temperature, float negative_weight, const float* rz_rows,
@@ -1242,6 +1330,52 @@ extern "C" int crossclr_influence_finish(const crossclr_plan* plan, const double
     LAUNCH(infl_finish_kernel, dim3(2), dim3(1024), stream, conn_all, plan->world, plan->rank, plan->b, plan->bpad,
            (double)score_threshold, (double)temperature_weights, neg_scale, loss_weight);
     return launch_status("infl_finish_kernel");
+}
+
+// The sustained rate of the bf16 matrix pipe on THIS device, measured in the run that quotes it (bench.py: `roofline.sustained_mfma`):
+// 256 blocks x 4 waves (one per SIMD), 16 independent accumulator chains of v_mfma_f32_32x32x16_bf16 per wave, nothing else in the
+// loop; operands pseudo-random (toggling data: what the package power limit allows a real kernel) or all zero (`zero_operands`).
+// One launch executes blocks * 4 * iters * 16 MFMAs of 32768 flop.
+namespace crossclr {
+#ifndef CROSSCLR_EMU
+__global__ void __launch_bounds__(256, 1) mfma_sustained_kernel(float* out, int iters, unsigned seed, int zero_operands) {
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    unsigned x = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        x = x * 1664525u + 1013904223u;
+        a[j] = zero_operands ? (__bf16)0.f : (__bf16)((float)(x >> 8) * (1.f / 16777216.f) - 0.5f);
+        x = x * 1664525u + 1013904223u;
+        b[j] = zero_operands ? (__bf16)0.f : (__bf16)((float)(x >> 8) * (1.f / 16777216.f) - 0.5f);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = mfma_32x32x16_bf16(a, b, acc[i]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+#endif
+}  // namespace crossclr
+
+extern "C" int crossclr_mfma_sustained(float* out, int blocks, int iters, unsigned seed, int zero_operands, void* stream) {
+#ifndef CROSSCLR_EMU
+    if (!out || blocks < 1 || blocks > 4096 || iters < 1) return fail(CROSSCLR_E_ARG, "bad mfma_sustained arguments");
+    LAUNCH(mfma_sustained_kernel, dim3(blocks), dim3(256), stream, out, iters, seed, zero_operands);
+    return launch_status("mfma_sustained_kernel");
+#else
+    (void)out; (void)blocks; (void)iters; (void)seed; (void)zero_operands; (void)stream;
+    return fail(CROSSCLR_E_ARG, "crossclr_mfma_sustained measures the device: not available in the host emulation");
+#endif
 }
 
 extern "C" int crossclr_selftest(int which, const void* in, void* out, void* stream) {

@@ -752,6 +752,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 }  // namespace crossclr
 #include "crossclr_kernels_sym.h"
 #include "crossclr_kernels_dsl.h"
+#include "crossclr_kernels_dslp.h"
 namespace crossclr {
 
 // ---------------------------------------------------------------------------------------------
@@ -765,6 +766,31 @@ namespace crossclr {
     hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 #endif
 
+// The launchers that instantiate the heavy kernel templates are "leaves": in the default single-translation-unit build (tests/emu, tools/
+// build_variant.py) they are static inline like everything else here; the product build (build.py, -DCROSSCLR_SPLIT) compiles
+// crossclr_api.cpp with the leaves only DECLARED and one small translation unit per leaf (csrc/tu_*.cpp: -DCROSSCLR_TU_<LEAF>) that
+// defines it -- the instantiations then compile in parallel instead of one after the other (6+ minutes -> the longest leaf).
+#ifdef CROSSCLR_SPLIT
+#define CROSSCLR_LEAF
+#else
+#define CROSSCLR_LEAF static inline
+#endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_FWD)
+#define CROSSCLR_DEF_FWD 1
+#endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_LDS)
+#define CROSSCLR_DEF_SAVED_LDS 1
+#endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_XF1)
+#define CROSSCLR_DEF_SAVED_XF1 1
+#endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_XFP)
+#define CROSSCLR_DEF_SAVED_XFP 1
+#endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_RECOMP)
+#define CROSSCLR_DEF_RECOMP 1
+#endif
+
 static inline int fast_fwd_tpr(int Dpad) { return Dpad <= 512 ? 8 : 4; }   // waves per block = 32-column tiles per row block
 
 static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, int skip_rank, bool symmetric, bool pairs = false) {
@@ -773,7 +799,12 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
 }
 
 // the software-pipelined forward (Dpad <= 512), all three kinds, with or without saving the exponentials
-static inline int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols,
+#ifndef CROSSCLR_DEF_FWD
+int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols,
+                      float* part, float* colpart, int* header, int kind, const float* krows, const float* kcols,
+                      void* stash, void* stream);
+#else
+CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols,
                                     float* part, float* colpart, int* header, int kind, const float* krows, const float* kcols,
                                     void* stash, void* stream) {
     if (wk.total <= 0) return CROSSCLR_OK;
@@ -829,6 +860,7 @@ static inline int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
 #undef CROSSCLR_LP3
     return CROSSCLR_OK;
 }
+#endif   // CROSSCLR_DEF_FWD
 
 static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, float* part,
                                float* colpart, int* header, bool symmetric, const float* krows, const float* kcols,
@@ -863,44 +895,117 @@ static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const 
 // the column ranks; cols / rz_cols / wrz_cols / kc use the column operand's indexing).  mode 2: the transpose of ONE rectangular block
 // (crossclr_backward_rect_saved_t): output rows = the partner's, cols / *_cols / kc = this rank's LOCAL operand and statistics,
 // rz / wrz / ks = the partner's statistics; g.col_ranks = rank segments per stash row, g.skip_rank = the partner's segment.
-static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* cols, const void* stash, const float* rz,
-                                      const float* wrz, const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
-                                      const float* ks, const float* kc, int mode, void* stream) {
-    const bool xf = mode == 3;      // mode 3 = mode 0 with `cols` in the fragment-major layout (crossclr_normalize_xf; Dpad <= 512)
-    if (xf) mode = 0;
-    const bool rect = mode == 1;
-    const bool skipping = rect && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
-    const int ntiles = (rect ? g.col_ranks - (skipping ? 1 : 0) : 1) * (2 * p->bpad / 32);
-    if (ntiles <= 0) return CROSSCLR_OK;
-    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+struct SavedLaunch {      // one launch of a saved backward, as the leaves below take it
+    const crossclr_plan* p; Geo g; const void* cols; const void* stash; const float *rz, *wrz, *rz_cols, *wrz_cols; float* gbuf; int accumulate;
+    const float *ks, *kc; int mode; int tps; void* stream; size_t stash_bytes;
+};
+// the pair kernel (crossclr_kernels_dslp.h): local block, fragment-major operand, two tiles per barrier interval
+#ifndef CROSSCLR_DEF_SAVED_XFP
+int launch_saved_xfp(const SavedLaunch& a);
+#else
+CROSSCLR_LEAF int launch_saved_xfp(const SavedLaunch& a) {
+    const crossclr_plan* p = a.p;
+    const Geo& g = a.g;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
-    const bf16_t* c = (const bf16_t*)cols;
-    const unsigned char* st = (const unsigned char*)stash;
-#ifdef CROSSCLR_DSL_MINIMAL   // tuning builds (tools/build_variant.py): only the headline instantiation is compiled (seconds instead of minutes)
+    void* stream = a.stream;
+    const unsigned char* st = (const unsigned char*)a.stash;
+    const unsigned sb = (unsigned)a.stash_bytes;
+    const unsigned char* xfo = (const unsigned char*)a.cols;
+    const float *rz = a.rz, *wrz = a.wrz, *rz_cols = a.rz_cols, *wrz_cols = a.wrz_cols, *ks = a.ks, *kc = a.kc;
+    float* gbuf = a.gbuf;
+    const int accumulate = a.accumulate, tps2 = a.tps, mode = a.mode;
+    (void)grid; (void)block; (void)stream; (void)st; (void)sb; (void)xfo; (void)rz; (void)wrz; (void)rz_cols; (void)wrz_cols; (void)kc; (void)gbuf;
+    (void)accumulate; (void)tps2; (void)mode;
+#ifdef CROSSCLR_DSL_MINIMAL   // tuning builds (tools/build_variant.py): only the headline instantiation is compiled
     if (p->Dpad != 512 || ks || mode != 0) return CROSSCLR_E_ARG;
-    if (xf) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
-    else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    CROSSCLR_FAST_LAUNCH((fast_bwd_xfp_kernel<32, false, 0, 1, 8>), grid, block, stream, xfo, st, sb, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps2, ks, kc);
     return CROSSCLR_OK;
 #else
-    if (xf) {
+#define CROSSCLR_LBP3(DK, SW, XP, TPRF, GRID)                                                                                                                                    \
+    do {                                                                                                                                                                         \
+        if (mode == 0) CROSSCLR_FAST_LAUNCH((fast_bwd_xfp_kernel<DK, SW, 0, XP, TPRF>), GRID, block, stream, xfo, st, sb, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps2, ks, kc);      \
+        else if (mode == 1) CROSSCLR_FAST_LAUNCH((fast_bwd_xfp_kernel<DK, SW, 1, XP, TPRF>), GRID, block, stream, xfo, st, sb, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps2, ks, kc); \
+        else CROSSCLR_FAST_LAUNCH((fast_bwd_xfp_kernel<DK, SW, 2, XP, TPRF>), GRID, block, stream, xfo, st, sb, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps2, ks, kc);                \
+    } while (0)
+#define CROSSCLR_LBP(DK, XP, TPRF, GRID) do { if (ks) CROSSCLR_LBP3(DK, true, XP, TPRF, GRID); else CROSSCLR_LBP3(DK, false, XP, TPRF, GRID); } while (0)
+    dim3 gridp2(2 * p->bpad / 128, p->bwd_slices, 2);
+    switch (p->Dpad) {
+        case 128: CROSSCLR_LBP(8, 1, 8, grid); break;
+        case 256: CROSSCLR_LBP(16, 1, 8, grid); break;
+        case 384: CROSSCLR_LBP(24, 1, 8, grid); break;
+        case 512: CROSSCLR_LBP(32, 1, 8, grid); break;
+        case 768: CROSSCLR_LBP(24, 2, 4, gridp2); break;      // two column parts of Dpad / 2 (blockIdx.z)
+        case 1024: CROSSCLR_LBP(32, 2, 4, gridp2); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LBP
+#undef CROSSCLR_LBP3
+    return CROSSCLR_OK;
+#endif
+}
+#endif   // CROSSCLR_DEF_SAVED_XFP
+
+// fast_bwd_dsl_kernel<..., XF>: local block, fragment-major operand, one tile per barrier interval
+#ifndef CROSSCLR_DEF_SAVED_XF1
+int launch_saved_xf1(const SavedLaunch& a);
+#else
+CROSSCLR_LEAF int launch_saved_xf1(const SavedLaunch& a) {
+    const crossclr_plan* p = a.p;
+    const Geo& g = a.g;
+    dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
+    void* stream = a.stream;
+    const bf16_t* c = (const bf16_t*)a.cols;
+    const unsigned char* st = (const unsigned char*)a.stash;
+    const float *rz = a.rz, *wrz = a.wrz, *rz_cols = a.rz_cols, *wrz_cols = a.wrz_cols, *ks = a.ks, *kc = a.kc;
+    float* gbuf = a.gbuf;
+    const int accumulate = a.accumulate, tps = a.tps;
+    (void)grid; (void)block; (void)stream; (void)c; (void)st; (void)rz; (void)wrz; (void)rz_cols; (void)wrz_cols; (void)kc; (void)gbuf; (void)accumulate; (void)tps;
+#ifdef CROSSCLR_DSL_MINIMAL
+    if (p->Dpad != 512 || ks) return CROSSCLR_E_ARG;
+    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    return CROSSCLR_OK;
+#else
 #define CROSSCLR_LBX2(DK) do { dim3 grid2(2 * p->bpad / 128, p->bwd_slices, 2);                                                                  \
                                if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, 2, 4, true>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
                                else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, 2, 4, true>), grid2, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
 #define CROSSCLR_LBX(DK) do { if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
                               else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, 1, 8, true>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
-        switch (p->Dpad) {
-            case 128: CROSSCLR_LBX(8); break;
-            case 256: CROSSCLR_LBX(16); break;
-            case 384: CROSSCLR_LBX(24); break;
-            case 512: CROSSCLR_LBX(32); break;
-            case 768: CROSSCLR_LBX2(24); break;      // two column parts of Dpad / 2 (blockIdx.z), like the LDS-staged launch
-            case 1024: CROSSCLR_LBX2(32); break;
-            default: return CROSSCLR_E_ARG;
-        }
+    switch (p->Dpad) {
+        case 128: CROSSCLR_LBX(8); break;
+        case 256: CROSSCLR_LBX(16); break;
+        case 384: CROSSCLR_LBX(24); break;
+        case 512: CROSSCLR_LBX(32); break;
+        case 768: CROSSCLR_LBX2(24); break;      // two column parts of Dpad / 2 (blockIdx.z), like the LDS-staged launch
+        case 1024: CROSSCLR_LBX2(32); break;
+        default: return CROSSCLR_E_ARG;
+    }
 #undef CROSSCLR_LBX
 #undef CROSSCLR_LBX2
-        return CROSSCLR_OK;
-    }
+    return CROSSCLR_OK;
+#endif
+}
+#endif   // CROSSCLR_DEF_SAVED_XF1
+
+// fast_bwd_dsl_kernel, column tiles staged through LDS: the local block (mode 0), rectangular blocks (1) and their transposes (2)
+#ifndef CROSSCLR_DEF_SAVED_LDS
+int launch_saved_lds(const SavedLaunch& a);
+#else
+CROSSCLR_LEAF int launch_saved_lds(const SavedLaunch& a) {
+    const crossclr_plan* p = a.p;
+    const Geo& g = a.g;
+    dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
+    void* stream = a.stream;
+    const bf16_t* c = (const bf16_t*)a.cols;
+    const unsigned char* st = (const unsigned char*)a.stash;
+    const float *rz = a.rz, *wrz = a.wrz, *rz_cols = a.rz_cols, *wrz_cols = a.wrz_cols, *ks = a.ks, *kc = a.kc;
+    float* gbuf = a.gbuf;
+    const int accumulate = a.accumulate, tps = a.tps, mode = a.mode;
+    (void)grid; (void)block; (void)stream; (void)c; (void)st; (void)rz; (void)wrz; (void)rz_cols; (void)wrz_cols; (void)kc; (void)gbuf; (void)accumulate; (void)tps; (void)mode;
+#ifdef CROSSCLR_DSL_MINIMAL
+    if (p->Dpad != 512 || ks || mode != 0) return CROSSCLR_E_ARG;
+    CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<32, false, 0>), grid, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);
+    return CROSSCLR_OK;
+#else
 #define CROSSCLR_LB3(DK, SW, XP, TPRF, GRID)                                                                                                   \
     do {                                                                                                                                        \
         if (mode == 0) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 0, XP, TPRF>), GRID, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc);      \
@@ -929,11 +1034,48 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
     return CROSSCLR_OK;
 #endif
 }
+#endif   // CROSSCLR_DEF_SAVED_LDS
+
+// mode 0 / 1 / 2: the LDS-staged kernel on the row-major operand -- the local symmetric block, a rectangular block, the transpose of one
+// rectangular block.  mode 3: mode 0 on the fragment-major operand, one tile per barrier interval.  mode 4 / 5 / 6: modes 0 / 1 / 2 on the
+// fragment-major operand with the pair kernel (crossclr_kernels_dslp.h; stash below 4 GiB: 32-bit scalar offsets, even slices).
+static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, const void* cols, const void* stash, const float* rz,
+                                      const float* wrz, const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate,
+                                      const float* ks, const float* kc, int mode, void* stream) {
+    const bool xfp = mode >= 4;
+    const bool xf = mode == 3 || xfp;
+    if (xfp) mode -= 4;
+    if (mode == 3) mode = 0;
+    const bool rect = mode == 1;
+    const bool skipping = rect && g.col_wrap == 0 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
+    const int per_rank = 2 * p->bpad / 32;
+    const int ntiles = (rect ? g.col_ranks - (skipping ? 1 : 0) : 1) * per_rank;
+    if (ntiles <= 0) return CROSSCLR_OK;
+    int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+    // every slice holds an EVEN number of tiles (the pair kernel needs it; the other kernels take the same cut so that all of them
+    // produce the same bits slice by slice)
+    tps = (tps + 1) & ~1;
+    SavedLaunch a = {p, g, cols, stash, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, ks, kc, mode, tps, stream, 0};
+    if (xfp) {
+        // the saved exponentials are addressed with 32-bit scalar offsets: local triangle / [row group][usable tile] / [row group][segments x tile]
+        a.stash_bytes = mode == 0 ? p->stash_bytes
+                                  : (size_t)per_rank * (size_t)(mode == 1 ? ntiles : g.col_ranks * per_rank) * 2048;
+        if (a.stash_bytes >= ((size_t)1 << 32)) return CROSSCLR_E_ARG;
+        return launch_saved_xfp(a);
+    }
+    return xf ? launch_saved_xf1(a) : launch_saved_lds(a);
+}
 // which backward the fast path uses: 16-row wavefronts (rows per block 128 at Dpad <= 512, 64 above) or the
 // 32-row kernel (Dpad <= 512 only)
 static inline int fast_bwd_rows_per_block(int Dpad, int use16) { return use16 ? (Dpad <= 512 ? 128 : 64) : 128; }
 
-static inline int fast_backward16(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
+#ifndef CROSSCLR_DEF_RECOMP
+int fast_backward16(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, const float* rz_rows, const float* wrz_rows,
+                    const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate, const float* krows, const float* kcols, void* stream);
+int fast_backward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols, const float* rz_rows, const float* wrz_rows,
+                  const float* rz_cols, const float* wrz_cols, float* gbuf, int accumulate, const float* krows, const float* kcols, void* stream);
+#else
+CROSSCLR_LEAF int fast_backward16(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                                   const float* rz_rows, const float* wrz_rows, const float* rz_cols,
                                   const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
                                   const float* kcols, void* stream) {
@@ -965,7 +1107,7 @@ static inline int fast_backward16(const crossclr_plan* p, const Geo& g, const vo
     return CROSSCLR_OK;
 }
 
-static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
+CROSSCLR_LEAF int fast_backward(const crossclr_plan* p, const Geo& g, const void* rows, const void* cols,
                                 const float* rz_rows, const float* wrz_rows, const float* rz_cols,
                                 const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
                                 const float* kcols, void* stream) {
@@ -991,6 +1133,7 @@ static inline int fast_backward(const crossclr_plan* p, const Geo& g, const void
 #undef CROSSCLR_L32
     return CROSSCLR_OK;
 }
+#endif   // CROSSCLR_DEF_RECOMP
 
 #endif  // CROSSCLR_KERNELS_ONLY
 

@@ -232,6 +232,30 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
     }
 }
 
+// K0y: the fragment-major copy of operands that are ALREADY packed (row-major bf16 [rows][Dpad], rows a multiple of 32): what a rank does
+// with the slices it RECEIVED from other ranks, so that the saved backwards of remote blocks can load their column tiles as MFMA B
+// fragments too (a gathered operand travels once, row-major; the second layout is made where it is needed).  A block = one tile of 32
+// rows: through LDS once, out as 16-byte chunks (same map as normalize_xf_kernel).  HBM-bound: reads and writes the operand once.
+__global__ void __launch_bounds__(256) xf_from_packed_kernel(const bf16_t* X, unsigned char* XF, int Dpad) {
+    CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[32][1024 + 8];     // (+8: rows 16 bytes apart in the bank map)
+    const size_t u = blockIdx.x;
+    const bf16_t* src = X + u * 32 * (size_t)Dpad;
+    const int chunks = Dpad / 8;                    // 16-byte pieces per row
+    for (int c = threadIdx.x; c < 32 * chunks; c += 256) {
+        const int r = c / chunks, k = c - r * chunks;
+        *reinterpret_cast<u32x4*>(&sh[r][8 * k]) = *reinterpret_cast<const u32x4*>(src + (size_t)r * Dpad + 8 * k);
+    }
+    __syncthreads();
+    const int nfr = Dpad / 32;
+    for (int c = threadIdx.x; c < 4 * Dpad; c += 256) {      // (ks, h, column d) -> one 16-byte chunk of the copy
+        const int ks = c / (2 * Dpad), rest = c - ks * 2 * Dpad, h = rest / Dpad, d = rest - h * Dpad;
+        struct { bf16_t e[8]; } v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = sh[16 * ks + 8 * (e >> 2) + 4 * h + (e & 3)][d];
+        *reinterpret_cast<u32x4*>(XF + ((u * nfr + (d >> 5)) * 2 + ks) * 1024 + (32 * h + (d & 31)) * 16) = __builtin_bit_cast(u32x4, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: forward denominators, generic tiled version.
 //   block = 256 threads (4 waves as 2x2), tile = 128 rows x 128 columns, K-chunks of 128 bytes.

@@ -90,11 +90,11 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf")
+                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf", "xf_all")
 
 
 _plan_cache: dict = {}
-_checked_shapes: set = set()
+_checked_shapes: dict = {}
 
 
 def _plan_for(b: int, D: int, world: int, rank: int, mode: int):
@@ -110,20 +110,35 @@ def _plan_for(b: int, D: int, world: int, rank: int, mode: int):
     return plan
 
 
-def _check_equal_rows_per_rank(b: int, D: int, group, dev) -> None:
+def _check_equal_rows_per_rank(b: int, D: int, group, dev, stash_bytes: int = 0) -> bool:
     """Every rank must bring the same [b, D] (the gathered operand is world x one rank's packed operand).  A mismatch would
-    otherwise surface as a hang or an opaque error inside all_gather_into_tensor; checked once per (group, shape)."""
+    otherwise surface as a hang or an opaque error inside all_gather_into_tensor; checked once per (group, shape).
+
+    The same all-reduce settles whether EVERY rank can hold `stash_bytes` of saved exponentials (a trial allocation): the
+    partner-gradient scheme ships blocks' transposed contributions instead of letting the partner recompute them, so a rank that could
+    not allocate its stash would raise while its peers sit in a collective.  Returns that agreement (rank-invariant)."""
     import torch.distributed as dist
-    key = (id(group), b, D)
-    if key in _checked_shapes:
-        return
-    t = torch.tensor([b, -b, D, -D], dtype=torch.int64, device=dev)
+    key = (id(group), b, D, stash_bytes)
+    got = _checked_shapes.get(key)
+    if got is not None:
+        return got
+    ok = 1
+    if stash_bytes > 0:
+        try:
+            trial = torch.empty(stash_bytes, dtype=torch.uint8, device=dev)
+            del trial
+        except torch.OutOfMemoryError:
+            ok = 0
+    t = torch.tensor([b, -b, D, -D, -ok], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     lo_b, hi_b, lo_d, hi_d = -int(t[1]), int(t[0]), -int(t[3]), int(t[2])
     if lo_b != hi_b or lo_d != hi_d:
         raise RuntimeError(f"CrossCLR (sharded): every rank must pass the same number of rows and columns; this rank has "
                            f"[{b}, {D}] but the group spans [{lo_b}..{hi_b}, {lo_d}..{hi_d}]")
-    _checked_shapes.add(key)
+    if len(_checked_shapes) > 64:
+        _checked_shapes.clear()
+    all_ok = _checked_shapes[key] = int(t[4]) == -1
+    return all_ok
 
 
 _last_exchange_mode = None    # what the most recent sharded forward used ("allgather" | "p2p" | "p2p_each"): read by bench.py
@@ -241,14 +256,14 @@ class _OperandExchange:
             _traced_wait("operands:peer", self._peer.pop(r))
 
 
-# the pairs scheme's column-sum exchange: (device, world, rank, n2, npairs) -> (outbox, inbox, send / receive split sizes); the
-# buffers are reused from step to step (a step's all-to-all has completed -- on the compute stream's order -- before the next
-# step's kernels overwrite the outbox)
+# the pairs scheme's column-sum exchange: (device, process group, stream, world, rank, n2, npairs) -> (outbox, inbox, send / receive split
+# sizes); the buffers are reused from step to step (a step's all-to-all has completed -- on the compute stream's order -- before the next
+# step's kernels overwrite the outbox).  Keyed by group AND stream: two criteria on two streams, or on two process groups, never share them.
 _pair_buffers: dict = {}
 
 
-def _pair_exchange_buffers(dev, world, rank, n2, npairs):
-    key = (str(dev), world, rank, n2, npairs)
+def _pair_exchange_buffers(dev, group, stream, world, rank, n2, npairs):
+    key = (str(dev), id(group), int(stream), world, rank, n2, npairs)
     got = _pair_buffers.get(key)
     if got is None:
         if len(_pair_buffers) > 16:
@@ -264,6 +279,47 @@ def _pair_exchange_buffers(dev, world, rank, n2, npairs):
         inbox = torch.empty(npairs, n2, dtype=torch.float32, device=dev)
         got = _pair_buffers[key] = (outbox, inbox, in_split, out_split, {r: i for i, r in enumerate(send_to)})
     return got
+
+
+# partner gradients: (outgoing [npairs, 2 bpad Dpad], incoming the same, one gradient-slice scratch) per (device, group, stream, shape),
+# reused from step to step like the column-sum buffers (the step's all-to-all is waited for before its backward ends)
+_partner_buffers: dict = {}
+
+
+def _partner_gradient_buffers(dev, group, stream, npairs, nel, gbuf_floats):
+    key = (str(dev), id(group), int(stream), npairs, nel, gbuf_floats)
+    got = _partner_buffers.get(key)
+    if got is None:
+        if len(_partner_buffers) > 8:
+            _partner_buffers.clear()
+        got = _partner_buffers[key] = (torch.empty(npairs, nel, dtype=torch.float32, device=dev),
+                                       torch.empty(npairs, nel, dtype=torch.float32, device=dev),
+                                       torch.empty(gbuf_floats, dtype=torch.float32, device=dev))
+    return got
+
+
+# How the packed operands travel when nothing is said (CROSSCLR_EXCHANGE unset): from 3 ranks on -- where the pair scheme applies and a
+# rank's forward touches only the K ranks after it and the antipode -- the need-ordered point-to-point form ("p2p": 4 of 7 slices on the
+# forward's critical path at 8 ranks, every xGMI link busy at once; with partner gradients the other 3 are never requested), otherwise one
+# all-gather.  `bench.py --gpus N` measures all three forms back to back on the node it runs on (set_exchange_for_benchmark).
+_exchange_override = None
+
+
+def set_exchange_for_benchmark(mode):
+    """bench.py: force "allgather" / "p2p" / "p2p_each" for the following steps (None: back to the default rule)."""
+    global _exchange_override
+    if mode not in (None, "allgather", "p2p", "p2p_each"):
+        raise ValueError(mode)
+    _exchange_override = mode
+
+
+def _exchange_mode(world: int, pairs_apply: bool) -> str:
+    if _exchange_override is not None:
+        return _exchange_override
+    e = os.environ.get("CROSSCLR_EXCHANGE")
+    if e in ("allgather", "p2p", "p2p_each"):
+        return e
+    return "p2p" if (world >= 3 and pairs_apply) else "allgather"
 
 
 class _Range:
@@ -323,40 +379,99 @@ _MAX_STASH_BYTES = int(float(os.environ.get("CROSSCLR_MAX_STASH_GB", "8")) * (1 
 _XF_WIDTHS_DEFAULT = frozenset((512, 768, 1024))
 
 
-# The fragment-major backward moves its column tiles with hand-counted inline-asm loads, and two schedules of it that compiled and
-# audited clean were wrong on the hardware.  The committed one is soaked per instantiation -- with THIS compiler.  So the
-# module does not take a library's word for it: the first step of a process at each kernel instantiation (padded width, sample
-# weights) runs BOTH saved backwards over the same stash and compares the gradient buffers bit for bit (one extra 0.3-ms launch and
-# one device synchronisation, once); a difference disables the fragment-major path for the process with a warning, and that step
-# keeps the LDS-staged result.  Under HIP-graph capture (no synchronisation possible) an unverified instantiation takes the LDS-staged
-# kernel.  The tests' injected build (host emulation: no such hazard exists there) skips the check.
+# The fragment-major backwards move their column tiles with hand-counted inline-asm loads, and two schedules of that idea that compiled
+# and audited clean were wrong on the hardware.  The committed ones are soaked per instantiation (tools/soak_xf.py) -- with
+# THIS compiler; a compiler upgrade means re-running that soak.  The module does not take a library's word for it either: before a
+# process takes one of them at a kernel instantiation (device, padded width, sample weights, library) it runs a SELF-TEST outside
+# any training step -- synthetic batches of 640 and 1152 rows (mirrored and direct tiles, both loop phases, an odd and an even number
+# of 256-row blocks), forward + finish, then the candidate against the LDS-staged kernel over the same saved exponentials, several launches each,
+# gradient buffers compared bit for bit (a few milliseconds, once).  A difference disables the candidate for the process with a warning
+# (crossclr_backward_saved_xfp falls back to crossclr_backward_saved_xf, that one to the LDS-staged kernel).  Under HIP-graph capture
+# nothing can be verified: an unverified instantiation then takes the LDS-staged kernel.  CROSSCLR_XF_RECHECK_STEPS=N repeats the
+# self-test every N backward launches of an instantiation (default 0: never).  The tests' injected build (host emulation: no such
+# hazard exists there) skips the check.
 _xf_verified: dict = {}
+_xf_launches: dict = {}
+_XF_RECHECK = int(os.environ.get("CROSSCLR_XF_RECHECK_STEPS", "0") or 0)
+_XF_SELFTEST_ROWS = (640, 1152)
 
 
-def _saved_backward_kernel(ws, plan, lib, pp, gbuf, stream, dev) -> str:
-    """"xf" / "lds": launch that saved backward; "done": the one-time comparison just ran and gbuf already holds this step's result."""
-    key = (plan.Dpad, ws.k_rows is not None, nat.library_path())
-    ok = _xf_verified.get(key)
-    if ok is not None:
-        return "xf" if ok else "lds"
-    if nat.injected_for_testing():
-        _xf_verified[key] = True
-        return "xf"
-    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
-        return "lds"
-    sw = _sw(ws.k_rows, ws.k_rows, None)
-    other = torch.empty_like(gbuf)
-    nat.check(lib.crossclr_backward_saved_xf(pp, _ptr(ws.xf), _ptr(ws.stash), ws.temperature, ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), sw,
-                                             _ptr(other), 0, stream))
-    nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz), sw,
-                                          _ptr(gbuf), 0, stream))
-    same = bool(torch.equal(other, gbuf))
-    _xf_verified[key] = same
-    if not same:
-        import warnings
-        warnings.warn("CrossCLR: the fragment-major saved backward (crossclr_backward_saved_xf) disagrees with the LDS-staged kernel on this "
-                      f"device / build at Dpad = {plan.Dpad}; it is disabled for this process (tools/soak_xf.py reproduces the comparison)")
-    return "done"       # gbuf holds the LDS-staged result of this step (bit-identical to the other one when they agree)
+def _xf_selftest(dev, D: int, weighted: bool, entry_name: str, launches: int = 3) -> bool:
+    """True when `entry_name` (a fragment-major saved backward) reproduces crossclr_backward_saved bit for bit on this device."""
+    lib = nat.library()
+    cand = getattr(lib, entry_name)
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    ok = True
+    for b in _XF_SELFTEST_ROWS:
+        plan = nat.make_plan(b, D, 1, 0, nat.MODE_BF16)
+        if not (plan.stash_bytes > 0 and plan.xf_bytes > 0):
+            return False
+        pp = ctypes.byref(plan)
+        g = torch.Generator().manual_seed(1000 + b)
+        # aligned pairs (t = v + noise): a soft-max that is neither flat nor one-hot, so every tile carries weights of mixed magnitude
+        v = torch.randn(b, D, generator=g)
+        t = (v + 0.5 * torch.randn(b, D, generator=g)).to(dev)
+        v = v.to(dev)
+        n2 = 2 * plan.bpad
+        f32 = dict(dtype=torch.float32, device=dev)
+        xhat = torch.empty(plan.operand_bytes, dtype=torch.uint8, device=dev)
+        xf = torch.empty(plan.xf_bytes, dtype=torch.uint8, device=dev)
+        inv_norm, diag = torch.empty(n2, **f32), torch.empty(plan.bpad, **f32)
+        logz, rz, wrz = torch.empty(n2, **f32), torch.empty(n2, **f32), torch.empty(n2, **f32)
+        part = torch.empty(plan.fwd_ws_floats, **f32)
+        loss_sum = torch.empty(max(2, plan.loss_ws_doubles), dtype=torch.float64, device=dev)
+        stash = torch.empty(plan.stash_bytes, dtype=torch.uint8, device=dev)
+        k = None
+        if weighted:
+            k = torch.zeros(2, plan.bpad, **f32)
+            k[:, :b] = (torch.rand(2, b, generator=g) > 0.3).float().to(dev)
+            k = k.view(-1)
+        sw = _sw(k, k, None)
+        nat.check(lib.crossclr_normalize_xf(pp, _ptr(v), _ptr(t), v.stride(0), t.stride(0), nat.IN_F32, _ptr(xhat), _ptr(xf), _ptr(inv_norm),
+                                            _ptr(diag), stream))
+        nat.check(lib.crossclr_forward_save(pp, _ptr(xhat), 0.05, 0.8, sw, _ptr(part), 0, _ptr(stash), stream))
+        nat.check(lib.crossclr_forward_finish_w(pp, _ptr(part), plan.fwd_slots, _ptr(diag), 0.05, 0.8, sw, _ptr(logz), _ptr(rz), _ptr(wrz),
+                                                _ptr(loss_sum), stream))
+        want = torch.empty(plan.gbuf_bytes // 4, **f32)
+        nat.check(lib.crossclr_backward_saved(pp, _ptr(xhat), _ptr(stash), 0.05, 0.8, _ptr(rz), _ptr(wrz), sw, _ptr(want), 0, stream))
+        for _ in range(launches):
+            got = torch.full_like(want, float("nan"))
+            nat.check(cand(pp, _ptr(xf), _ptr(stash), 0.05, 0.8, _ptr(rz), _ptr(wrz), sw, _ptr(got), 0, stream))
+            ok = ok and bool(torch.equal(got, want))
+    return ok
+
+
+def _saved_backward_entry(ws, plan, dev) -> str:
+    """Which saved backward of the local block this step launches: "crossclr_backward_saved_xfp" (pairs of tiles per barrier),
+    "crossclr_backward_saved_xf", or "crossclr_backward_saved" (column tiles staged through LDS; reads the row-major operand)."""
+    if ws.xf is None:
+        return "crossclr_backward_saved"
+    weighted = ws.k_rows is not None
+    cands = ["crossclr_backward_saved_xf"]
+    if plan.stash_bytes < (1 << 32) and os.environ.get("CROSSCLR_XFP", "1") != "0":
+        cands.insert(0, "crossclr_backward_saved_xfp")
+    for name in cands:
+        key = (str(dev), plan.Dpad, weighted, name, nat.library_path())
+        ok = _xf_verified.get(key)
+        if ok and _XF_RECHECK > 0:
+            n = _xf_launches[key] = _xf_launches.get(key, 0) + 1
+            if n % _XF_RECHECK == 0 and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                ok = None
+        if ok is None:
+            if nat.injected_for_testing():
+                ok = True
+            elif dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return "crossclr_backward_saved"          # nothing can be verified inside a capture
+            else:
+                ok = _xf_selftest(dev, plan.D, weighted, name)
+                if not ok:
+                    import warnings
+                    warnings.warn(f"CrossCLR: {name} disagrees with the LDS-staged saved backward on this device / build at Dpad = {plan.Dpad}; "
+                                  "it is disabled for this process (tools/soak_xf.py reproduces the comparison)")
+            _xf_verified[key] = ok
+        if ok:
+            return name
+    return "crossclr_backward_saved"
 
 
 def _use_xf(plan) -> bool:
@@ -404,8 +519,15 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     small_tau = bool(lib.crossclr_needs_row_shift(float(temperature), float(negative_w)))
     mode = _resolve_mode(compute_mode, b * world, video.dtype, small_tau)
     plan = _plan_for(b, D, world, rank, mode)
+    stash_everywhere = True
     if world > 1:
-        _check_equal_rows_per_rank(b, D, group, dev)
+        # (what a rank of the pair scheme keeps alive between forward and backward: the local stash and one rectangular stash per block
+        #  it evaluates itself -- K pair partners and the antipode)
+        need = 0
+        if save_for_backward and plan.stash_bytes > 0 and plan.fast_path == 1:
+            nblocks = (world - 1) // 2 + (1 if world % 2 == 0 else 0)
+            need = int(plan.stash_bytes + nblocks * lib.crossclr_rect_stash_bytes(ctypes.byref(plan), 1))
+        stash_everywhere = _check_equal_rows_per_rank(b, D, group, dev, need)
     stream = _stream_for(video)
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -440,7 +562,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.k_cols = ws.k_rows
 
     ws.prenormalized = bool(prenormalized) or project is not None
-    ws.xf = None
+    ws.xf = ws.xf_all = None
     if project is not None:
         if plan.fast_path != 1 or plan.Dpad > 512 or mode != nat.MODE_BF16:
             raise RuntimeError("the fused projection needs the bf16 register-resident path (embed_dim <= 512)")
@@ -472,12 +594,12 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         # Partner gradients (default with the pair scheme and a backward to follow): the rank that evaluated a pair block also forms
         # that block's contribution to its partner's gradient from the saved exponentials and ships it, instead of the partner
         # recomputing the block.  Decided from rank-invariant facts only (every rank must agree on what travels).
-        partner_possible = (save_for_backward and world >= 3 and plan.fast_path == 1 and plan.stash_bytes > 0 and not small_tau and
+        partner_possible = (save_for_backward and world >= 3 and plan.fast_path == 1 and plan.stash_bytes > 0 and not small_tau and stash_everywhere and
                             os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1" and os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1" and
                             os.environ.get("CROSSCLR_PARTNER_GRADS", "1") != "0" and lib.crossclr_rect_stash_bytes(pp, 1) > 0)
-        xmode = os.environ.get("CROSSCLR_EXCHANGE", "allgather")
-        if (xmode in ("p2p", "p2p_each") and world >= 3 and plan.fast_path == 1 and not small_tau and
-                os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1"):
+        pairs_apply = world >= 3 and plan.fast_path == 1 and not small_tau and os.environ.get("CROSSCLR_DISABLE_PAIR_FORWARD") != "1"
+        xmode = _exchange_mode(world, pairs_apply)
+        if xmode in ("p2p", "p2p_each") and pairs_apply:
             first_peers = [(rank + 1 + k) % world for k in range((world - 1) // 2)]     # in the order the forward needs them
             if world % 2 == 0:
                 first_peers.append((rank + world // 2) % world)
@@ -503,7 +625,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     # generic tiled kernels do the rest (no symmetric evaluation, no pair scheme, no save-for-backward in this regime).
     ws.shift = ws.shift_cols = None
     if lib.crossclr_needs_row_shift(ws.temperature, ws.negative_w):
-        return _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev, save_for_backward)
+        return _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev, save_for_backward, k_cols_ready)
     # Local (symmetric) block.  When a backward will follow and the plan offers it, the forward also saves its bf16
     # exponentials (plan.stash_bytes, 0.27 GB at b = 8192) so that the backward does not recompute the similarity
     # product -- the analogue of the reference's autograd-saved [B,2B] float64 tensors, 50x smaller.
@@ -541,7 +663,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         if save_remote:
             ws.saved_blocks, ws.recompute_ranges = [], []
         if npairs:
-            outbox, inbox, in_split, out_split, out_row = _pair_exchange_buffers(dev, world, rank, n2, npairs)
+            outbox, inbox, in_split, out_split, out_row = _pair_exchange_buffers(dev, group, stream, world, rank, n2, npairs)
         # One launch per peer when the operands arrive peer by peer (p2p_each) and the workspace has a launch group for each
         # (local + peers + antipode + received <= 8); otherwise ONE launch over the whole pair range behind one wait.
         per_peer = npairs > 0 and gather.mode == "p2p_each" and npairs + 3 <= nat.LAUNCH_GROUPS
@@ -561,6 +683,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                 group_of += 1
         elif npairs:
             gather.wait_forward()   # (p2p: the peers this rank evaluates itself; all-gather: everything)
+            for peer in peers:      # (p2p_each beyond the workspace's launch groups: the slices arrive one by one, the launch needs all)
+                gather.wait_peer(peer)
             colsum = torch.empty(npairs * n2, **f32)
             if save_remote:
                 st = torch.empty(lib.crossclr_rect_stash_bytes(pp, npairs), dtype=torch.uint8, device=dev)
@@ -633,8 +757,10 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     return loss, ws
 
 
-def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev, needs_backward):
-    """Two-pass forward (include/crossclr.h, "two-pass soft-max"): row maxima, then sums relative to them."""
+def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev, needs_backward, k_cols_ready):
+    """Two-pass forward (include/crossclr.h, "two-pass soft-max"): row maxima, then sums relative to them.
+    k_cols_ready: waits for the asynchronous gather of the other ranks' negative scales (ws.k_cols) -- every launch over the
+    gathered operand reads them, here and in the backward (`gather.wait()` covers the operand exchange only)."""
     import torch.distributed as dist
     plan = ws.plan
     pp = ctypes.byref(plan)
@@ -647,6 +773,7 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
                                           stream))
     if ws.sharded:
         gather.wait()
+        k_cols_ready()
         nat.check(lib.crossclr_forward_rowmax(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(part),
                                               _ptr(ws.shift), 1, stream))
     # second pass over the local block; with a backward to follow (exact-fp32 plans) it also saves the exponentials relative to the
@@ -681,6 +808,19 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
     return loss, ws
 
 
+def _remote_xfp(ws, plan, lib, pp, dev) -> bool:
+    """Do the saved backwards of the REMOTE blocks (and the partner gradients) run the pair kernel on fragment-major operands?  Needs the
+    local fragment-major copy (ws.xf: the step took the fragment-major pair), the pair kernel verified on this device for the local
+    block, and a gathered operand / rectangular stashes below 4 GiB (32-bit offsets).  CROSSCLR_REMOTE_XFP=0 keeps the LDS-staged kernels."""
+    if ws.xf is None or os.environ.get("CROSSCLR_REMOTE_XFP", "1") == "0":
+        return False
+    if ws.world * plan.operand_bytes >= (1 << 32):
+        return False
+    if any(lib.crossclr_rect_stash_bytes(pp, n) >= (1 << 32) for _, n, _ in (ws.saved_blocks or [])):
+        return False
+    return _saved_backward_entry(ws, plan, dev) == "crossclr_backward_saved_xfp"
+
+
 def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad_out: torch.Tensor):
     lib = nat.library()
     plan = ws.plan
@@ -712,17 +852,13 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
                                               _sw(ws.k_rows, ws.k_cols, None), _ptr(ws.shift), _ptr(ws.shift_cols), _ptr(gbuf), 1, stream))
     elif ws.stash is not None:
         with _Range("crossclr.backward"):
-            which = _saved_backward_kernel(ws, plan, lib, pp, gbuf, stream, dev) if ws.xf is not None else "lds"
-            if which == "xf":
-                nat.check(lib.crossclr_backward_saved_xf(pp, _ptr(ws.xf), _ptr(ws.stash), ws.temperature, ws.negative_w,
-                                                         _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
-                                                         stream))
-            elif which == "lds":
-                nat.check(lib.crossclr_backward_saved(pp, _ptr(ws.xhat), _ptr(ws.stash), ws.temperature, ws.negative_w,
-                                                      _ptr(ws.rz), _ptr(ws.wrz), _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0,
-                                                      stream))
+            entry = _saved_backward_entry(ws, plan, dev)
+            operand = ws.xhat if entry == "crossclr_backward_saved" else ws.xf
+            nat.check(getattr(lib, entry)(pp, _ptr(operand), _ptr(ws.stash), ws.temperature, ws.negative_w, _ptr(ws.rz), _ptr(ws.wrz),
+                                          _sw(ws.k_rows, ws.k_rows, None), _ptr(gbuf), 0, stream))
         ws.stash = None   # consumed: give the 0.27 GB back to the allocator as soon as the launch is queued
-        ws.xf = None
+        if not (ws.sharded and ws.saved_blocks is not None):
+            ws.xf = None      # (a sharded step's partner gradients read it once more below)
     else:
         nat.check(lib.crossclr_backward_w(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, ws.temperature, ws.negative_w,
                                           _ptr(ws.rz), _ptr(ws.wrz), _ptr(rz_loc), _ptr(wrz_loc),
@@ -733,31 +869,42 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
             ws.wrz_cols = ws.rz_cols * ws.negative_w
         sw_all = _sw(ws.k_rows, ws.k_cols, None)
         partner_work = None
+        # remote blocks on the fragment-major operand: the slices this rank received are re-laid out HERE (the exchange moved the row-major
+        # operand once; crossclr_pack_xf_from_packed: the slices of the blocks this rank evaluated, ~40 us for 117 MB at 8 ranks), the
+        # transposes read this rank's own copy
+        remote_xfp = _remote_xfp(ws, plan, lib, pp, dev)
+        if remote_xfp:
+            ws.xf_all = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device=dev)
+            for first, n, _ in ws.saved_blocks:
+                runs = [(first, min(n, world - first))] + ([(0, n - (world - first))] if first + n > world else [])
+                for r0, cnt in runs:
+                    nat.check(lib.crossclr_pack_xf_from_packed(pp, ws.xcols.data_ptr() + r0 * plan.operand_bytes, cnt,
+                                                               ws.xf_all.data_ptr() + r0 * plan.operand_bytes, stream))
         if ws.partner_peers:
             # Pair blocks, the partner's half first (its transfer then hides behind this rank's own blocks): block (r, s) transposed,
             # from the exponentials saved for it -> [2 bpad, Dpad] fp32 per partner, shipped with one all-to-all.
             import torch.distributed as dist
             n2, npairs = 2 * plan.bpad, len(ws.partner_peers)
             nel = n2 * plan.Dpad
-            _, _, in_split, out_split, out_row = _pair_exchange_buffers(dev, world, rank, n2, npairs)
-            outg = torch.empty(npairs, nel, dtype=torch.float32, device=dev)
-            ing = torch.empty(npairs, nel, dtype=torch.float32, device=dev)
-            tmp = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
+            _, _, in_split, out_split, out_row = _pair_exchange_buffers(dev, ws.group, stream, world, rank, n2, npairs)
+            outg, ing, tmp = _partner_gradient_buffers(dev, ws.group, stream, npairs, nel, plan.gbuf_bytes // 4)
             for first, n, st in ws.saved_blocks:
                 for which in range(n):
                     peer = (first + which) % world
                     if peer not in out_row or peer not in ws.partner_peers:
                         continue                                # (the antipodal block: both sides own their rows)
-                    nat.check(lib.crossclr_backward_rect_saved_t(pp, _ptr(ws.xhat), _ptr(st), first, n, which, ws.temperature, ws.negative_w,
-                                                                 _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
-                                                                 _ptr(tmp), stream))
+                    entry_t, operand_t = ((lib.crossclr_backward_rect_saved_t_xfp, ws.xf) if remote_xfp else
+                                          (lib.crossclr_backward_rect_saved_t, ws.xhat))
+                    nat.check(entry_t(pp, _ptr(operand_t), _ptr(st), first, n, which, ws.temperature, ws.negative_w,
+                                      _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all, _ptr(tmp), stream))
                     torch.sum(tmp.view(-1, nel), 0, out=outg[out_row[peer]])      # the column slices, in index order
             partner_work = dist.all_to_all_single(ing.view(-1), outg.view(-1), output_split_sizes=[x * plan.Dpad for x in out_split],
                                                   input_split_sizes=[x * plan.Dpad for x in in_split], group=ws.group, async_op=True)
         for first, n, st in ws.saved_blocks:        # blocks this rank evaluated in the forward: from their saved exponentials
-            nat.check(lib.crossclr_backward_rect_saved(pp, _ptr(ws.xcols), _ptr(st), first, n, ws.temperature, ws.negative_w,
-                                                       _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all,
-                                                       _ptr(gbuf), 1, stream))
+            entry_r, operand_r = ((lib.crossclr_backward_rect_saved_xfp, ws.xf_all) if remote_xfp else
+                                  (lib.crossclr_backward_rect_saved, ws.xcols))
+            nat.check(entry_r(pp, _ptr(operand_r), _ptr(st), first, n, ws.temperature, ws.negative_w,
+                              _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols), sw_all, _ptr(gbuf), 1, stream))
         if ws.recompute_ranges:
             ws.exchange.wait()                      # (point-to-point exchange: the slices only this recompute needs)
         for first, n in ws.recompute_ranges:        # blocks the other side of a pair evaluated: recompute
@@ -770,6 +917,7 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
             for k in range(npairs):          # fixed order over the source ranks: deterministic
                 g0 += ing[k]
         ws.saved_blocks = None
+        ws.xf = ws.xf_all = None
     elif ws.sharded and ws.shift is None:
         if ws.wrz_cols is None:
             _traced_wait("statistics", [ws.stats_work])

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define CROSSCLR_LAUNCH_GROUPS 8   /* launch groups the forward workspace has room for */
-#define CROSSCLR_ABI_VERSION 4
+#define CROSSCLR_ABI_VERSION 5
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
 #define CROSSCLR_IN_F32 0
@@ -223,6 +223,12 @@ int crossclr_pack_xf(const crossclr_plan* plan, const void* video_hat, const voi
 int crossclr_backward_saved_xf(const crossclr_plan* plan, const void* xhat_xf, const void* stash,
                                float temperature, float negative_weight, const float* rz, const float* wrz,
                                const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+/* The same backward -- same arguments, the same bits in `gbuf` -- with TWO 32-column tiles per barrier interval
+ * (fast_bwd_xfp_kernel: one barrier, one closing wait and one set of cursor updates per 64 MFMAs; 32-bit scalar offsets into the
+ * saved exponentials, hence plan->stash_bytes < 4 GiB -- CROSSCLR_E_ARG otherwise: take crossclr_backward_saved_xf).               */
+int crossclr_backward_saved_xfp(const crossclr_plan* plan, const void* xhat_xf, const void* stash,
+                               float temperature, float negative_weight, const float* rz, const float* wrz,
+                               const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
 /* Two-pass regime, save-for-backward pair (exact-fp32 plans, local block; ABI 3): the second pass also leaves
  * U[p][q] = exp2(x_pq - shift_p) and Ut[p][q] = U[q][p] behind (crossclr_stash_bytes_s = twice plan->stash_bytes, 0 = not
  * available), and the backward forms the weights U rz_p + Ut rz_q from them instead of recomputing the similarity product
@@ -266,6 +272,24 @@ int crossclr_backward_rect_saved_t(const crossclr_plan* plan, const void* xhat_r
                                    int which, float temperature, float negative_weight, const float* rz_rows, const float* wrz_rows,
                                    const float* rz_all, const float* wrz_all, const crossclr_sample_weights* sw, float* gpartner,
                                    void* stream);
+/* ---- remote blocks on the fragment-major operand (ABI version 5) --------------------------------------------------------------
+ * crossclr_pack_xf_from_packed: the fragment-major copy (layout: crossclr_normalize_xf) of `nranks` consecutive PACKED operands --
+ * what a rank does with the slices of the gathered operand it received (the exchange moves the row-major operand only).
+ * crossclr_backward_rect_saved_xfp / _t_xfp: crossclr_backward_rect_saved / _t with the pair kernel (fast_bwd_xfp_kernel: column tiles
+ * as MFMA B fragments straight from that copy, two tiles per barrier interval); same arguments except the operand -- the copy of the
+ * WHOLE gathered array (only the slices of first_rank .. first_rank+nranks-1 are read) resp. of this rank's own operand -- and the same
+ * gradients within the summation order of the slices (the pair kernel cuts even slices).  CROSSCLR_E_ARG for operands / stashes of
+ * 4 GiB or more (32-bit offsets): take the LDS-staged entry points then.                                                         */
+int crossclr_pack_xf_from_packed(const crossclr_plan* plan, const void* xhat_packed, int nranks, void* xhat_xf, void* stream);
+int crossclr_backward_rect_saved_xfp(const crossclr_plan* plan, const void* xf_all, const void* stash, int first_rank, int nranks,
+                                     float temperature, float negative_weight, const float* rz_rows, const float* wrz_rows,
+                                     const float* rz_all, const float* wrz_all, const crossclr_sample_weights* sw, float* gbuf,
+                                     int accumulate, void* stream);
+int crossclr_backward_rect_saved_t_xfp(const crossclr_plan* plan, const void* xf_rows, const void* stash, int first_rank, int nranks,
+                                       int which, float temperature, float negative_weight, const float* rz_rows, const float* wrz_rows,
+                                       const float* rz_all, const float* wrz_all, const crossclr_sample_weights* sw, float* gpartner,
+                                       void* stream);
+
 int crossclr_backward_ranks(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
                             int first_rank, int nranks, float temperature, float negative_weight,
                             const float* rz_rows, const float* wrz_rows, const float* rz_all, const float* wrz_all,
@@ -386,6 +410,12 @@ int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* g
 /* Hardware assumption checks (MFMA fragment layouts, ds_read_b64_tr_b16 gather).  `out` is a
  * device buffer of at least 64 KiB; the caller compares it with the documented layouts.        */
 int crossclr_selftest(int which, const void* in, void* out, void* stream);
+
+/* Measurement aid (bench.py `roofline.sustained_mfma`; no reference counterpart): `blocks` x 4 waves x `iters` x 16
+ * v_mfma_f32_32x32x16_bf16 on 16 independent accumulators per wave and nothing else -- what the matrix pipe of THIS device
+ * sustains with toggling (pseudo-random) or all-zero operands.  `out`: device buffer of blocks * 256 floats (a checksum
+ * nobody reads).  flop per launch = blocks * 4 * iters * 16 * 32768.                                                     */
+int crossclr_mfma_sustained(float* out, int blocks, int iters, unsigned seed, int zero_operands, void* stream);
 
 #ifdef __cplusplus
 }

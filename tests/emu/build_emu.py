@@ -18,12 +18,26 @@ def sources():
            [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "emu_runtime.cpp")]
 
 
+UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_recomp.cpp"]
+
+
 def build(force=False):
+    """Six translation units in parallel, like the product build (crossmodal-contrastive-learning_amd/build.py, -DCROSSCLR_SPLIT)."""
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
-    cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DCROSSCLR_EMU", "-I", HERE, "-I", CSRC,
-           "-Wno-unused-value", "-Wno-psabi", os.path.join(CSRC, "crossclr_api.cpp"), os.path.join(HERE, "emu_runtime.cpp"), "-o", OUT]
-    subprocess.check_call(cmd)
+    import tempfile
+    common = [CLANG, "-O2", "-std=c++17", "-fPIC", "-pthread", "-DCROSSCLR_EMU", "-DCROSSCLR_SPLIT", "-I", HERE, "-I", CSRC,
+              "-Wno-unused-value", "-Wno-psabi"]
+    with tempfile.TemporaryDirectory(prefix="crossclr_emu_") as tmp:
+        procs = []
+        for u in UNITS + ["emu_runtime.cpp"]:
+            src = os.path.join(HERE if u == "emu_runtime.cpp" else CSRC, u)
+            obj = os.path.join(tmp, u.replace(".cpp", ".o"))
+            procs.append((u, obj, subprocess.Popen(common + ["-c", src, "-o", obj])))
+        failed = [u for u, _, p in procs if p.wait() != 0]
+        if failed:
+            raise subprocess.CalledProcessError(1, "clang++ -c " + " ".join(failed))
+        subprocess.check_call([CLANG, "-shared", "-fPIC", "-pthread"] + [obj for _, obj, _ in procs] + ["-o", OUT])
     return OUT
 
 

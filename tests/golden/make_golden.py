@@ -182,6 +182,12 @@ def main():
     metas.append(case("g6_aligned_b256_d128", "aligned", 256, 128, 13))
     metas.append(case("g6_tau0005_b2048_d512", "randn", 2048, 512, 16, tau=0.005, full=False))
     metas.append(case("g6_tau0002_cluster_b1024_d256", "cluster", 1024, 256, 17, tau=0.002, w=1.0, full=False))
+    # G9: the regime compute_mode="auto" resolves to bf16 in (global batch >= 1024) at temperatures between the two-pass threshold
+    # (0.0078) and the other goldens' 0.02: the logit carries the bf16 rounding of a cosine times 1/tau.  (No "aligned" case here: at
+    # these temperatures its reference loss is exactly 0.0 and its gradients ~1e-24 .. 1e-34 -- nothing a tolerance can be stated against.)
+    for tau, tag in ((0.01, "tau001"), (0.015, "tau0015")):
+        metas.append(case(f"g9_{tag}_b2048_d512", "randn", 2048, 512, 21, tau=tau, full=False))
+        metas.append(case(f"g9_{tag}_cluster_b2048_d512", "cluster", 2048, 512, 23, tau=tau, full=False))
     # G7: large
     if args.large:
         metas.append(case("g7_b4096_d512_s1234", "randn", 4096, 512, 1234, full=False))

@@ -30,6 +30,13 @@ template __global__ void fast_bwd_dsl_kernel<32, false, 0, 1, 8, true> BSIG;   /
 template __global__ void fast_bwd_dsl_kernel<8, true, 0, 1, 8, true> BSIG;     // XF, one fragment per wave, sample weights
 template __global__ void fast_bwd_dsl_kernel<24, false, 0, 1, 8, true> BSIG;
 template __global__ void fast_bwd_dsl_kernel<32, true, 0, 2, 4, true> BSIG;    // XF, two column parts (D = 1024), sample weights
+#define PSIG (const unsigned char*, const unsigned char*, unsigned, Geo, const float*, const float*, const float*, const float*, float*, int, int, const float*, const float*)
+template __global__ void fast_bwd_xfp_kernel<32, false, 0, 1, 8> PSIG;         // the pair kernel (two tiles per barrier interval): the headline backward
+template __global__ void fast_bwd_xfp_kernel<8, true, 0, 1, 8> PSIG;           // one fragment per wave, sample weights
+template __global__ void fast_bwd_xfp_kernel<24, false, 0, 1, 8> PSIG;
+template __global__ void fast_bwd_xfp_kernel<32, true, 0, 2, 4> PSIG;          // two column parts (D = 1024), sample weights
+template __global__ void fast_bwd_xfp_kernel<32, false, 1, 1, 8> PSIG;         // rectangular block (remote columns: reciprocal segment walk)
+template __global__ void fast_bwd_xfp_kernel<16, true, 2, 1, 8> PSIG;          // the transpose of a rectangular block (partner gradients)
 template __global__ void fast_fwd_pipe_kernel<8, 1, false, true> FSIG;
 template __global__ void fast_fwd_pipe_kernel<8, 3, true, true> FSIG;
 template __global__ void fast_fwd_pipe_kernel<32, 1, false, true> FSIG;  // the headline forward
@@ -42,13 +49,13 @@ template __global__ void fast_fwd_pipe_kernel<64, 2, false, true, 1> FSIG;
 def test_no_asm_loaded_register_is_read_before_its_wait(tmp_path):
     src, asm = tmp_path / "audit.hip", tmp_path / "audit.s"
     src.write_text(SRC)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S",
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S",
                            "-DCROSSCLR_KERNELS_ONLY", "-I", CSRC, str(src), "-o", str(asm)], stderr=subprocess.DEVNULL)
     text = asm.read_text()
     kernels = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", text, re.M)
-    assert len(kernels) == 14, kernels
+    assert len(kernels) == 20, kernels
     scratch = [int(x) for x in re.findall(r";\s*ScratchSize:\s*(\d+)", text)]
-    assert len(scratch) >= 14 and all(s == 0 for s in scratch), scratch
+    assert len(scratch) >= 20 and all(s == 0 for s in scratch), scratch
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py"), str(asm)], capture_output=True, text=True)
     assert r.returncode == 0 and "flagged: 0" in r.stdout, r.stdout[-2000:]
     # and the audit itself must be able to see the loads it is meant to guard

@@ -72,3 +72,19 @@ def test_bench_gpus8_selftest_with_the_per_peer_exchange():
     vs, ts = zip(*[orc.make_inputs("randn", 8, 16, 1234 + r) for r in range(8)])
     ref = float(orc.bf16_operand_model_loss(torch.cat(vs), torch.cat(ts), 0.03, 0.8))
     assert abs(out["loss"] - ref) < 5e-3 * max(1.0, abs(ref))
+
+
+def test_bench_gpus8_selftest_measures_the_three_exchanges():
+    """Without CROSSCLR_EXCHANGE the multi-rank bench runs its timed region once per way the operands can travel (all-gather, batched
+    point-to-point, per peer) and reports the table; `value` / `ms_per_step` are the fastest form's, which the per-rank block names."""
+    out = _run(["--gpus", "8", "--selftest-emu", "--rows", "8", "--dim", "16", "--steps", "1", "--warmup", "0", "--prewarm", "0",
+                "--mode", "bf16"], timeout=2400)
+    px = out["per_exchange"]
+    assert set(px) == {"allgather", "p2p", "p2p_each"} and sum(1 for v in px.values() if v["winner"]) == 1
+    best = next(k for k, v in px.items() if v["winner"])
+    assert abs(px[best]["ms_per_step"] - out["ms_per_step"]) <= 1e-3 * out["ms_per_step"] + 1e-4
+    assert all(px[best]["ms_per_step"] <= v["ms_per_step"] for v in px.values())
+    assert {r["exchange"] for r in out["per_rank"]} == {best}
+    vs, ts = zip(*[orc.make_inputs("randn", 8, 16, 1234 + r) for r in range(8)])
+    ref = float(orc.bf16_operand_model_loss(torch.cat(vs), torch.cat(ts), 0.03, 0.8))
+    assert abs(out["loss"] - ref) < 5e-3 * max(1.0, abs(ref))

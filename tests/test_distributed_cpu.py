@@ -30,6 +30,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         mode, *knobs = mode.split("+")
         if "p2p" in knobs:       # the need-ordered point-to-point operand exchange instead of the all-gather
             os.environ["CROSSCLR_EXCHANGE"] = "p2p"
+        if "allgather" in knobs:  # one all_gather_into_tensor (the default below 3 ranks; from 3 ranks on the default is "p2p")
+            os.environ["CROSSCLR_EXCHANGE"] = "allgather"
         if "each" in knobs:      # one send / receive pair per peer distance, one forward launch per pair partner as its slice lands
             os.environ["CROSSCLR_EXCHANGE"] = "p2p_each"
         if "nosave" in knobs:    # remote blocks recompute in the backward (reads EVERY rank's slice: also the late p2p ones)
@@ -41,8 +43,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         if "xf" in knobs:        # the LOCAL block on the fragment-major pair (crossclr_normalize_xf + crossclr_backward_saved_xf), which the
             os.environ["CROSSCLR_XF_WIDTHS"] = "128,256,384,512,768,1024"     # module's policy only takes from 2048 rows and D = 512 on
             calls = []
-            real = nat.library().crossclr_backward_saved_xf
-            nat.library().crossclr_backward_saved_xf = lambda *a: (calls.append(1), real(*a))[1]
+            real = nat.library().crossclr_backward_saved_xfp      # (the pair kernel: what the module takes for a stash below 4 GiB)
+            nat.library().crossclr_backward_saved_xfp = lambda *a: (calls.append(1), real(*a))[1]
         v, t = orc.make_inputs("randn", B, D, 77)
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
@@ -109,7 +111,14 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (3, 24, 530, "bf16+xf", 5e-3, 2e-2),
                                                        # 8 ranks (BASELINE configs 4 / 5's world size), tiny shapes: three pairs + the antipode
                                                        (8, 32, 16, "bf16", 5e-3, 2e-2),
-                                                       (8, 32, 16, "bf16+each", 5e-3, 2e-2)])
+                                                       (8, 32, 16, "bf16+each", 5e-3, 2e-2),
+                                                       # the all-gather where the default rule would take the point-to-point exchange
+                                                       (4, 24, 16, "bf16+allgather", 5e-3, 2e-2),
+                                                       (8, 32, 16, "bf16+allgather", 5e-3, 2e-2),
+                                                       # 13 ranks: six pair partners + local + received > the workspace's 8 launch groups, so
+                                                       # the per-peer exchange falls back to ONE launch over the pair range -- behind a wait
+                                                       # for EVERY peer's slice (round-3 advisor finding)
+                                                       (13, 26, 16, "bf16+each", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()

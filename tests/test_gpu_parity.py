@@ -97,6 +97,11 @@ def test_large_cases_sampled_rows(name, mode):
         pytest.skip("fp32 at B=8192 is covered by the forward-only test; keep the GPU suite short")
     v, t = golden_inputs(m)
     loss, gv, gt = run_module(v, t, m, mode)
+    if name == "g7_b8192_d512_s1234" and mode == "bf16":
+        # this case is what pins the fragment-major saved backwards to the REFERENCE's goldens (tests/test_gpu_xf.py compares them with
+        # the LDS-staged kernel only): make sure it really ran one of them -- the pair kernel unless the self-test rejected it
+        took = [k[3] for k, ok in L._xf_verified.items() if ok and k[1] == 512 and not k[2]]
+        assert "crossclr_backward_saved_xfp" in took or "crossclr_backward_saved_xf" in took, L._xf_verified
     small_tau = max(1.0, abs(m["negative_weight"])) / m["temperature"] > 128      # two-pass regime: "auto" computes in fp32 there
     exact = mode == "fp32" or (mode == "auto" and small_tau)
     # explicit bf16 at small temperatures: a bf16 cosine (2^-9) times 1/tau -- the bars are stated at tau = 0.03
@@ -583,14 +588,26 @@ def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, 
     lossN = (total / (2.0 * B)).item()
     gv, gt = torch.empty_like(vd), torch.empty_like(td)
     go = torch.ones(1, dtype=torch.float64, device="cuda")
+    # the same blocks through the pair kernel on fragment-major operands (crossclr_backward_rect_saved_xfp / _t_xfp): the copy is made from
+    # the PACKED slices (crossclr_pack_xf_from_packed -- what a rank does with the slices it received) and every launch must reproduce
+    # the LDS-staged kernel's gradient buffer BIT FOR BIT (same slices, same MFMA sequence per accumulator)
+    xfall = None
+    if pl.xf_bytes and world * pl.operand_bytes < (1 << 32):
+        xfall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device="cuda")
+        nat.check(lib.crossclr_pack_xf_from_packed(ctypes.byref(pl), p(xall), world, p(xfall), stream))
     for r in range(world):
         pp = ctypes.byref(plans[r])
         xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
         gbuf = torch.empty(pl.gbuf_bytes // 4, **f32)
         nat.check(lib.crossclr_backward_saved(pp, p(xr), p(stashes[r]), 0.03, 0.8, p(rz[r]), p(wrz[r]), sw(r, False, False), p(gbuf), 0, stream))
         for first, n, st in blocks[r]:
+            twin = gbuf.clone() if xfall is not None else None
             nat.check(lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, n, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
                                                        sw(r, True, False), p(gbuf), 1, stream))
+            if twin is not None and (r < 2 or B <= 8192):        # (every rank at the small shapes, two ranks of the big ones)
+                nat.check(lib.crossclr_backward_rect_saved_xfp(pp, p(xfall), p(st), first, n, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
+                                                               sw(r, True, False), p(twin), 1, stream))
+                assert torch.equal(twin, gbuf), (r, first, n)
         if K and partner:
             # partner gradients: rank s = r-1-k evaluated block (s, r) and forms its transposed contribution to r's buffer
             # (crossclr_backward_rect_saved_t, played here by the same GPU); r adds the column slices' sum
@@ -602,6 +619,12 @@ def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, 
                 tmp = torch.empty(pl.gbuf_bytes // 4, **f32)
                 nat.check(lib.crossclr_backward_rect_saved_t(ctypes.byref(plans[src]), p(xs), p(st), first, n, k, 0.03, 0.8, p(rz[src]),
                                                              p(wrz[src]), p(rz), p(wrz), sw(src, True, False), p(tmp), stream))
+                if xfall is not None and (r < 2 or B <= 8192):
+                    tmp2 = torch.full_like(tmp, float("nan"))
+                    xfs = xfall[src * pl.operand_bytes:(src + 1) * pl.operand_bytes]
+                    nat.check(lib.crossclr_backward_rect_saved_t_xfp(ctypes.byref(plans[src]), p(xfs), p(st), first, n, k, 0.03, 0.8, p(rz[src]),
+                                                                     p(wrz[src]), p(rz), p(wrz), sw(src, True, False), p(tmp2), stream))
+                    assert torch.equal(tmp2, tmp), (r, src, k)
                 gbuf[:nel] += tmp.view(-1, nel).sum(0)
         elif K:
             nat.check(lib.crossclr_backward_ranks(pp, p(xr), p(xall), (r - K) % world, K, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),

@@ -1,8 +1,10 @@
-"""The fragment-major saved backward on the MI355X (crossclr_normalize_xf -> crossclr_backward_saved_xf, include/crossclr.h ABI 4):
+"""The fragment-major saved backwards on the MI355X (crossclr_normalize_xf -> crossclr_backward_saved_xfp: two tiles per barrier interval,
+the kernel a training step runs; crossclr_backward_saved_xf: one tile per interval; include/crossclr.h ABI 5):
 the column tiles go from global memory straight into MFMA B fragments through inline-asm buffer loads whose completion is counted by
 hand (s_waitcnt vmcnt).  The host emulation cannot see a wrong count -- the hardware can: every accumulator receives the same MFMA
 sequence as in the LDS-staged kernel, so the two gradient buffers must agree BIT FOR BIT, launch after launch, for every DK
-instantiation, with mirrored and direct tiles, with and without sample weights."""
+instantiation, with mirrored and direct tiles, with and without sample weights.  (Against the REFERENCE these kernels are pinned by
+tests/test_gpu_parity.py::test_large_cases_sampled_rows, which asserts that it ran one of them.)"""
 import ctypes
 
 import pytest
@@ -43,16 +45,16 @@ def test_fragment_major_backward_equals_the_lds_staged_one_bit_for_bit(B, D, wei
     nat.check(lib.crossclr_backward_saved(pp, p(ws.xhat), p(ws.stash), ws.temperature, ws.negative_w, p(ws.rz), p(ws.wrz), sw, p(g_lds), 0, stream))
     torch.cuda.synchronize()
     assert torch.isfinite(g_lds).all()
-    for it in range(30 if B <= 4096 else 12):
-        g_xf = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
-        nat.check(lib.crossclr_backward_saved_xf(pp, p(ws.xf), p(ws.stash), ws.temperature, ws.negative_w, p(ws.rz), p(ws.wrz), sw, p(g_xf), 0,
-                                                 stream))
+    for entry in (lib.crossclr_backward_saved_xfp, lib.crossclr_backward_saved_xf):
+        for it in range(30 if B <= 4096 else 12):
+            g_xf = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+            nat.check(entry(pp, p(ws.xf), p(ws.stash), ws.temperature, ws.negative_w, p(ws.rz), p(ws.wrz), sw, p(g_xf), 0, stream))
+            torch.cuda.synchronize()
+            assert torch.equal(g_xf, g_lds), (it, (g_xf - g_lds).abs().max().item())
+        # accumulate = 1 adds on top of what is there
+        nat.check(entry(pp, p(ws.xf), p(ws.stash), ws.temperature, ws.negative_w, p(ws.rz), p(ws.wrz), sw, p(g_xf), 1, stream))
         torch.cuda.synchronize()
-        assert torch.equal(g_xf, g_lds), (it, (g_xf - g_lds).abs().max().item())
-    # accumulate = 1 adds on top of what is there
-    nat.check(lib.crossclr_backward_saved_xf(pp, p(ws.xf), p(ws.stash), ws.temperature, ws.negative_w, p(ws.rz), p(ws.wrz), sw, p(g_xf), 1, stream))
-    torch.cuda.synchronize()
-    assert torch.equal(g_xf, g_lds + g_lds)
+        assert torch.equal(g_xf, g_lds + g_lds)
 
 
 def test_the_fragment_major_copy_is_the_packed_operand_rearranged():
@@ -83,10 +85,11 @@ def test_the_fragment_major_copy_is_the_packed_operand_rearranged():
         assert torch.equal(xh2, ws.xhat) and torch.equal(inv, ws.inv_norm) and torch.equal(dg, ws.diag)
 
 
-def test_the_module_verifies_the_fragment_major_backward_once_per_process_and_falls_back(monkeypatch):
-    """loss._saved_backward_kernel: the first step at a kernel instantiation runs both saved backwards and compares them bit for bit;
-    agreement -> the fragment-major one from then on; a difference (simulated here by feeding it a zeroed operand copy) -> a warning, the
-    LDS-staged kernel for the rest of the process, and correct gradients on that very step."""
+def test_the_module_self_tests_the_fragment_major_backwards_and_falls_back(monkeypatch):
+    """loss._saved_backward_entry: before a process takes a fragment-major backward at a kernel instantiation it runs loss._xf_selftest
+    (synthetic batches, candidate vs LDS-staged kernel, bit for bit) -- outside the training step: the step itself launches ONE saved
+    backward.  Agreement -> the pair kernel from then on; a candidate that is wrong (simulated by feeding it a zeroed operand copy) -> a
+    warning and the next candidate: crossclr_backward_saved_xf, then the LDS-staged kernel; the gradients never change."""
     import warnings
     lib = nat.library()
     B, D = 2304, 512
@@ -97,25 +100,39 @@ def test_the_module_verifies_the_fragment_major_backward_once_per_process_and_fa
         v, t = v0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
         crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode="bf16").backward()
         return v.grad, t.grad
-    calls = {"xf": 0, "lds": 0}
-    real_xf, real_lds = lib.crossclr_backward_saved_xf, lib.crossclr_backward_saved
-    monkeypatch.setattr(lib, "crossclr_backward_saved_xf", lambda *a: (calls.__setitem__("xf", calls["xf"] + 1), real_xf(*a))[1])
-    monkeypatch.setattr(lib, "crossclr_backward_saved", lambda *a: (calls.__setitem__("lds", calls["lds"] + 1), real_lds(*a))[1])
+    calls = {"xfp": 0, "xf": 0, "lds": 0}
+    real = {"xfp": lib.crossclr_backward_saved_xfp, "xf": lib.crossclr_backward_saved_xf, "lds": lib.crossclr_backward_saved}
+    count = lambda k: (lambda *a: (calls.__setitem__(k, calls[k] + 1), real[k](*a))[1])
+    for k, name in (("xfp", "crossclr_backward_saved_xfp"), ("xf", "crossclr_backward_saved_xf"), ("lds", "crossclr_backward_saved")):
+        monkeypatch.setattr(lib, name, count(k))
     monkeypatch.setattr(L, "_xf_verified", {})
     gv, gt = step()
-    assert calls == {"xf": 1, "lds": 1} and list(L._xf_verified.values()) == [True]
+    selftest_lds = calls["lds"]                       # the self-test's reference launches (one per synthetic batch)
+    assert calls["xfp"] >= 1 + 2 and calls["xf"] == 0 and selftest_lds == len(L._XF_SELFTEST_ROWS) and list(L._xf_verified.values()) == [True]
+    before = dict(calls)
     gv2, gt2 = step()
-    assert calls == {"xf": 2, "lds": 1} and torch.equal(gv, gv2) and torch.equal(gt, gt2)
-    # a build whose fragment-major kernel is wrong
+    assert calls == {"xfp": before["xfp"] + 1, "xf": 0, "lds": selftest_lds} and torch.equal(gv, gv2) and torch.equal(gt, gt2)
+    # a build whose pair kernel is wrong: the one-tile kernel takes over
     zeros = torch.zeros(nat.make_plan(B, D, 1, 0, nat.MODE_BF16).xf_bytes, dtype=torch.uint8, device="cuda")
-    monkeypatch.setattr(lib, "crossclr_backward_saved_xf",
-                        lambda pp, xf, *rest: (calls.__setitem__("xf", calls["xf"] + 1), real_xf(pp, ctypes.c_void_p(zeros.data_ptr()), *rest))[1])
+    broken = lambda k: (lambda pp, xf, *rest: (calls.__setitem__(k, calls[k] + 1), real[k](pp, ctypes.c_void_p(zeros.data_ptr()), *rest))[1])
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xfp", broken("xfp"))
     monkeypatch.setattr(L, "_xf_verified", {})
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         gv3, gt3 = step()
-    assert any("fragment-major" in str(x.message) for x in w) and list(L._xf_verified.values()) == [False]
-    assert torch.equal(gv3, gv) and torch.equal(gt3, gt)
+    assert any("crossclr_backward_saved_xfp disagrees" in str(x.message) for x in w)
+    assert sorted(L._xf_verified.values()) == [False, True] and torch.equal(gv3, gv) and torch.equal(gt3, gt)
     before = dict(calls)
     gv4, _ = step()
-    assert calls["xf"] == before["xf"] and calls["lds"] == before["lds"] + 1 and torch.equal(gv4, gv)
+    assert calls == {"xfp": before["xfp"], "xf": before["xf"] + 1, "lds": before["lds"]} and torch.equal(gv4, gv)
+    # both wrong: the LDS-staged kernel
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xf", broken("xf"))
+    monkeypatch.setattr(L, "_xf_verified", {})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        gv5, gt5 = step()
+    assert sum("disagrees" in str(x.message) for x in w) == 2 and list(L._xf_verified.values()) == [False, False]
+    assert torch.equal(gv5, gv) and torch.equal(gt5, gt)
+    before = dict(calls)
+    gv6, _ = step()
+    assert calls["lds"] == before["lds"] + 1 and calls["xfp"] == before["xfp"] and calls["xf"] == before["xf"] and torch.equal(gv6, gv)

@@ -332,17 +332,18 @@ def test_saved_backward_with_mirrored_tiles(B, D, weighted, monkeypatch):
 @pytest.mark.parametrize("B,D,weighted", [(150, 24, False), (300, 40, True), (150, 200, False), (140, 300, True), (130, 420, False),
                                           (130, 600, True)])
 def test_fragment_major_backward_is_bit_identical_to_the_lds_staged_one(B, D, weighted, monkeypatch):
-    """plan.xf_bytes > 0: crossclr_normalize_xf also writes the operand as MFMA B fragments and crossclr_backward_saved_xf
-    (fast_bwd_dsl_kernel<..., XF>) loads them straight into registers -- two register sets, loop unrolled by two, every load
-    complete inside its iteration.  Every accumulator receives the same MFMA sequence as in the LDS-staged kernel, so the gradients
+    """plan.xf_bytes > 0: crossclr_normalize_xf also writes the operand as MFMA B fragments; crossclr_backward_saved_xfp
+    (fast_bwd_xfp_kernel: two tiles per barrier interval) and crossclr_backward_saved_xf (fast_bwd_dsl_kernel<..., XF>: one) load them
+    straight into registers.  Every accumulator receives the same MFMA sequence as in the LDS-staged kernel, so all three gradients
     must agree BIT FOR BIT (DK = 8 / 16 / 24 / 32, two column parts at D = 600, mirrored and direct tiles, with and without sample weights)."""
     plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
     assert plan.fast_path == 1 and plan.stash_bytes > 0 and plan.xf_bytes == plan.operand_bytes and plan.bpad >= 256
     monkeypatch.setenv("CROSSCLR_XF_WIDTHS", "128,256,384,512,768,1024")     # (the module's default policy takes this path at 128 and 512 only)
     seen = []
     lib = nat.library()
-    real = lib.crossclr_backward_saved_xf
-    monkeypatch.setattr(lib, "crossclr_backward_saved_xf", lambda *a: (seen.append(1), real(*a))[1])
+    real_p, real_1 = lib.crossclr_backward_saved_xfp, lib.crossclr_backward_saved_xf
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xfp", lambda *a: (seen.append("xfp"), real_p(*a))[1])
+    monkeypatch.setattr(lib, "crossclr_backward_saved_xf", lambda *a: (seen.append("xf"), real_1(*a))[1])
     v, t = orc.make_inputs("randn", B, D, 31)
     kw = {}
     if weighted:
@@ -355,12 +356,17 @@ def test_fragment_major_backward_is_bit_identical_to_the_lds_staged_one(B, D, we
         loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", **kw)
         loss.backward()
         return loss.item(), vv.grad, tt.grad
-    lx, gvx, gtx = step()
+    lx, gvx, gtx = step()                                   # the pair kernel (two tiles per barrier interval): what a step runs
+    assert seen == ["xfp"]
+    monkeypatch.setenv("CROSSCLR_XFP", "0")
+    l1, gv1, gt1 = step()                                   # one tile per barrier interval
+    assert seen == ["xfp", "xf"]
+    assert lx == l1 and torch.equal(gvx, gv1) and torch.equal(gtx, gt1)
+    monkeypatch.delenv("CROSSCLR_XFP")
     monkeypatch.setenv("CROSSCLR_DISABLE_XF", "1")
     assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).xf_bytes == 0
-    assert len(seen) == 1
     ll, gvl, gtl = step()
-    assert len(seen) == 1      # (this one went through crossclr_backward_saved)
+    assert len(seen) == 2      # (this one went through crossclr_backward_saved)
     assert lx == ll and torch.equal(gvx, gvl) and torch.equal(gtx, gtl)
     monkeypatch.delenv("CROSSCLR_DISABLE_XF")
     # the XF entry point refuses a plan without the layout, and the prenormalized path (crossclr_pack_xf) agrees too

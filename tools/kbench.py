@@ -15,5 +15,5 @@ peak = 2500.0 if mode == "bf16" else 157.3
 f = 6.0 * B * B * D / (st["step_forward"] * 1e-3) / 1e12
 b = 8.0 * B * B * D / (st["step_backward"] * 1e-3) / 1e12
 tot = sum(st[k] for k in ("normalize", "step_forward", "forward_finish", "step_backward", "backward_finish"))
-print(f"B={B} D={D} {mode} fast={int(st['fast_path'])} saved={int(st['saved_path'])} xf={int(st.get('xf_path', 0))}: " + " ".join(f"{k}={st[k]:.4f}ms" for k in st if k not in ("fast_path", "saved_path", "xf_path", "step_forward", "step_backward")) +
+print(f"B={B} D={D} {mode} fast={int(st['fast_path'])} saved={int(st['saved_path'])} xf={int(st.get('xf_path', 0))} xfp={int(st.get('xfp_path', 0))}: " + " ".join(f"{k}={st[k]:.4f}ms" for k in st if k not in ("fast_path", "saved_path", "xf_path", "xfp_path", "step_forward", "step_backward")) +
       f" | sum={tot:.4f}ms fwd {f:.0f} TF alg ({f/peak:.1%}) bwd {b:.0f} TF alg ({b/peak:.1%}) step {14.0*B*B*D/(tot*1e-3)/1e12/peak:.1%}")

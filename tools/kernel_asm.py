@@ -12,7 +12,7 @@ src = os.path.join(tmp, "k.hip")
 open(src, "w").write('#include "crossclr_kernels_fast.h"\nnamespace crossclr {\ntemplate __global__ void %s(%s);\n}\n' % (kern, sig))
 out = os.path.join(tmp, "k.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S",
-                       "-DCROSSCLR_KERNELS_ONLY", "-I", CSRC, src, "-o", out] + flags, stderr=subprocess.DEVNULL)
+                       "-DCROSSCLR_KERNELS_ONLY", "-I", CSRC, src, "-o", out] + flags + [a for a in sys.argv[3:] if a.startswith(("-f", "-m"))], stderr=subprocess.DEVNULL)
 s = open(out).read()
 for key in ("; NumVgprs", "; NumAgprs", "; ScratchSize", "; Occupancy", "; LDSByteSize", "; TotalNumSgprs"):
     m = re.search(re.escape(key) + r":\s*(\S+)", s)

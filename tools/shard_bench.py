@@ -86,15 +86,33 @@ for world in (1, 2, 4, 8):
     for r in range(world):
         rzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = rz
         wrzc[r * 2 * plan.bpad:(r + 1) * 2 * plan.bpad] = wrz
+    # the module's default: the pair kernel (fast_bwd_xfp_kernel) for the local block AND, on fragment-major copies, for the remote blocks
+    # and partner gradients (CROSSCLR_REMOTE_XFP=0: the LDS-staged kernels for the remote ones, as in round 3)
+    remote_xfp = xf is not None and os.environ.get("CROSSCLR_REMOTE_XFP", "1") != "0" and world * plan.operand_bytes < (1 << 32)
+    xfall = None
+    if remote_xfp and saved:
+        xfall = torch.empty(world * plan.operand_bytes, dtype=torch.uint8, device="cuda")
+        def relay():
+            rc = 0
+            for first, nr, _ in saved:
+                runs = [(first, min(nr, world - first))] + ([(0, nr - (world - first))] if first + nr > world else [])
+                for r0, cnt in runs:
+                    rc |= lib.crossclr_pack_xf_from_packed(pp, xall.data_ptr() + r0 * plan.operand_bytes, cnt, xfall.data_ptr() + r0 * plan.operand_bytes, stream)
+            return rc
+        run("xf_from_packed", relay)
     if xf is not None:
-        run("bwd_local(saved, xf)", lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(gbuf), 0, stream))
+        run("bwd_local(saved, xfp)", lambda: lib.crossclr_backward_saved_xfp(pp, p(xf), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(gbuf), 0, stream))
     elif stash is not None:
         run("bwd_local(saved)", lambda: lib.crossclr_backward_saved(pp, p(xr), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(gbuf), 0, stream))
     else:
         run("bwd_local", lambda: lib.crossclr_backward(pp, p(xr), p(xr), 1, rank, -1, 0.03, 0.8, p(rz), p(wrz), p(rz), p(wrz), p(gbuf), 0, stream))
     for i, (first, nr, st) in enumerate(saved):
-        run(f"bwd_saved[{nr}]" + ("" if i == 0 else "'"), lambda: lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, nr, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc),
-                                                                                                   None, p(gbuf), 1, stream))
+        if xfall is not None:
+            run(f"bwd_saved_xfp[{nr}]" + ("" if i == 0 else "'"), lambda: lib.crossclr_backward_rect_saved_xfp(pp, p(xfall), p(st), first, nr, 0.03, 0.8, p(rz), p(wrz), p(rzc),
+                                                                                                               p(wrzc), None, p(gbuf), 1, stream))
+        else:
+            run(f"bwd_saved[{nr}]" + ("" if i == 0 else "'"), lambda: lib.crossclr_backward_rect_saved(pp, p(xall), p(st), first, nr, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc),
+                                                                                                       None, p(gbuf), 1, stream))
     if K and os.environ.get("CROSSCLR_PARTNER_GRADS", "1") != "0":
         # partner gradients (the default): this rank forms the transposed contribution of each of its K pair blocks for the partner
         # (crossclr_backward_rect_saved_t), sums the column slices and -- after the exchange, not timed here -- adds what it received
@@ -104,7 +122,10 @@ for world in (1, 2, 4, 8):
         def partner():
             rc = 0
             for k in range(K):
-                rc |= lib.crossclr_backward_rect_saved_t(pp, p(xr), p(st_p), (rank + 1) % world, K, k, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc), None, p(tmp), stream)
+                if xfall is not None:
+                    rc |= lib.crossclr_backward_rect_saved_t_xfp(pp, p(xf), p(st_p), (rank + 1) % world, K, k, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc), None, p(tmp), stream)
+                else:
+                    rc |= lib.crossclr_backward_rect_saved_t(pp, p(xr), p(st_p), (rank + 1) % world, K, k, 0.03, 0.8, p(rz), p(wrz), p(rzc), p(wrzc), None, p(tmp), stream)
                 torch.sum(tmp.view(-1, nel), 0, out=outg[k])
             for k in range(K):
                 gbuf[:nel] += outg[k]
