@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
 from typing import Optional
 
 import torch
@@ -959,11 +960,59 @@ class _device_of:
 
 def _refuse_double_backward(what: str) -> None:
     """The autograd engine runs `backward` with grad mode ON exactly when the caller asked for a graph through it
-    (`create_graph=True`).  The reference's eager ops (loss.py:79-114) are twice differentiable; these closed-form kernels are
-    not -- raise instead of silently handing back a gradient that autograd would treat as a constant."""
+    (`create_graph=True`).  The closed-form kernels of the projection / ranking paths are not twice differentiable --
+    raise instead of silently handing back a gradient that autograd would treat as a constant.  (The CrossCLR criterion itself
+    carries second-order terms: `_second_order_grads`.)"""
     if torch.is_grad_enabled():
         raise RuntimeError(f"{what}: differentiating through the backward (create_graph=True / double backward) is not "
                            "supported by the HIP kernels; use the eager reference for second-order terms")
+
+
+_second_order_warned = False
+
+
+def _differentiable_loss(video, text, temperature, negative_w, negative_scale, loss_weight, prenormalized):
+    """The criterion as a chain of differentiable device ops (float64 soft-max like the reference's, trainer/loss.py:79-114, written
+    in the closed form of DESIGN.md section 6: Z_p = sum_q e^{A_pq} + sum_{q != p} k_q e^{w S_pq} + k_p e^0,
+    L = sum_p omega_p (log Z_p - A_pp) / 2B).  NOT the product's first-order path: it exists so that `create_graph=True` (gradient
+    penalties, meta-gradients) -- which the reference's eager ops allow -- works through this module too; it materialises the
+    [B, 2B] float64 logits exactly as the reference does."""
+    F = torch.nn.functional
+    b = video.shape[0]
+    vn = video if prenormalized else F.normalize(video, dim=1)
+    tn = text if prenormalized else F.normalize(text, dim=1)
+    inv_tau = 1.0 / float(temperature)
+    off = 1.0 - torch.eye(b, dtype=torch.float64, device=video.device)
+    inter = (vn @ tn.t()).double() * inv_tau
+    pos = inter.diagonal()
+
+    def side(a, intra_rows, k, omega):
+        intra = (intra_rows @ intra_rows.t()).double() * inv_tau * off * float(negative_w)      # masked diagonal: logit 0, not -inf
+        m = torch.maximum(a.max(dim=1).values, intra.max(dim=1).values).detach()
+        ei, ea = torch.exp(a - m[:, None]), torch.exp(intra - m[:, None])
+        if k is not None:
+            ea = ea * k.double()[None, :]
+        nll = torch.log(ei.sum(1) + ea.sum(1)) + m - pos
+        return (nll * omega.double()).sum() if omega is not None else nll.sum()
+
+    kv, kt = negative_scale if negative_scale is not None else (None, None)
+    ov, ot = loss_weight if loss_weight is not None else (None, None)
+    return (side(inter, vn, kv, ov) + side(inter.t(), tn, kt, ot)) / (2.0 * b)
+
+
+def _second_order_grads(video, text, grad_out, temperature, negative_w, group, negative_scale, loss_weight, prenormalized):
+    global _second_order_warned
+    import torch.distributed as dist
+    if group is not None and dist.get_world_size(group) > 1:
+        raise RuntimeError("CrossCLR_onlyIntraModality: create_graph=True (double backward) is not available for the row-sharded "
+                           "loss; gather the features (all_gather_with_grad) and call the criterion without a process group")
+    if not _second_order_warned:
+        _second_order_warned = True
+        warnings.warn("CrossCLR: create_graph=True -- the gradient is formed by differentiable device ops (float64 [B, 2B] logits, "
+                      "as in the reference) instead of the HIP backward kernels, so that it can be differentiated again", stacklevel=3)
+    with torch.enable_grad():
+        loss = _differentiable_loss(video, text, temperature, negative_w, negative_scale, loss_weight, prenormalized)
+        return torch.autograd.grad(loss, (video, text), grad_out.to(loss.dtype), create_graph=True, allow_unused=True)
 
 
 class _CrossCLRFunction(torch.autograd.Function):
@@ -975,13 +1024,20 @@ class _CrossCLRFunction(torch.autograd.Function):
             loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight,
                                      save_for_backward=needs_grad, prenormalized=prenormalized)
         ctx.ws = ws
-        ctx.save_for_backward(video_c, text_c)
+        ctx.second_order = (float(temperature), float(negative_w), group, negative_scale, loss_weight, bool(prenormalized))
+        ctx.save_for_backward(video, text)      # (the inputs themselves: a graph through the backward needs their identity)
+        ctx.row_major = (video_c, text_c)       # (aliases of the inputs unless they had to be copied into row-major form)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        _refuse_double_backward("CrossCLR_onlyIntraModality")
-        video_c, text_c = ctx.saved_tensors
+        video, text = ctx.saved_tensors
+        if torch.is_grad_enabled() and (video.requires_grad or text.requires_grad or grad_out.requires_grad):
+            # create_graph=True: the reference's eager ops (loss.py:79-114) are twice differentiable, so is this path
+            gv, gt = _second_order_grads(video, text, grad_out, *ctx.second_order)
+            return (gv if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
+                    None, None, None, None, None, None, None)
+        video_c, text_c = ctx.row_major
         with _device_of(video_c):
             gv, gt = _backward_impl(ctx.ws, video_c, text_c, grad_out)
         return (gv if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,

@@ -643,3 +643,22 @@ def test_remote_blocks_with_saved_exponentials_equal_single_device(world, B, D, 
     scale = vg.grad.abs().max().item()
     assert (gv - vg.grad).abs().max().item() <= 3e-3 * scale      # bf16 weights rounded in different tile groupings
     assert (gt - tg.grad).abs().max().item() <= 3e-3 * scale
+
+
+def test_second_order_terms_on_the_device():
+    """create_graph=True through the criterion (the reference's eager ops, trainer/loss.py:79-114, are twice differentiable): the first
+    gradient equals the HIP backward's, and a gradient penalty differentiates to the op-for-op oracle's values."""
+    v, t = orc.make_inputs("randn", 64, 48, 5)
+    vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.8, compute_mode="fp32").cuda()
+    loss = crit(vd, td)
+    with pytest.warns(UserWarning, match="create_graph"):
+        gv, gt = torch.autograd.grad(loss, (vd, td), create_graph=True)
+    ((gv.double() ** 2).sum() + (gt.double() ** 2).sum()).backward()
+    _, gv1, gt1 = run_module(v, t, {"temperature": 0.05, "negative_weight": 0.8}, "fp32")
+    assert (gv.detach() - gv1).abs().max().item() <= 1e-5 * gv1.abs().max().item()
+    vc, tc = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    rv, rt = torch.autograd.grad(orc.eager_loss(vc, tc, 0.05, 0.8), (vc, tc), create_graph=True)
+    ((rv.double() ** 2).sum() + (rt.double() ** 2).sum()).backward()
+    assert (vd.grad.cpu() - vc.grad).abs().max().item() <= 1e-4 * vc.grad.abs().max().item()
+    assert (td.grad.cpu() - tc.grad).abs().max().item() <= 1e-4 * tc.grad.abs().max().item()

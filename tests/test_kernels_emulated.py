@@ -440,14 +440,38 @@ def test_two_pass_regime_saves_both_exponential_matrices(B, D, weighted, sym, mo
         assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 1e-3 * scale
 
 
-def test_double_backward_raises_instead_of_returning_a_constant():
-    """The reference's loss (trainer/loss.py:79-114) is twice differentiable; the closed-form backward here is not: asking for a
-    graph through it must raise, never silently treat the first gradient as a constant."""
+def test_double_backward_matches_the_reference_and_never_returns_a_constant():
+    """The reference's loss (trainer/loss.py:79-114) is twice differentiable.  The criterion carries that semantic (create_graph=True forms the
+    gradient by differentiable device ops; the first-order path is untouched): a gradient penalty ||dL/dv||^2 differentiates to the same
+    values as through the op-for-op oracle.  The ranking loss's closed-form backward is not twice differentiable and must raise."""
     v, t = orc.make_inputs("randn", 8, 16, 1)
+    def penalty_grads(loss_fn):
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = loss_fn(vv, tt)
+        gv, gt = torch.autograd.grad(loss, (vv, tt), create_graph=True)
+        assert gv.requires_grad and gt.requires_grad
+        pen = (gv.double() ** 2).sum() + 0.5 * (gt.double() ** 2).sum() + loss
+        pen.backward()
+        return loss.detach(), gv.detach(), vv.grad, tt.grad
+    with pytest.warns(UserWarning, match="create_graph"):
+        got = penalty_grads(lambda a, b: crossclr_amd.crossclr_loss(a, b, 0.05, 0.8, compute_mode="fp32"))
+    want = penalty_grads(lambda a, b: orc.eager_loss(a, b, 0.05, 0.8))
+    assert abs(got[0].item() - want[0].item()) <= 1e-6
+    for g, w in zip(got[1:], want[1:]):
+        assert (g.double() - w.double()).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item())
+    # the ordinary backward of the same module still runs the kernels (no graph through it: grad mode is off inside)
     vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
-    loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="fp32")
-    with pytest.raises(RuntimeError, match="double backward"):
-        torch.autograd.grad(loss, vv, create_graph=True)
+    crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="fp32").backward()
+    assert (vv.grad.double() - want[1].double()).abs().max().item() <= 1e-5 * want[1].abs().max().item()
+    # per-sample weights go through the same closed form
+    k = (torch.tensor([1.0, 0.0, 1.0, 0.5, 1.0, 1.0, 2.0, 1.0]), torch.ones(8))
+    om = (torch.linspace(0.5, 1.5, 8), torch.ones(8))
+    vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    lw = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="fp32", negative_scale=k, loss_weight=om)
+    g1, = torch.autograd.grad(lw, vv, create_graph=True)
+    vv2, tt2 = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    crossclr_amd.crossclr_loss(vv2, tt2, 0.05, 0.8, compute_mode="fp32", negative_scale=k, loss_weight=om).backward()
+    assert (g1.detach() - vv2.grad).abs().max().item() <= 1e-5 * vv2.grad.abs().max().item()
     a, b = torch.nn.functional.normalize(v, dim=1).requires_grad_(True), torch.nn.functional.normalize(t, dim=1).requires_grad_(True)
     mm = crossclr_amd.max_margin_loss(a, b, 0.1)
     with pytest.raises(RuntimeError, match="double backward"):
