@@ -236,6 +236,7 @@ def secondary_lines(dev):
     case("config2_fp32_fwd_b4096", 4096, 512, "fp32", True, False, GOLDEN_LOSS_B4096_SEED1234)
     case("d1024_bf16_fwd_bwd", 8192, 1024, "bf16", False, False, None)
     case("d1024_influential", 8192, 1024, "bf16", False, True, None)
+    case("d1536_bf16_fwd_bwd", 8192, 1536, "bf16", False, False, None)     # beyond the register-resident forward: generic forward + saved D-slice backward in 3 column parts
     return out
 
 

@@ -4,7 +4,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
 git-ignored but travels to the GPU box with the source snapshot.
 
-The library is compiled as SIX translation units in parallel (-DCROSSCLR_SPLIT): crossclr_api.cpp (the extern "C" boundary, the
+The library is compiled as SEVEN translation units in parallel (-DCROSSCLR_SPLIT): crossclr_api.cpp (the extern "C" boundary, the
 generic / projection / exact-fp32 kernels) and one small tu_*.cpp per "leaf" launcher of crossclr_kernels_fast.h, each of which
 instantiates one family of the heavy register-resident kernel templates (forward, the three saved backwards, the recomputing
 backwards).  Wall time = the longest leaf (~3 minutes) instead of the sum (~10)."""
@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # saved backward -2.7 %, forward ~-2 % (profiles/r04_ab_noslp.txt, A/B on one box)
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 FLAGS = COMMON + ["-shared", "-x", "hip"]          # (the single-translation-unit form: tools/build_variant.py, tools/isa_loop_stats.py)
-UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_recomp.cpp"]
+UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_saved_wide.cpp", "tu_recomp.cpp"]
 
 
 def sources():

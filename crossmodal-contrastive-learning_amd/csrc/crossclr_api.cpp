@@ -151,6 +151,15 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     }
 #endif
     if (!plan->fast_path && dpad > 256) dpad = round_up(D, 256);  // generic backward slices D by 256
+    // wide bf16 plans (1024 < D <= 4096): generic forward, but its exponentials are saved for the D-slice backward, which runs as 3 ... 8
+    // column parts of 384 / 512 columns -- the operand is padded to parts x columns
+    bool wide = false;
+#ifndef CROSSCLR_NO_FAST
+    if (mode == CROSSCLR_MODE_BF16 && !plan->fast_path && !env.disable_fast && !env.disable_save && !env.disable_symmetric && wide_bf16_dpad(D) > 0) {
+        dpad = wide_bf16_dpad(D);
+        wide = true;
+    }
+#endif
     plan->Dpad = dpad;
     // backward kernel: 0 generic tiled, 1 register-resident 32-row waves (Dpad <= 512), 2 16-row waves (Dpad <= 1024)
     plan->fast_bwd = 0;
@@ -202,6 +211,15 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         if (!plan->fast_bwd) dsl = plan->Dpad % 256 == 0 ? plan->Dpad / 256 : (plan->Dpad % 128 == 0 ? plan->Dpad / 128 : plan->Dpad / 64);
         const int blocks = (2 * plan->bpad / row_blk) * dsl;
         int sl = (256 + blocks - 1) / blocks;
+        if (wide) {   // saved backward: (128-row blocks) x (column parts) x slices thread blocks, one per CU: the cut with the fewest rounds of 256
+            const int wb = (2 * plan->bpad / 128) * (dpad / (dpad % 512 == 0 ? 512 : 384));
+            double best = 1e30;
+            for (int c = 1; c <= 4; ++c) {
+                const double rounds = (double)((wb * c + 255) / 256) / c;
+                if (rounds < best - 1e-9) { best = rounds; sl = c; }
+            }
+            if (wb < 256 && sl < (256 + wb - 1) / wb) sl = (256 + wb - 1) / wb;
+        }
         const int tiles = 2 * plan->bpad / tile;
         if (sl > tiles / 2) sl = tiles / 2;
         if (sl > 16) sl = 16;
@@ -221,6 +239,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     plan->stash_bytes = 0;
 #ifndef CROSSCLR_NO_FAST
     if (plan->fast_path && plan->fast_bwd && !env.disable_save) plan->stash_bytes = fast_stash_bytes(plan->bpad, plan->Dpad);
+    if (wide) plan->stash_bytes = wide_stash_bytes(plan->bpad);
     // exact-fp32 mode: the whole stacked [2 bpad] x [2 bpad] matrix of fp32 exponentials (1 GiB at b = 8192), up to 16 GiB
     if (mode == CROSSCLR_MODE_FP32 && !env.disable_save && plan->operand_bytes < (1ull << 32)) {
         const size_t sb = (size_t)2 * plan->bpad * (size_t)2 * plan->bpad * 4;
@@ -444,10 +463,16 @@ static int forward_generic_sym(const crossclr_plan* plan, const Geo& g, const vo
     dim3 grid(2 * plan->bpad / 256, plan->fwd_slots), block(256);     // one blockIdx.x per PAIR of row blocks (I, ntiles - 1 - I)
 #define CROSSCLR_LSY(TT, SW, MODE, ST) \
     LAUNCH((fwd_sums_kernel<TT, SW, MODE, ST, true>), grid, block, stream, (const TT*)x, (const TT*)x, g, 0, out, k, shift, stash, header, colpart)
-    if (stash) {   // (exact-fp32 plans only: T = float)
-        if (shift) { if (k) CROSSCLR_LSY(float, true, 2, true); else CROSSCLR_LSY(float, false, 2, true); }
-        else { if (k) CROSSCLR_LSY(float, true, 0, true); else CROSSCLR_LSY(float, false, 0, true); }
-        return launch_status("fwd_sums_kernel (symmetric, save)");
+    if (stash) {   // exact-fp32 plans (T = float: fp32 fragments, both triangles) or wide bf16 plans (bf16 records, upper triangle)
+        if constexpr (sizeof(T) == 2) {
+            if (shift) return fail(CROSSCLR_E_ARG, "bf16 plans save their exponentials in the single-pass soft-max only");
+            if (k) CROSSCLR_LSY(bf16_t, true, 0, true); else CROSSCLR_LSY(bf16_t, false, 0, true);
+            return launch_status("fwd_sums_kernel (symmetric, save, bf16 records)");
+        } else {
+            if (shift) { if (k) CROSSCLR_LSY(float, true, 2, true); else CROSSCLR_LSY(float, false, 2, true); }
+            else { if (k) CROSSCLR_LSY(float, true, 0, true); else CROSSCLR_LSY(float, false, 0, true); }
+            return launch_status("fwd_sums_kernel (symmetric, save)");
+        }
     }
     if (rowmax) { if (k) CROSSCLR_LSY(T, true, 1, false); else CROSSCLR_LSY(T, false, 1, false); }
     else if (shift) { if (k) CROSSCLR_LSY(T, true, 2, false); else CROSSCLR_LSY(T, false, 2, false); }
@@ -542,6 +567,8 @@ extern "C" int crossclr_forward_save(const crossclr_plan* plan, const void* xhat
         return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
     float* out = part + (size_t)slot0 * 2 * plan->bpad;
     int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    if (!plan->fast_path && plan->mode == CROSSCLR_MODE_BF16)   // wide bf16 plan: upper triangle, bf16 records in the register-resident layout
+        return forward_generic_sym<bf16_t>(plan, g, xhat, out, kcols, part + ws_colpart_off(plan), header, stream, static_cast<float*>(stash));
     if (!plan->fast_path) {   // exact-fp32 mode
         if (!env_knobs().disable_symmetric)   // upper triangle; every fragment stored twice (as evaluated + transposed)
             return forward_generic_sym<float>(plan, g, xhat, out, kcols, part + ws_colpart_off(plan), header, stream, static_cast<float*>(stash));
@@ -568,7 +595,7 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g);
     if (rc) return rc;
-    if (!plan->fast_path) {   // exact-fp32 mode
+    if (!plan->fast_path && plan->mode == CROSSCLR_MODE_FP32) {   // exact-fp32 mode
         const int NQ = 2 * plan->bpad / 32;
         const int tps = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
         const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;

@@ -170,6 +170,15 @@ static inline int fwd_max_slots(const FwdWork& w) {
     return m;
 }
 
+// Saved bf16 exponentials of a symmetric local block (crossclr_kernels_fast.h, "stash"): one 2-KiB record per 32 x 32 tile (r32, t) with
+// t >= tpr * (r32 / tpr) -- the upper triangle at the granularity of the forward's row blocks (tpr 32-row groups each), row group by row group.
+__host__ __device__ __forceinline__ size_t stash_tile_index(int tpr, int NT, int r32, int t) {
+    const size_t rb = (size_t)(r32 / tpr), w = (size_t)(r32 % tpr);
+    const size_t before = (size_t)tpr * (rb * NT - (size_t)(tpr / 2) * rb * (rb - 1));   // tiles of row blocks < rb
+    return before + w * ((size_t)NT - tpr * rb) + ((size_t)t - tpr * rb);
+}
+static inline size_t stash_tiles_total(int tpr, int NT) { return stash_tile_index(tpr, NT, NT, NT); }
+
 // Timeline instrumentation of the two pipelined kernels (variant builds only: tools/build_variant.py NAME -DCROSSCLR_TIMING;
 // read back with crossclr_debug_timing, tools/timeline.py): thread 0 of every block stamps the constant 100 MHz counter
 // (s_memrealtime) and the shader-clock counter (s_memtime) at a few marks -- block start / first tile ready / main loop done /

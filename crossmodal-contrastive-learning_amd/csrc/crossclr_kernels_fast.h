@@ -224,6 +224,19 @@ static inline int fast_dpad(int D) {
     return 0;
 }
 
+// bf16 plans beyond the register-resident forward (D > 1024): the generic tiled forward saves its exponentials in the register-resident
+// layout and the D-slice saved backward runs as XP column parts of 384 / 512 columns (blockIdx.z) -- Dpad = XP x part, XP = 3 ... 8
+static inline int wide_bf16_dpad(int D) {
+    if (D <= 1024) return 0;
+    if (D <= 1152) return 1152;     // 3 x 384
+    if (D <= 1536) return 1536;     // 3 x 512
+    if (D <= 2048) return 2048;     // 4 x 512
+    if (D <= 2560) return 2560;     // 5 x 512
+    if (D <= 3072) return 3072;     // 6 x 512
+    if (D <= 4096) return 4096;     // 8 x 512
+    return 0;
+}
+
 __device__ __forceinline__ int sigma16(int q) { return ((q & 3) << 2) | ((q >> 2) & 3); }
 __device__ __forceinline__ int swz_slot(int chunk, int q) { return (chunk & ~15) | ((chunk ^ sigma16(q)) & 15); }
 
@@ -276,12 +289,7 @@ __device__ __forceinline__ void issue_tile_dma(const unsigned char* tile_src, un
 //    (tpr = 32-row groups per row block of the forward: 8 for Dpad <= 512, 4 above).
 //    fast_bwd_dsl_kernel turns it into W = E (1/Z_p + 1/Z_q) without recomputing the similarity product.
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ size_t stash_tile_index(int tpr, int NT, int r32, int t) {
-    const size_t rb = (size_t)(r32 / tpr), w = (size_t)(r32 % tpr);
-    const size_t before = (size_t)tpr * (rb * NT - (size_t)(tpr / 2) * rb * (rb - 1));   // tiles of row blocks < rb
-    return before + w * ((size_t)NT - tpr * rb) + ((size_t)t - tpr * rb);
-}
-static inline size_t stash_tiles_total(int tpr, int NT) { return stash_tile_index(tpr, NT, NT, NT); }
+// (stash_tile_index / stash_tiles_total: crossclr_device.h -- the generic forward of wide bf16 plans fills the same layout)
 
 // ---------------------------------------------------------------------------------------------
 // backward: 4 waves x 32 rows per block, ONE wave per SIMD so each wave owns the whole 512-entry
@@ -781,6 +789,9 @@ namespace crossclr {
 #if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_LDS)
 #define CROSSCLR_DEF_SAVED_LDS 1
 #endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_WIDE)
+#define CROSSCLR_DEF_SAVED_WIDE 1
+#endif
 #if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_XF1)
 #define CROSSCLR_DEF_SAVED_XF1 1
 #endif
@@ -882,6 +893,8 @@ static inline int fast_forward(const crossclr_plan* p, const Geo& g, const void*
 static inline size_t fast_stash_bytes(int bpad, int Dpad) {
     return Dpad <= 512 ? stash_tiles_total(8, 2 * bpad / 32) * 2048 : (Dpad <= 1024 ? stash_tiles_total(4, 2 * bpad / 32) * 2048 : 0);
 }
+// wide bf16 plans (wide_bf16_dpad): the generic symmetric forward fills the 128-row-block layout
+static inline size_t wide_stash_bytes(int bpad) { return stash_tiles_total(4, 2 * bpad / 32) * 2048; }
 // bytes of the stash of a rectangular (remote / pairs) launch over `nranks` column ranks
 static inline size_t fast_stash_bytes_rect(int bpad, int Dpad, int nranks) {
     return Dpad <= 1024 ? (size_t)(2 * bpad / 32) * (size_t)(2 * bpad / 32) * (size_t)nranks * 2048 : 0;
@@ -1036,6 +1049,44 @@ CROSSCLR_LEAF int launch_saved_lds(const SavedLaunch& a) {
 }
 #endif   // CROSSCLR_DEF_SAVED_LDS
 
+// fast_bwd_dsl_kernel for wide bf16 plans (Dpad > 1024: 3 ... 8 column parts, blockIdx.z): the local symmetric block from the records the
+// generic forward saved (fwd_sums_kernel<bf16_t, ..., ST, SYM>)
+#ifndef CROSSCLR_DEF_SAVED_WIDE
+int launch_saved_wide(const SavedLaunch& a);
+#else
+CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
+    const crossclr_plan* p = a.p;
+    const Geo& g = a.g;
+    dim3 block(256);
+    void* stream = a.stream;
+    const bf16_t* c = (const bf16_t*)a.cols;
+    const unsigned char* st = (const unsigned char*)a.stash;
+    const float *rz = a.rz, *wrz = a.wrz, *rz_cols = a.rz_cols, *wrz_cols = a.wrz_cols, *ks = a.ks, *kc = a.kc;
+    float* gbuf = a.gbuf;
+    const int accumulate = a.accumulate, tps = a.tps;
+    (void)block; (void)stream; (void)c; (void)st; (void)rz; (void)wrz; (void)rz_cols; (void)wrz_cols; (void)kc; (void)gbuf; (void)accumulate; (void)tps;
+    if (a.mode != 0) return CROSSCLR_E_ARG;
+#ifdef CROSSCLR_DSL_MINIMAL
+    return CROSSCLR_E_ARG;
+#else
+#define CROSSCLR_LBW(DK, XP) do { dim3 gridw(2 * p->bpad / 128, p->bwd_slices, XP);                                                            \
+                                  if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, XP, 4>), gridw, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
+                                  else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, XP, 4>), gridw, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
+    switch (p->Dpad) {
+        case 1152: CROSSCLR_LBW(24, 3); break;
+        case 1536: CROSSCLR_LBW(32, 3); break;
+        case 2048: CROSSCLR_LBW(32, 4); break;
+        case 2560: CROSSCLR_LBW(32, 5); break;
+        case 3072: CROSSCLR_LBW(32, 6); break;
+        case 4096: CROSSCLR_LBW(32, 8); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LBW
+    return CROSSCLR_OK;
+#endif
+}
+#endif   // CROSSCLR_DEF_SAVED_WIDE
+
 // mode 0 / 1 / 2: the LDS-staged kernel on the row-major operand -- the local symmetric block, a rectangular block, the transpose of one
 // rectangular block.  mode 3: mode 0 on the fragment-major operand, one tile per barrier interval.  mode 4 / 5 / 6: modes 0 / 1 / 2 on the
 // fragment-major operand with the pair kernel (crossclr_kernels_dslp.h; stash below 4 GiB: 32-bit scalar offsets, even slices).
@@ -1063,6 +1114,7 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
         if (a.stash_bytes >= ((size_t)1 << 32)) return CROSSCLR_E_ARG;
         return launch_saved_xfp(a);
     }
+    if (p->Dpad > 1024) return launch_saved_wide(a);
     return xf ? launch_saved_xf1(a) : launch_saved_lds(a);
 }
 // which backward the fast path uses: 16-row wavefronts (rows per block 128 at Dpad <= 512, 64 above) or the

@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                                                        float* part, const float* kcols, const float* shift, float* stash, int* header,
                                                        float* colpart) {
     static_assert(!ST || MODE == 0 || MODE == 2, "exponentials are saved by the passes that form sums");
+    static_assert(!(ST && sizeof(T) == 2) || MODE == 0, "bf16 records: the single-pass soft-max only");
     static_assert(!SYM || MODE <= 3, "symmetric evaluation: the soft-max passes; MODE 3: one pass for both directions");
     // MODE 3 + SYM (score statistics in ONE pass): only the rows of modality 0 are walked (grid.x = bpad / 128), against the column
     // tiles of modality 1; every tile also yields, per column q, the hinge sum and the active count over the block's rows against
@@ -440,7 +441,21 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                             rowacc[pi] += e;
                         }
                     }
-                    if (ST) {
+                    if constexpr (ST && sizeof(T) == 2) {
+                        // bf16 plans beyond the register-resident kernels (Dpad > 1024): the record of tile (p32, q32), q32 >= 4 (p32 / 4) --
+                        // [k-step th = r4 >> 1][lane][8 bf16], lane (p, half) holding E[p][16 th + 8 (r4 & 1) + 4 half + j] -- in the upper-
+                        // triangle layout of the register-resident forward with 128-row blocks (stash_tile_index, tpr = 4): what
+                        // fast_bwd_dsl_kernel<..., TPRF = 4> reads, the mirrored half through its transposing gather.  8 bytes per lane and r4.
+                        const int p32 = (row0 + 64 * wr + 32 * pi) >> 5, q32 = (int)((ct.row0 + 64 * wc + 32 * qi) >> 5);
+                        if (q32 >= 4 * (p32 / 4)) {
+                            struct B4 { bf16_t e[4]; } pk;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(ev[j]);
+                            unsigned char* rec = reinterpret_cast<unsigned char*>(stash) + stash_tile_index(4, 2 * g.bpad / 32, p32, q32) * 2048 +
+                                                 1024 * (r4 >> 1) + 16 * lane + 8 * (r4 & 1);
+                            *reinterpret_cast<B4*>(rec) = pk;
+                        }
+                    } else if constexpr (ST) {
                         const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (ct.row0 + 64 * wc + 32 * qi) >> 5;
                         const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);     // floats of one matrix
                         *reinterpret_cast<f32x4*>(stash + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = ev;

@@ -18,11 +18,11 @@ def sources():
            [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "emu_runtime.cpp")]
 
 
-UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_recomp.cpp"]
+UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_saved_wide.cpp", "tu_recomp.cpp"]
 
 
 def build(force=False):
-    """Six translation units in parallel, like the product build (crossmodal-contrastive-learning_amd/build.py, -DCROSSCLR_SPLIT)."""
+    """Seven translation units in parallel, like the product build (crossmodal-contrastive-learning_amd/build.py, -DCROSSCLR_SPLIT)."""
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
     import tempfile

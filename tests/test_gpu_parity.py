@@ -319,7 +319,12 @@ def test_sharded_host_path_with_real_collectives_on_one_gpu(monkeypatch):
     (640, 600, "bf16"),     # 512 < D <= 768: 4-wave persistent forward + 16-row-wave backward, Dpad = 768
     (512, 1024, "bf16"),    # BASELINE config 5's embedding width: 4-wave persistent forward + 16-row-wave backward
     (2048, 768, "bf16"),    # the common ViT-L / BERT width
-    (300, 1100, "bf16"),    # D > 1024: generic tiled bf16 kernels end to end (Dpad = 1280)
+    (300, 1100, "bf16"),    # D > 1024: generic tiled forward that saves bf16 records + the D-slice backward in 3 parts of 384 (Dpad = 1152)
+    (1500, 1536, "bf16"),   # 3 parts of 512, ragged batch, several 128-row blocks (mirrored and direct tiles)
+    (640, 2000, "bf16"),    # 4 parts of 512
+    (384, 2300, "bf16"),    # 5 parts (Dpad = 2560)
+    (256, 4096, "bf16"),    # 8 parts
+    (200, 4500, "bf16"),    # beyond 4096: the recomputing generic backward
     (777, 200, "fp32"),     # generic fp32, Dpad = 256
     (1024, 768, "fp32"),    # generic fp32, three backward slices
     (3000, 512, "auto"),    # auto -> bf16 (global batch >= 1024)

@@ -201,7 +201,14 @@ def test_plan_geometry():
     p = nat.make_plan(100, 700, 1, 0, nat.MODE_BF16)
     assert (p.Dpad, p.fast_path, p.fast_bwd) == (768, 1, 2)   # 512 < D <= 1024: 4-wave forward, 16-row-wave backward
     p = nat.make_plan(100, 1500, 1, 0, nat.MODE_BF16)
-    assert (p.Dpad, p.fast_path, p.fast_bwd) == (1536, 0, 0)  # wider: generic tiled kernels
+    assert (p.Dpad, p.fast_path, p.fast_bwd) == (1536, 0, 0)  # wider: generic tiled forward ...
+    assert p.stash_bytes > 0 and p.xf_bytes == 0              # ... that saves its exponentials for the D-slice backward (3 column parts)
+    assert [nat.make_plan(100, d, 1, 0, nat.MODE_BF16).Dpad for d in (1025, 1153, 2048, 2049, 3000, 4096)] == [1152, 1536, 2048, 2560, 3072, 4096]
+    p = nat.make_plan(8192, 1536, 1, 0, nat.MODE_BF16)
+    assert p.bwd_slices == 2 and p.gbuf_bytes == 2 * 2 * 8192 * 1536 * 4     # 128 row blocks x 3 parts x 2 slices = 3 rounds of 256
+    assert nat.make_plan(8192, 2048, 1, 0, nat.MODE_BF16).bwd_slices == 1
+    p = nat.make_plan(100, 5000, 1, 0, nat.MODE_BF16)
+    assert (p.Dpad, p.fast_path, p.stash_bytes) == (5120, 0, 0)  # beyond 4096: the recomputing generic backward
     assert nat.make_plan(100, 512, 1, 0, nat.MODE_BF16).fast_bwd == 1 and nat.make_plan(100, 512, 1, 0, nat.MODE_FP32).fast_bwd == 0
     with pytest.raises(nat.CrossCLRNativeError):
         nat.make_plan(0, 16, 1, 0, nat.MODE_FP32)
@@ -479,3 +486,36 @@ def test_double_backward_matches_the_reference_and_never_returns_a_constant():
     mm2 = crossclr_amd.max_margin_loss(a, b, 0.1)
     mm2.backward()          # the ordinary backward is unaffected
     assert a.grad is not None
+
+
+@pytest.mark.parametrize("B,D,weighted", [(40, 1100, False), (150, 1030, True)])
+def test_wide_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
+    """1024 < D <= 4096, bf16: the generic symmetric forward leaves bf16 records in the register-resident layout (128-row blocks) and the
+    D-slice saved backward runs as column parts of 384 / 512 columns -- against the streaming float64 oracle (reference: loss.py:83-112,
+    shape-agnostic) and against the recomputing generic backward of the same library (CROSSCLR_DISABLE_SAVE=1)."""
+    v, t = orc.make_inputs("randn", B, D, 77 + B)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(5)
+        kw = dict(negative_scale=(torch.rand(B, generator=g) + 0.5, (torch.rand(B, generator=g) > 0.2).float()),
+                  loss_weight=(torch.rand(B, generator=g) + 0.5, torch.ones(B)))
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.03, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
+    assert plan.stash_bytes > 0 and plan.fast_path == 0
+    ls, gvs, gts = step()
+    monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
+    assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).stash_bytes == 0
+    lr, gvr, gtr = step()
+    assert abs(ls - lr) <= 1e-6 * max(1.0, abs(lr))
+    scale = max(gvr.abs().max().item(), gtr.abs().max().item())
+    # (the saved exponentials are rounded to bf16 once more when the weights are formed: a few 1e-3 of max|grad|)
+    assert (gvs - gvr).abs().max().item() <= 1e-2 * scale and (gts - gtr).abs().max().item() <= 1e-2 * scale
+    if not weighted:
+        ref = orc.streaming_loss_and_grads(v, t, 0.03, 0.8)
+        assert abs(ls - float(ref["loss"])) <= 1e-3
+        assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 1e-2 * scale
+        assert (gts.double() - ref["grad_t"]).abs().max().item() <= 1e-2 * scale
