@@ -111,6 +111,8 @@ _SIGNATURES = {
     # ABI version 3: producer-side fusion (projection head + L2-norm + pack)
     "crossclr_project_pack": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
+    "crossclr_project_pack_wf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
     "crossclr_project_backward_prep": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, _P, _P, _P, _P,
                                                       ctypes.c_long, _P]),
     # ABI version 3: two-pass soft-max for small temperatures

@@ -373,48 +373,68 @@ extern "C" int crossclr_normalize(const crossclr_plan* plan, const void* video, 
 // ------------------------------------------------------------------------------------------------
 // producer-side fusion (crossclr_kernels_project.h)
 #ifndef CROSSCLR_NO_FAST
-template <typename TIN>
+template <typename TIN, bool WF>
 static int project_pack_t(const crossclr_plan* p, const void* xv, const void* xt, long ldv, long ldt, int Din_v, int Din_t, const void* wv,
                           const void* wt, int ldw_v, int ldw_t, const float* bv, const float* bt, void* xhat, float* inv_norm, float* diag,
                           void* stream) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
-    dim3 grid(p->bpad / 64), block(256);
-#define CROSSCLR_LPP(DKP) LAUNCH((project_pack_kernel<TIN, DKP>), grid, block, stream, (const TIN*)xv, (const TIN*)xt, ldv, ldt, Din_v, Din_t, \
-                                 (const bf16_t*)wv, (const bf16_t*)wt, ldw_v, ldw_t, bv, bt, g, (bf16_t*)xhat, inv_norm, diag)
+    // 64 rows per block up to Dpad = 512 when that still gives every CU a block; 32 rows otherwise (and always above 512: accumulators)
+    const bool rows32 = p->bpad / 64 < 256;
+    dim3 grid(p->bpad / 64), grid32(p->bpad / 32), block(256);
+#define CROSSCLR_LPPX(DKP, RFV, GRID) LAUNCH((project_pack_kernel<TIN, DKP, RFV, WF>), GRID, block, stream, (const TIN*)xv, (const TIN*)xt, ldv, ldt, Din_v, Din_t, \
+                                             (const bf16_t*)wv, (const bf16_t*)wt, ldw_v, ldw_t, bv, bt, g, (bf16_t*)xhat, inv_norm, diag)
+#define CROSSCLR_LPP(DKP) do { if (rows32) CROSSCLR_LPPX(DKP, 1, grid32); else CROSSCLR_LPPX(DKP, 2, grid); } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LPP(1); break;
         case 256: CROSSCLR_LPP(2); break;
         case 384: CROSSCLR_LPP(3); break;
         case 512: CROSSCLR_LPP(4); break;
-        default: return fail(CROSSCLR_E_ARG, "crossclr_project_pack: Dpad %d (supported: <= 512)", p->Dpad);
+        case 768: CROSSCLR_LPPX(6, 1, grid32); break;        // wide embeddings: 32 rows per block (the accumulators of 64 x 1024 x 2 would not fit)
+        case 1024: CROSSCLR_LPPX(8, 1, grid32); break;
+        default: return fail(CROSSCLR_E_ARG, "crossclr_project_pack: Dpad %d (supported: <= 1024)", p->Dpad);
     }
 #undef CROSSCLR_LPP
+#undef CROSSCLR_LPPX
     return launch_status("project_pack_kernel");
 }
 #endif
 
-extern "C" int crossclr_project_pack(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text,
-                                     int Din_video, int Din_text, int in_dtype, const void* w_video, const void* w_text, int ldw_video,
-                                     int ldw_text, const float* bias_video,
-                                     const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream) {
+template <bool WF>
+static int project_pack_any(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text,
+                            int Din_video, int Din_text, int in_dtype, const void* w_video, const void* w_text, int ldw_video,
+                            int ldw_text, const float* bias_video, const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream) {
     if (!plan || !x_video || !x_text || !w_video || !w_text || !xhat || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
 #ifdef CROSSCLR_NO_FAST
     return fail(CROSSCLR_E_ARG, "crossclr_project_pack needs the register-resident path");
 #else
-    if (plan->mode != CROSSCLR_MODE_BF16 || !plan->fast_path || plan->Dpad > 512)
-        return fail(CROSSCLR_E_ARG, "crossclr_project_pack: bf16 plans with D <= 512 only");
+    if (plan->mode != CROSSCLR_MODE_BF16 || !plan->fast_path || plan->Dpad > 1024)
+        return fail(CROSSCLR_E_ARG, "crossclr_project_pack: bf16 plans with D <= 1024 only");
     if (Din_video < 1 || Din_text < 1 || ld_video < Din_video || ld_text < Din_text) return fail(CROSSCLR_E_ARG, "row stride smaller than Din");
     if (ldw_video % 64 != 0 || ldw_video < Din_video || ldw_text % 64 != 0 || ldw_text < Din_text)
         return fail(CROSSCLR_E_ARG, "weights must be zero-padded to ldw = a multiple of 64 >= Din (got %d / %d for Din %d / %d)", ldw_video, ldw_text, Din_video, Din_text);
     switch (in_dtype) {
-        case CROSSCLR_IN_F32: return project_pack_t<float>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F64: return project_pack_t<double>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F16: return project_pack_t<in_f16>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_BF16: return project_pack_t<in_bf16>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F32: return project_pack_t<float, WF>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F64: return project_pack_t<double, WF>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F16: return project_pack_t<in_f16, WF>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_BF16: return project_pack_t<in_bf16, WF>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, w_video, w_text, ldw_video, ldw_text, bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
     }
     return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
 #endif
+}
+extern "C" int crossclr_project_pack(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text,
+                                     int Din_video, int Din_text, int in_dtype, const void* w_video, const void* w_text, int ldw_video,
+                                     int ldw_text, const float* bias_video,
+                                     const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream) {
+    return project_pack_any<false>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, in_dtype, w_video, w_text, ldw_video, ldw_text,
+                                   bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
+}
+extern "C" int crossclr_project_pack_wf(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text,
+                                        int Din_video, int Din_text, int in_dtype, const void* wf_video, const void* wf_text, int ldw_video,
+                                        int ldw_text, const float* bias_video,
+                                        const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream) {
+    return project_pack_any<true>(plan, x_video, x_text, ld_video, ld_text, Din_video, Din_text, in_dtype, wf_video, wf_text, ldw_video, ldw_text,
+                                  bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
 }
 
 extern "C" int crossclr_project_backward_prep(const crossclr_plan* plan, const float* g_video, const float* g_text, long ld_gv,

@@ -931,8 +931,12 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     const TIN* own = (mod == 0 ? video + (size_t)i * ldv : text + (size_t)i * ldt);
     const TIN* oth = (mod == 0 ? text + (size_t)i * ldt : video + (size_t)i * ldv);
     TIN* out = (mod == 0 ? gvideo + (size_t)i * ldgv : gtext + (size_t)i * ldgt);
+    // prenormalized == 2: the rows given ARE the unit vectors x^ = y / ||y|| (the packed operand of a fused projection) and inv_norm holds
+    // 1 / ||y||: the gradient w.r.t. y is wanted -- same formula with the rows taken as they are (no second division by the norm)
+    const bool unit_rows = prenormalized == 2;
     const double io = (double)inv_norm[mod * g.bpad + i];
-    const double ip = (double)inv_norm[(1 - mod) * g.bpad + i];
+    const double ip = unit_rows ? 1.0 : (double)inv_norm[(1 - mod) * g.bpad + i];
+    const double ix = unit_rows ? 1.0 : io;      // row as given -> unit row
     const float* grow = gbuf + ((size_t)mod * g.bpad + i) * g.Dpad;
     const size_t slice = (size_t)2 * g.bpad * g.Dpad;
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
@@ -940,7 +944,7 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
     // ||x|| < eps: x/eps, no projection term (inv_norm is stored as float: (float)1e12 = 999999995904); prenormalized rows:
     // the gradient is the one w.r.t. the unit vectors as given (inv_norm = 1, no projection)
-    const bool clamped = io >= 9.99e11 || prenormalized != 0;
+    const bool clamped = io >= 9.99e11 || prenormalized == 1;
     const double go = grad_out[0];
     if (g.D <= 256 * kRowCache) {
         double gh[kRowCache][4], xh[kRowCache][4];
@@ -957,7 +961,7 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     gh[k][j] = (d + j < g.D) ? ((double)sum[j] * sc - o[j] * ip * pc) : 0.0;
-                    xh[k][j] = x[j] * io;
+                    xh[k][j] = x[j] * ix;
                     dot += xh[k][j] * gh[k][j];
                 }
             }
@@ -983,12 +987,12 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
     double dot = 0.0;
     for (int d = lane; d < g.D; d += 64) {
         double ghd = graw(d) * sc - in_load(oth, d) * ip * pc;
-        dot += in_load(own, d) * io * ghd;
+        dot += in_load(own, d) * ix * ghd;
     }
     dot = wave_sum_f64(dot);
     for (int d = lane; d < g.D; d += 64) {
         double ghd = graw(d) * sc - in_load(oth, d) * ip * pc;
-        double x = in_load(own, d) * io;
+        double x = in_load(own, d) * ix;
         double v = clamped ? ghd : (ghd - x * dot);
         in_store(out, d, v * io * go);
     }
@@ -1007,13 +1011,15 @@ __global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf,
     if (i >= g.b) return;
     const TIN* pv = video + (size_t)i * ldv;
     const TIN* pt = text + (size_t)i * ldt;
+    const bool unit_rows = prenormalized == 2;      // (see bwd_finish_kernel: unit rows given, gradient w.r.t. the un-normalised vectors)
     const double iv = (double)inv_norm[i], it = (double)inv_norm[g.bpad + i];
+    const double ixv = unit_rows ? 1.0 : iv, ixt = unit_rows ? 1.0 : it;
     const float* grv = gbuf + (size_t)i * g.Dpad;
     const float* grt = gbuf + ((size_t)g.bpad + i) * g.Dpad;
     const size_t slice = (size_t)2 * g.bpad * g.Dpad;
     const double sc = (double)inv_tau / (2.0 * (double)Bglobal);
     const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
-    const bool clamped_v = iv >= 9.99e11 || prenormalized != 0, clamped_t = it >= 9.99e11 || prenormalized != 0;
+    const bool clamped_v = iv >= 9.99e11 || prenormalized == 1, clamped_t = it >= 9.99e11 || prenormalized == 1;
     const double go = grad_out[0];
     double ghv[kRowCache][4], ght[kRowCache][4], xv[kRowCache][4], xt[kRowCache][4];
     double dotv = 0.0, dott = 0.0;
@@ -1034,10 +1040,10 @@ __global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool in = d + j < g.D;
-                ghv[k][j] = in ? ((double)sv[j] * sc - c[j] * it * pc) : 0.0;
-                ght[k][j] = in ? ((double)st[j] * sc - a[j] * iv * pc) : 0.0;
-                xv[k][j] = a[j] * iv;
-                xt[k][j] = c[j] * it;
+                ghv[k][j] = in ? ((double)sv[j] * sc - c[j] * ixt * pc) : 0.0;
+                ght[k][j] = in ? ((double)st[j] * sc - a[j] * ixv * pc) : 0.0;
+                xv[k][j] = a[j] * ixv;
+                xt[k][j] = c[j] * ixt;
                 dotv += xv[k][j] * ghv[k][j];
                 dott += xt[k][j] * ght[k][j];
             }

@@ -15,9 +15,62 @@
 
 namespace crossclr {
 
-// grid = bpad / 64; 4 waves: wave w owns output columns [Dpad/4 * w, Dpad/4 * (w+1)) of all 64 rows and both modalities.
-// DKP = Dpad / 128 = 32-wide column fragments per wave (1..4: Dpad = 128 .. 512).
-template <typename TIN, int DKP>
+// 16 consecutive elements of an input row, fetched as RAW registers (16-byte loads where the row allows it) and converted to bf16 only when
+// they are committed to LDS -- so that the loads of K chunk c + 1 stay in flight behind the MFMAs of chunk c (a converting load would be
+// waited for on the spot: the first version of this kernel exposed one HBM latency per chunk and read bf16 inputs two bytes at a time).
+template <typename TIN> struct Raw16 {          // generic / fallback: converted on the spot (double inputs)
+    float e[16];
+    __device__ __forceinline__ void load(const TIN* row, int k, int Din, bool valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e[j] = (valid && k + j < Din) ? (float)in_load(row, k + j) : 0.f;
+    }
+    __device__ __forceinline__ float get(int j) const { return e[j]; }
+};
+template <> struct Raw16<float> {
+    f32x4 v[4];
+    __device__ __forceinline__ void load(const float* row, int k, int Din, bool valid) {
+        if (valid && k + 16 <= Din && (reinterpret_cast<uintptr_t>(row + k) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(row + k + 4 * q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j >> 2][j & 3] = (valid && k + j < Din) ? row[k + j] : 0.f;
+        }
+    }
+    __device__ __forceinline__ float get(int j) const { return v[j >> 2][j & 3]; }
+};
+template <int F16> struct Raw16Half {           // bf16 / fp16 inputs: two 16-byte loads
+    u32x4 v[2];
+    __device__ __forceinline__ void load(const unsigned short* row, int k, int Din, bool valid) {
+        if (valid && k + 16 <= Din && (reinterpret_cast<uintptr_t>(row + k) & 15) == 0) {
+            v[0] = *reinterpret_cast<const u32x4*>(row + k);
+            v[1] = *reinterpret_cast<const u32x4*>(row + k + 8);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const unsigned lo = (valid && k + j < Din) ? row[k + j] : 0u, hi = (valid && k + j + 1 < Din) ? row[k + j + 1] : 0u;
+                v[j >> 3][(j >> 1) & 3] = lo | (hi << 16);
+            }
+        }
+    }
+    __device__ __forceinline__ unsigned short bits(int j) const { return (unsigned short)(v[j >> 3][(j >> 1) & 3] >> (16 * (j & 1))); }
+};
+template <> struct Raw16<in_bf16> : Raw16Half<0> {
+    __device__ __forceinline__ void load(const in_bf16* row, int k, int Din, bool valid) { Raw16Half<0>::load(reinterpret_cast<const unsigned short*>(row), k, Din, valid); }
+    __device__ __forceinline__ float get(int j) const { return bf16_bits_to_f32(bits(j)); }
+};
+template <> struct Raw16<in_f16> : Raw16Half<1> {
+    __device__ __forceinline__ void load(const in_f16* row, int k, int Din, bool valid) { Raw16Half<1>::load(reinterpret_cast<const unsigned short*>(row), k, Din, valid); }
+    __device__ __forceinline__ float get(int j) const { in_f16 h; h.bits = bits(j); return (float)in_load(&h, 0); }
+};
+
+// grid = bpad / (32 RF); 4 waves: wave w owns output columns [Dpad/4 * w, Dpad/4 * (w+1)) of all 32 RF rows and both modalities.
+// DKP = Dpad / 128 = 32-wide column fragments per wave (1..4: Dpad = 128 .. 512 with RF = 2 row fragments = 64 rows per block;
+// 6 / 8: Dpad = 768 / 1024 with RF = 1 = 32 rows per block -- either way 2 x RF x DKP <= 16 accumulator tuples = 256 registers).
+// WF: the weights arrive FRAGMENT-MAJOR -- [Dpad / 32][ldw / 16][64 lanes][8 bf16], lane (l31, half) of record (d32, ks) holding
+// W[32 d32 + l31][16 ks + 8 half .. + 7] (rows beyond D zero) -- so that a wave's B fragment is ONE coalesced 1-KiB load instead of 64
+// scattered 16-byte pieces of 64 different weight rows (the row-major form costs the kernel 3x: the texture addresser, not the MFMA pipe).
+template <typename TIN, int DKP, int RF = 2, bool WF = false>
 __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, const TIN* xt, long ldv, long ldt, int Din_v, int Din_t,
                                                               const bf16_t* wv, const bf16_t* wt, int ldw_v, int ldw_t,
                                                               const float* bias_v, const float* bias_t, Geo g,
@@ -29,19 +82,22 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
     constexpr int A0 = 0;                   // [2 buffers][2 modalities][ATILE]
     constexpr int R0 = 4 * ATILE;           // reduction scratch: [3 quantities][4 waves][64 rows] floats
     constexpr int LDS_MAIN = R0 + 3 * 4 * 64 * 4;
-    constexpr int OUT_BYTES = 2 * 64 * DP * 2;     // the packed rows of both modalities, staged for coalesced stores
+    constexpr int ROWS = 32 * RF;           // rows per block
+    constexpr int OUT_BYTES = 2 * ROWS * DP * 2;   // the packed rows of both modalities, staged for coalesced stores
+    static_assert(2 * RF * DKP <= 16, "accumulators: 2 modalities x RF x DKP tuples of 16 registers");
+    static_assert(OUT_BYTES <= 160 * 1024, "LDS budget of the output staging");
     constexpr int LDS_BYTES = LDS_MAIN > OUT_BYTES ? LDS_MAIN : OUT_BYTES;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int row0 = blockIdx.x * 64;
+    const int row0 = blockIdx.x * ROWS;
 
-    f32x16 acc[2][2][CF];
+    f32x16 acc[2][RF][CF];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int rf = 0; rf < 2; ++rf)
+        for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
             for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
@@ -49,60 +105,65 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
 
     // staging role: row srow, 16 consecutive k from 16 * spair
     const int srow = tid >> 2, spair = tid & 3;
-    auto stage = [&](int kc, int buf) {
+    Raw16<TIN> raw[2];
+    const bool srow_valid = row0 + srow < g.b && srow < ROWS;
+    auto fetch = [&](int kc) {          // raw loads only: nothing here waits for them
+        raw[0].load(xv + (size_t)(row0 + srow) * ldv, kc + 16 * spair, Din_v, srow_valid);
+        raw[1].load(xt + (size_t)(row0 + srow) * ldt, kc + 16 * spair, Din_t, srow_valid);
+    };
+    auto commit = [&](int buf) {        // convert, write the two 16-byte K-tile chunks of this thread's row
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const TIN* src = (m == 0 ? xv + (size_t)(row0 + srow) * ldv : xt + (size_t)(row0 + srow) * ldt);
             struct { bf16_t e[8]; } pk[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {       // 4 x 4 consecutive elements (16-byte loads where the row is fp32 and aligned)
-                double v4[4] = {0.0, 0.0, 0.0, 0.0};
-                if (row0 + srow < g.b) row_load4(src, kc + 16 * spair + 4 * q, m == 0 ? Din_v : Din_t, v4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pk[q >> 1].e[4 * (q & 1) + j] = f32_to_bf16_bits((float)v4[j]);
-            }
+            for (int j = 0; j < 16; ++j) pk[j >> 3].e[j & 7] = f32_to_bf16_bits(raw[m].get(j));
             unsigned char* tile = lds + A0 + (buf * 2 + m) * ATILE;
             *reinterpret_cast<u32x4*>(tile + ktile_off(srow, 2 * spair)) = __builtin_bit_cast(u32x4, pk[0]);
             *reinterpret_cast<u32x4*>(tile + ktile_off(srow, 2 * spair + 1)) = __builtin_bit_cast(u32x4, pk[1]);
         }
     };
     const int nchunks = ((Din_v > Din_t ? Din_v : Din_t) + KC - 1) / KC;     // (the shorter modality multiplies zeros in its last chunks)
-    stage(0, 0);
+    fetch(0);
+    commit(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) stage((c + 1) * KC, buf ^ 1);     // (the other buffer: its readers finished before the last barrier)
+        if (c + 1 < nchunks) fetch((c + 1) * KC);     // in flight behind this chunk's MFMAs
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 a[2][2], b[2][CF];
+            bf16x8 a[2][RF], b[2][CF];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const unsigned char* tile = lds + A0 + (buf * 2 + m) * ATILE;
 #pragma unroll
-                for (int rf = 0; rf < 2; ++rf) a[m][rf] = Operand<bf16_t>::load(tile, 32 * rf + l31, ks, half);
+                for (int rf = 0; rf < RF; ++rf) a[m][rf] = Operand<bf16_t>::load(tile, 32 * rf + l31, ks, half);
                 const bf16_t* w = m == 0 ? wv : wt;
                 const int ldw = m == 0 ? ldw_v : ldw_t;
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf) {
                     const int d = CF * 32 * wave + 32 * cf + l31;
                     const int k = c * KC + 16 * ks + 8 * half;             // (the weights are zero-padded to a multiple of 64 columns)
-                    if (d < g.D && k < ldw) b[m][cf] = *reinterpret_cast<const bf16x8*>(w + (size_t)d * ldw + k);
+                    if constexpr (WF) {
+                        if (k < ldw) b[m][cf] = *reinterpret_cast<const bf16x8*>(w + (((size_t)(CF * wave + cf) * (ldw / 16) + (c * 4 + ks)) * 64 + lane) * 8);
+                        else b[m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+                    } else if (d < g.D && k < ldw) b[m][cf] = *reinterpret_cast<const bf16x8*>(w + (size_t)d * ldw + k);
                     else b[m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
                 }
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int rf = 0; rf < 2; ++rf)
+                for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
                     for (int cf = 0; cf < CF; ++cf) acc[m][rf][cf] = mfma_32x32x16_bf16(a[m][rf], b[m][cf], acc[m][rf][cf]);
         }
+        if (c + 1 < nchunks) commit(buf ^ 1);          // (the other buffer: its readers finished before the last barrier)
         __syncthreads();
     }
     // ---- bias, row statistics: lane (l31, half) holds column d = CF*32*wave + 32 cf + l31 of rows 32 rf + frag_row(r, half) ----
     float* red = reinterpret_cast<float*>(lds + R0);
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf) {
+    for (int rf = 0; rf < RF; ++rf) {
         float ssv[16], sst[16], dot[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ssv[r] = sst[r] = dot[r] = 0.f;
@@ -127,9 +188,9 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
         }
     }
     __syncthreads();
-    float iv[2][16], it[2][16];
+    float iv[RF][16], it[RF][16];
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf)
+    for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * rf + frag_row(r, half);
@@ -140,9 +201,9 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
             iv[rf][r] = valid ? 1.f / (nv > 1e-12f ? nv : 1e-12f) : 0.f;     // x / max(||x||, eps), eps = 1e-12 (F.normalize default)
             it[rf][r] = valid ? 1.f / (nt > 1e-12f ? nt : 1e-12f) : 0.f;
         }
-    if (wave == 0 && l31 == 0) {      // lanes 0 and 32 of wave 0 cover the 64 rows between them (16 rows per fragment and half)
+    if (wave == 0 && l31 == 0) {      // lanes 0 and 32 of wave 0 cover the block's rows between them (16 rows per fragment and half)
 #pragma unroll
-        for (int rf = 0; rf < 2; ++rf)
+        for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * rf + frag_row(r, half);
@@ -156,19 +217,19 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
     // ---- unit rows -> bf16 -> LDS [modality][row][Dpad] -> 16-byte coalesced stores ----
     bf16_t* outl = reinterpret_cast<bf16_t*>(lds);
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf)
+    for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
         for (int cf = 0; cf < CF; ++cf) {
             const int d = CF * 32 * wave + 32 * cf + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * rf + frag_row(r, half);
-                outl[(0 * 64 + row) * DP + d] = f32_to_bf16_bits(d < g.D ? acc[0][rf][cf][r] * iv[rf][r] : 0.f);
-                outl[(1 * 64 + row) * DP + d] = f32_to_bf16_bits(d < g.D ? acc[1][rf][cf][r] * it[rf][r] : 0.f);
+                outl[(0 * ROWS + row) * DP + d] = f32_to_bf16_bits(d < g.D ? acc[0][rf][cf][r] * iv[rf][r] : 0.f);
+                outl[(1 * ROWS + row) * DP + d] = f32_to_bf16_bits(d < g.D ? acc[1][rf][cf][r] * it[rf][r] : 0.f);
             }
         }
     __syncthreads();
-    constexpr int PIECES = 2 * 64 * DP * 2 / 16;     // 16-byte pieces of the staged rows
+    constexpr int PIECES = 2 * ROWS * DP * 2 / 16;   // 16-byte pieces of the staged rows
     for (int i = tid; i < PIECES; i += 256) {
         const int m = i / (PIECES / 2), rem = i - m * (PIECES / 2);
         const int row = rem / (DP / 8), pc = rem - row * (DP / 8);

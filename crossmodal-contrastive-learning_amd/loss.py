@@ -502,7 +502,7 @@ def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
                   compute_mode: str, group, negative_scale=None, loss_weight=None,
                   save_for_backward: bool = False, prenormalized: bool = False, project=None) -> "tuple[torch.Tensor, _Workspace]":
-    """project = (w_video_bf16, w_text_bf16, (ldw_video, ldw_text), bias_video, bias_text, D): `video` / `text` are the projection head's INPUTS
+    """project = (w_video_bf16, w_text_bf16 [fragment-major: projection._weights_bf16(w, Dpad)], (ldw_video, ldw_text), bias_video, bias_text, D): `video` / `text` are the projection head's INPUTS
     [b, Din]; the packed operand comes from crossclr_project_pack (projection + L2-norm + pack in one launch) instead of
     crossclr_normalize, and the step behaves like prenormalized=True from there on (projection.py)."""
     import torch.distributed as dist
@@ -565,13 +565,18 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     ws.prenormalized = bool(prenormalized) or project is not None
     ws.xf = ws.xf_all = None
     if project is not None:
-        if plan.fast_path != 1 or plan.Dpad > 512 or mode != nat.MODE_BF16:
-            raise RuntimeError("the fused projection needs the bf16 register-resident path (embed_dim <= 512)")
+        if plan.fast_path != 1 or plan.Dpad > 1024 or mode != nat.MODE_BF16:
+            raise RuntimeError("the fused projection needs the bf16 register-resident path (embed_dim <= 1024)")
         wv, wt, ldws, bias_v, bias_t, _ = project
         with _Range("crossclr.project_pack"):
-            nat.check(lib.crossclr_project_pack(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), video.shape[1], text.shape[1],
+            nat.check(lib.crossclr_project_pack_wf(pp, _ptr(video), _ptr(text), video.stride(0), text.stride(0), video.shape[1], text.shape[1],
                                                 ws.in_dtype, _ptr(wv), _ptr(wt), ldws[0], ldws[1], _ptr(bias_v), _ptr(bias_t), _ptr(ws.xhat),
                                                 _ptr(ws.inv_norm), _ptr(ws.diag), stream))
+            # the saved backward's fragment-major copy, re-laid from the packed rows (16 MiB at b = 8192, D = 512: a few microseconds
+            # against the ~10 % the fragment-major backward is faster by)
+            if save_for_backward and plan.xf_bytes > 0 and plan.stash_bytes > 0 and not small_tau and _use_xf(plan) and world == 1:
+                ws.xf = torch.empty(plan.xf_bytes, dtype=torch.uint8, device=dev)
+                nat.check(lib.crossclr_pack_xf_from_packed(pp, ws.xhat.data_ptr(), 1, ws.xf.data_ptr(), stream))
     else:
         # With a saved backward to follow (plan.xf_bytes > 0: bf16 register-resident path, D <= 512) the same launch also leaves the
         # unit rows in the fragment-major layout that backward loads straight into MFMA fragments (crossclr_backward_saved_xf).
@@ -938,7 +943,7 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         nat.check(lib.crossclr_backward_finish_p(pp, _ptr(gbuf), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
                                                  ws.in_dtype, _ptr(ws.inv_norm), ws.temperature, _sw(None, None, ws.lw),
                                                  _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0),
-                                                 1 if ws.prenormalized else 0, stream))
+                                                 int(ws.prenormalized), stream))    # 0 raw rows / 1 unit rows as given / 2 unit rows, gradient w.r.t. the un-normalised vectors (projection.py)
     return gv, gt
 
 

@@ -7,13 +7,13 @@ produced.  `ProjectedCrossCLR` owns those two layers and evaluates
 
 with the projection, the L2-normalisation of `trainer/loss.py:79-80` and the packing of the kernels' operand fused into ONE launch
 (`crossclr_project_pack`): the projected features never travel to HBM and back, and the separate normalize launch disappears.
-Backward: the loss kernels return the gradient w.r.t. the unit rows; `crossclr_project_backward_prep` applies the
-normalise-backward; the projection's own gradients (dW = g^T x, dx = g W, db = column sums) are plain library GEMMs.
-bf16 operands with fp32 accumulation (the BASELINE headline mode), embed_dim <= 512.
+Backward: the loss' finish kernel reads the packed bf16 unit rows and 1 / ||y|| and writes g_y = d(loss)/d(projected features) in bf16
+(normalise-backward and positive-pair term fused: `crossclr_backward_finish_p(prenormalized = 2)`); the projection's own gradients
+(dW = g_y^T x, dx = g_y W, db = column sums) are plain library GEMMs with bf16 operands and fp32 accumulation (hipBLASLt), against the
+bf16 weights the forward multiplied with (cast once per parameter version).
+bf16 operands with fp32 accumulation (the BASELINE headline mode), embed_dim <= 1024 (64 rows per block up to 512, 32 rows above).
 """
 from __future__ import annotations
-
-import ctypes
 
 import torch
 from torch import nn
@@ -22,13 +22,47 @@ from . import _native as nat
 from . import loss as L
 
 
-def _weights_bf16(w: torch.Tensor) -> "tuple[torch.Tensor, int]":
-    """nn.Linear weight [D, Din] -> bf16 [D, ldw], columns zero-padded to a multiple of 64 (the kernel's K chunk)."""
+_weight_cache: dict = {}      # (id(weight), form) -> (data_ptr, _version, device, Dpad, copy, ldw): re-cast only when the parameter changed
+
+
+def _weights_bf16(w: torch.Tensor, Dpad: int = 0) -> "tuple[torch.Tensor, int]":
+    """nn.Linear weight [D, Din] as the kernels want it, columns zero-padded to ldw = a multiple of 64 (the kernel's K chunk).
+    Dpad = 0: bf16 [D, ldw] row-major (the backward's dx = g_y W GEMM; `crossclr_project_pack`).
+    Dpad > 0: FRAGMENT-MAJOR for `crossclr_project_pack_wf` -- [Dpad / 32][ldw / 16][64][8], lane (l31, half) of record (d32, ks) holding
+    W[32 d32 + l31][16 ks + 8 half .. + 7], rows beyond D zero: a wave's MFMA B fragment is one coalesced 1-KiB load.
+    Cached per parameter VERSION (gradient accumulation, evaluation and the backward of the same step reuse the copy; an optimiser step
+    bumps `_version` and the next forward casts again)."""
+    key = (id(w), Dpad > 0)
+    hit = _weight_cache.get(key)
+    if hit is not None and hit[0] == w.data_ptr() and hit[1] == w._version and hit[2] == w.device and hit[3] == Dpad and hit[4].numel() >= w.numel():
+        return hit[4], hit[5]
     D, Din = w.shape
     ldw = (Din + 63) // 64 * 64
-    out = torch.zeros(D, ldw, dtype=torch.bfloat16, device=w.device)
-    out[:, :Din] = w.detach()
+    if Dpad > 0:
+        pad = torch.zeros(Dpad, ldw, dtype=torch.bfloat16, device=w.device) if (Dpad != D or ldw != Din) else None
+        if pad is None:
+            pad = w.detach().to(torch.bfloat16)
+        else:
+            pad[:D, :Din].copy_(w.detach())
+        out = pad.view(Dpad // 32, 32, ldw // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    elif ldw == Din:
+        out = w.detach().to(torch.bfloat16).contiguous()
+    else:
+        out = torch.empty(D, ldw, dtype=torch.bfloat16, device=w.device)
+        out[:, :Din].copy_(w.detach())
+        out[:, Din:].zero_()
+    if len(_weight_cache) > 32:
+        _weight_cache.clear()
+    _weight_cache[key] = (w.data_ptr(), w._version, w.device, Dpad, out, ldw)
     return out, ldw
+
+
+def _mm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bf16 x bf16 library GEMM with fp32 accumulation; fp32 result where this torch build offers it (the sum over the batch in dW)."""
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return torch.mm(a, b)
 
 
 class _ProjectedFunction(torch.autograd.Function):
@@ -36,8 +70,9 @@ class _ProjectedFunction(torch.autograd.Function):
     def forward(ctx, xv, xt, wv, bv, wt, bt, temperature, negative_w, group):
         xv_c, xt_c = L._row_major(xv.detach()), L._row_major(xt.detach())
         needs = any(ctx.needs_input_grad[:6])
-        wvb, ldw = _weights_bf16(wv)
-        wtb, ldw_t = _weights_bf16(wt)
+        Dpad = L._plan_for(xv.shape[0], wv.shape[0], 1, 0, nat.MODE_BF16).Dpad
+        wvb, ldw = _weights_bf16(wv, Dpad)          # fragment-major (crossclr_project_pack_wf)
+        wtb, ldw_t = _weights_bf16(wt, Dpad)
         bvf = None if bv is None else bv.detach().float().contiguous()
         btf = None if bt is None else bt.detach().float().contiguous()
         with L._device_of(xv_c):
@@ -45,39 +80,33 @@ class _ProjectedFunction(torch.autograd.Function):
                                        project=(wvb, wtb, (ldw, ldw_t), bvf, btf, wv.shape[0]))
         ctx.ws = ws
         ctx.save_for_backward(xv_c, xt_c, wv.detach(), wt.detach())
-        ctx.has_bias = (bv is not None, bt is not None)
+        ctx.bias_dtype = (None if bv is None else bv.dtype, None if bt is None else bt.dtype)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         L._refuse_double_backward("ProjectedCrossCLR")
         xv, xt, wv, wt = ctx.saved_tensors
-        ws, lib = ctx.ws, nat.library()
+        ws = ctx.ws
         plan = ws.plan
         b, D, bpad, Dpad = plan.b, plan.D, plan.bpad, plan.Dpad
-        dev = xv.device
         with L._device_of(xv):
-            # the unit rows in fp32 (the positive-pair term of the gradient is the PARTNER's unit row)
+            # The finish kernel reads the packed bf16 unit rows themselves -- own row for the normalise-backward, partner's row for the
+            # positive-pair term -- with 1 / ||y|| from the forward, and writes g_y = d(loss)/d(projected features) in bf16
+            # (prenormalized = 2): no fp32 copies of the unit rows, no separate normalise-backward pass.
             packed = ws.xhat.view(torch.bfloat16).view(2, bpad, Dpad)
-            yv, yt = packed[0, :b, :D].float(), packed[1, :b, :D].float()
-            ws.in_dtype = nat.IN_F32
-            # the finish kernel's "rows as given" are these unit rows: its inv_norm array must read all ones (as crossclr_pack
-            # would have left it); the real 1 / ||y|| goes into the normalise-backward below
-            inv_norm, ws.inv_norm = ws.inv_norm, torch.ones_like(ws.inv_norm)
-            gv, gt = L._backward_impl(ws, yv, yt, grad_out)        # d(loss) / d(unit rows)   (ws.prenormalized is set)
-            ws.inv_norm = inv_norm
-            gyv, gyt = torch.empty_like(gv), torch.empty_like(gt)
-            nat.check(lib.crossclr_project_backward_prep(ctypes.byref(plan), L._ptr(gv), L._ptr(gt), gv.stride(0), gt.stride(0),
-                                                         L._ptr(ws.xhat), L._ptr(ws.inv_norm), L._ptr(gyv), L._ptr(gyt), gyv.stride(0),
-                                                         L._stream_for(xv)))
+            ws.in_dtype = nat.IN_BF16
+            ws.prenormalized = 2
+            gyv, gyt = L._backward_impl(ws, packed[0, :b, :D], packed[1, :b, :D], grad_out)
+            # the projection's own gradients: bf16 operands, fp32 accumulation (plain library GEMMs -- hipBLASLt)
             need = ctx.needs_input_grad
-            xvf, xtf = xv.float(), xt.float()
-            dxv = (gyv @ wv.float()).to(xv.dtype) if need[0] else None
-            dxt = (gyt @ wt.float()).to(xt.dtype) if need[1] else None
-            dwv = (gyv.t() @ xvf).to(wv.dtype) if need[2] else None
-            dwt = (gyt.t() @ xtf).to(wt.dtype) if need[4] else None
-            dbv = gyv.sum(0) if (need[3] and ctx.has_bias[0]) else None
-            dbt = gyt.sum(0) if (need[5] and ctx.has_bias[1]) else None
+            bf = torch.bfloat16
+            dxv = torch.mm(gyv, _weights_bf16(wv)[0][:, :wv.shape[1]]).to(xv.dtype) if need[0] else None     # (the bf16 values the forward multiplied with)
+            dxt = torch.mm(gyt, _weights_bf16(wt)[0][:, :wt.shape[1]]).to(xt.dtype) if need[1] else None
+            dwv = _mm_f32(gyv.t(), xv if xv.dtype == bf else xv.to(bf)).to(wv.dtype) if need[2] else None
+            dwt = _mm_f32(gyt.t(), xt if xt.dtype == bf else xt.to(bf)).to(wt.dtype) if need[4] else None
+            dbv = torch.sum(gyv, 0, dtype=torch.float32).to(ctx.bias_dtype[0]) if (need[3] and ctx.bias_dtype[0] is not None) else None
+            dbt = torch.sum(gyt, 0, dtype=torch.float32).to(ctx.bias_dtype[1]) if (need[5] and ctx.bias_dtype[1] is not None) else None
         return dxv, dxt, dwv, dbv, dwt, dbt, None, None, None
 
 

@@ -300,6 +300,9 @@ int crossclr_backward_ranks(const crossclr_plan* plan, const void* xhat_rows, co
  * loss.py:79-80 is not repeated: crossclr_pack only casts / lays the rows out as the packed operand (inv_norm := 1) and forms
  * the fp32 positive-pair cosine; crossclr_backward_finish_p with prenormalized = 1 returns d(loss)/d(the unit rows as given)
  * -- no projection, no 1/||x|| -- so that the producer's own normalise-backward (autograd of F.normalize upstream) applies.
+ * prenormalized = 2: the rows given are the unit vectors (e.g. the packed bf16 operand itself: video = X[0], text = X[1], ld = Dpad,
+ * in_dtype bf16) and inv_norm holds 1 / ||y|| of the vectors they came from: returns d(loss)/dy = (G - xhat (xhat . G)) / ||y|| in the rows'
+ * dtype -- the normalise-backward of a fused projection head without a separate pass (crossclr_project_pack below).
  * A producer that writes X[2][bpad][Dpad] itself in the plan's element type skips crossclr_pack's copy and only needs
  * diag_cos[i] = vhat_i . that_i.                                                                                       */
 int crossclr_pack(const crossclr_plan* plan, const void* video_hat, const void* text_hat, long ld_video, long ld_text,
@@ -311,7 +314,7 @@ int crossclr_backward_finish_p(const crossclr_plan* plan, const float* gbuf,
                                const double* grad_out, void* grad_video, void* grad_text,
                                long ld_gvideo, long ld_gtext, int prenormalized, void* stream);
 
-/* ---- producer-side fusion: projection head + L2-norm + pack in one launch (bf16 plans, Dpad <= 512) ----
+/* ---- producer-side fusion: projection head + L2-norm + pack in one launch (bf16 plans, Dpad <= 1024) ----
  * /root/reference/README.md:24-38 feeds the criterion "features: [bsz, f_dim]" that a projection layer produced; this entry point IS
  * that layer's forward fused with trainer/loss.py:79-80:   y_m = x_m W_m^T + b_m;   xhat_m = y_m / max(||y_m||, 1e-12)
  *   x_video / x_text  [b, Din_video] / [b, Din_text] row-major (row strides in elements), any supported in_dtype
@@ -319,12 +322,19 @@ int crossclr_backward_finish_p(const crossclr_plan* plan, const float* gbuf,
  *   bias_*            fp32 [D] or NULL
  * writes the packed operand, inv_norm[2][bpad] (= 1 / ||y||) and the fp32 positive-pair cosines diag_cos[bpad] exactly as
  * crossclr_normalize does -- everything downstream (forward, backward, crossclr_backward_finish_p with prenormalized = 1) is unchanged.
+ * Backward: crossclr_backward_finish_p(prenormalized = 2) on the packed operand returns g_y directly (bf16); the older two-step form --
  * crossclr_project_backward_prep turns the gradient w.r.t. the unit rows (what crossclr_backward_finish_p(prenormalized = 1) returns)
  * into the gradient w.r.t. y:  g_y = (G - xhat (xhat . G)) / ||y||, fp32 [b, D] per modality; the projection's own backward
  * (dW = g_y^T x, dx = g_y W, db = column sums) is two plain GEMMs on the caller's side.                                          */
 int crossclr_project_pack(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text, int Din_video,
                           int Din_text, int in_dtype, const void* w_video, const void* w_text, int ldw_video, int ldw_text, const float* bias_video,
                           const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream);
+/* The same launch with the weights FRAGMENT-MAJOR (what the host module passes): wf_* = bf16 [Dpad / 32][ldw / 16][64][8], lane
+ * (l31 = lane & 31, half = lane >> 5) of record (d32, ks) holding W[32 d32 + l31][16 ks + 8 half .. + 7], rows beyond D and columns beyond
+ * Din zero -- a wave's MFMA B fragment is then ONE coalesced 1-KiB load instead of 64 scattered 16-byte pieces (3x on the MI355X).       */
+int crossclr_project_pack_wf(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text, int Din_video,
+                             int Din_text, int in_dtype, const void* wf_video, const void* wf_text, int ldw_video, int ldw_text,
+                             const float* bias_video, const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream);
 int crossclr_project_backward_prep(const crossclr_plan* plan, const float* g_video, const float* g_text, long ld_gv, long ld_gt,
                                    const void* xhat, const float* inv_norm, float* gy_video, float* gy_text, long ld_out,
                                    void* stream);

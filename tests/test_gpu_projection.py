@@ -48,7 +48,9 @@ def _reference(xv, xt, wv, bv, wt, bt, tau, w):
     return loss.item(), [a.grad if a is not None else None for a in args]
 
 
-@pytest.mark.parametrize("b,din_v,din_t,D,bias", [(2048, 768, 512, 512, True), (1000, 300, 200, 256, False), (512, 1024, 1024, 128, True)])
+@pytest.mark.parametrize("b,din_v,din_t,D,bias", [(2048, 768, 512, 512, True), (1000, 300, 200, 256, False), (512, 1024, 1024, 128, True),
+                                                  (1024, 512, 300, 768, True), (2048, 1024, 768, 1024, False),     # 32 rows per block
+                                                  (4096, 512, 512, 512, True)])    # the fragment-major pair backward behind the projection
 def test_fused_projection_matches_float64_autograd(b, din_v, din_t, D, bias, monkeypatch):
     g = torch.Generator().manual_seed(b + D)
     xv, xt = torch.randn(b, din_v, generator=g), torch.randn(b, din_t, generator=g)
@@ -63,6 +65,8 @@ def test_fused_projection_matches_float64_autograd(b, din_v, din_t, D, bias, mon
         raise AssertionError("crossclr_normalize was launched on the fused-projection path")
     monkeypatch.setattr(lib, "crossclr_normalize", boom, raising=False)
     monkeypatch.setattr(lib, "crossclr_pack", boom, raising=False)
+    # ... nor the two-step normalise-backward: the finish kernel writes g_y itself (prenormalized = 2)
+    monkeypatch.setattr(lib, "crossclr_project_backward_prep", boom, raising=False)
     loss = crossclr_amd.projected_crossclr_loss(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], leaves[5], 0.03, 0.8)
     loss.backward()
     torch.cuda.synchronize()

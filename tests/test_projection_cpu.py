@@ -25,7 +25,8 @@ def reference(xv, xt, wv, bv, wt, bt, tau, w):
     return loss.item(), [a.grad if a is not None else None for a in args]
 
 
-@pytest.mark.parametrize("b,din_v,din_t,D,bias", [(40, 24, 40, 32, True), (70, 64, 100, 48, False), (130, 30, 30, 200, True)])
+@pytest.mark.parametrize("b,din_v,din_t,D,bias", [(40, 24, 40, 32, True), (70, 64, 100, 48, False), (130, 30, 30, 200, True),
+                                                  (40, 64, 24, 600, True)])      # Dpad = 768: 32 rows per block
 def test_fused_projection_matches_float64_autograd(b, din_v, din_t, D, bias):
     g = torch.Generator().manual_seed(b + D)
     xv, xt = torch.randn(b, din_v, generator=g), torch.randn(b, din_t, generator=g)
@@ -87,3 +88,12 @@ def test_packed_operand_equals_normalize_of_the_projection():
     packed = xhat.view(torch.bfloat16).view(2, plan.bpad, plan.Dpad)
     assert (packed[0, :b, :D].double() - F.normalize(yv, dim=1)).abs().max().item() < 2e-2
     assert float(packed[:, b:, :].abs().max()) == 0.0 and float(packed[:, :, D:].abs().max()) == 0.0
+    # the same launch with FRAGMENT-MAJOR weights (crossclr_project_pack_wf: what the module passes): the same bits
+    wvf, _ = _weights_bf16(wv, plan.Dpad)
+    wtf, _ = _weights_bf16(wt, plan.Dpad)
+    assert wvf.numel() == plan.Dpad * ldw
+    xhat2 = torch.empty_like(xhat)
+    inv2, diag2 = torch.empty_like(inv), torch.empty_like(diag)
+    nat.check(lib.crossclr_project_pack_wf(ctypes.byref(plan), xv.data_ptr(), xt.data_ptr(), din, din, din, din, nat.IN_F32, wvf.data_ptr(), wtf.data_ptr(),
+                                           ldw, ldw, 0, 0, xhat2.data_ptr(), inv2.data_ptr(), diag2.data_ptr(), 0))
+    assert torch.equal(xhat, xhat2) and torch.equal(inv[:b], inv2[:b]) and torch.equal(diag[:b], diag2[:b])
