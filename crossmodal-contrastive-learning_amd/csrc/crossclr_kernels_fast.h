@@ -89,11 +89,17 @@ __device__ __forceinline__ void lds_dma16_buf(const BufRsrc& b, unsigned voff, u
 __device__ __forceinline__ void lds_dma4_buf(const BufRsrc& b, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, (int)voff, (int)soff, 0, 0);
 }
-// (aux = 2: non-temporal.  The only user is the forward's stash of saved exponentials -- 0.27 GB written once and read by the backward
-//  much later; streaming stores keep it from evicting the column tiles out of L2: forward_save -2 % (0.1535 -> 0.1506 ms, A/B in one
-//  process).  The same hint on the backward's stash LOADS costs +3.7 %: every tile is read twice.)
+// (The only user is the forward's stash of saved exponentials -- 0.27 GB written once and read by the backward much later.  Round 3: aux = 2
+//  (non-temporal), -2 %.  Round 4: sc1 | nt -- the line is DROPPED from the XCD's L2 once written (MI355X_MICROARCH.md, stores of each
+//  flavour): with plain or nt stores every XCD pushes 0.5 MB of stash lines through its 4-MiB L2 per tile interval and a column tile
+//  survives ~8 tiles; with sc1 the L2 belongs to the column tiles, which is what makes the XCD-aware range placement (fwd_make_perm) work:
+//  FETCH_SIZE 224 -> 71 MB per launch, forward_save -7 % (profiles/r04_ab_fwd_xcd*.txt; sc1 alone: the same counters, ~1 % slower).
+//  The nt hint on the backward's stash LOADS costs +3.7 %: every tile is read twice.)
+#ifndef CROSSCLR_STASH_AUX
+#define CROSSCLR_STASH_AUX 18      // cache policy of the stash stores: 2 = nt, 16 = sc1, 18 = sc1 | nt (A/B: tools/ab_fwd_xcd.sh)
+#endif
 __device__ __forceinline__ void buf_store16(const BufRsrc& b, unsigned voff, unsigned soff, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, CROSSCLR_STASH_AUX);
 }
 __device__ __forceinline__ void buf_store4(const BufRsrc& b, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff, (int)soff, 0);
@@ -824,8 +830,25 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
     unsigned char* st = (unsigned char*)stash;
     dim3 grid(wk.nblk), block(256);
     const bool sw = krows != nullptr && kcols != nullptr;
+    // XCD-aware placement of the ranges (crossclr_device.h: fwd_make_perm), computed once per work list and thread
+    static const bool xcd_aware = [] { const char* e = getenv("CROSSCLR_FWD_XCD"); return !(e && e[0] == '0'); }();
+    static thread_local struct { FwdWork wk; FwdPerm perm; bool valid; } pcache[4];
+    static thread_local int pnext = 0;
+    const FwdPerm* permp = nullptr;
+    for (int i = 0; i < 4; ++i)
+        if (pcache[i].valid && memcmp(&pcache[i].wk, &wk, sizeof(FwdWork)) == 0) { permp = &pcache[i].perm; break; }
+    if (!permp) {
+        auto& e = pcache[pnext];
+        pnext = (pnext + 1) & 3;
+        memset(&e.wk, 0, sizeof(FwdWork));
+        e.wk = wk;
+        fwd_make_perm(wk, xcd_aware, &e.perm);
+        e.valid = true;
+        permp = &e.perm;
+    }
+    const FwdPerm perm = *permp;
 #define CROSSCLR_LP3(DK, KIND, SW, ST) \
-    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st)
+    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st, perm)
 #define CROSSCLR_LP2(DK, KIND)                                   \
     do {                                                          \
         if (sw && st) CROSSCLR_LP3(DK, KIND, true, true);         \
@@ -840,7 +863,7 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
         else CROSSCLR_LP2(DK, 3);                        \
     } while (0)
 #define CROSSCLR_LPW3(DK, KIND, SW, ST) \
-    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST, 1>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st)
+    CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST, 1>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st, perm)
 #define CROSSCLR_LPW2(DK, KIND)                                   \
     do {                                                           \
         if (sw && st) CROSSCLR_LPW3(DK, KIND, true, true);         \

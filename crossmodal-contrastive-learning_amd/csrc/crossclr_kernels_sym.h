@@ -26,7 +26,7 @@ namespace crossclr {
 template <int DK, int KIND, bool SW, bool ST, int NH = 2>
 __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, const bf16_t* xc, Geo g, FwdWork wk, float* part,
                                                                float* colpart, int* header, const float* ks, const float* kc,
-                                                               unsigned char* stash) {
+                                                               unsigned char* stash, FwdPerm perm) {
     static_assert(KIND >= 1 && KIND <= 3, "1 symmetric, 2 rectangular, 3 pairs");
     constexpr int RB = DK * 32;            // bytes per operand row
     constexpr int QT = 32;
@@ -52,8 +52,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
     const int per_rank = 2 * g.bpad / QT, per_mod = g.bpad / QT;
     const int skip_seg = (KIND == 2 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
 
-    int w = fwd_block_begin(wk, blockIdx.x);                // (ranges of equal cost, not of equal length: FwdWork)
-    const int w_end = fwd_block_begin(wk, blockIdx.x + 1);
+    // the work range of this block (XCD-aware placement: fwd_make_perm; everything below is indexed by the RANGE, not by blockIdx)
+    const int vb = uniform(blockIdx.x < 256 ? (int)perm.v[blockIdx.x < 256 ? blockIdx.x : 0] : (int)blockIdx.x);
+    int w = fwd_block_begin(wk, vb);                        // (ranges of equal cost, not of equal length: FwdWork)
+    const int w_end = fwd_block_begin(wk, vb + 1);
     if (w >= w_end) return;                                 // (a trailing range that holds no item's first unit)
     // item = (row block rb, index j inside its tile list); mt = the tile's index inside the column operand (DMA / statistics
     // address), seg / in_seg = its rank segment and position inside the segment (modality, ragged test) -- tracked
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pipe_kernel(const bf16_t* x, 
 #pragma unroll
         for (int s = 0; s < NH; ++s) {
             const float v = rowacc[s] + wave_xor_f32(rowacc[s], 32);
-            if (half == 0) part[(size_t)(blockIdx.x - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + 32 * s + l31] = v;
+            if (half == 0) part[(size_t)(vb - fwd_first_block(wk, my_rb)) * 2 * g.bpad + row0w + 32 * s + l31] = v;
         }
     };
     // ---- the tile whose epilogue is still owed ----

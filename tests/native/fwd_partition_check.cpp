@@ -41,6 +41,34 @@ static int check(int kind, int bpad, int usable, int max_blocks, int tpr, bool v
     for (int b = 0; b < w.nblk; ++b) { sum += cost[b]; if (cost[b] > worst) worst = cost[b]; }
     const double mean = (double)sum / w.nblk;
     if (verbose) printf("kind %d bpad %5d tpr %d blocks %3d per %4d slots %2d: heaviest range %ld units, mean %.1f\n", kind, bpad, tpr, w.nblk, w.per, slots, worst, mean);
+    // XCD-aware placement (fwd_make_perm): a bijection of the ranges; the identity when switched off; and at the headline size the
+    // blocks of one XCD (b % 8) start within a few hundred column tiles of each other -- their column tiles share that XCD's L2
+    {
+        FwdPerm pm, id;
+        fwd_make_perm(w, true, &pm);
+        fwd_make_perm(w, false, &id);
+        const int n = w.nblk < 256 ? w.nblk : 256;
+        std::vector<int> seen(256, 0);
+        for (int b = 0; b < 256; ++b) { if (id.v[b] != b) ++bad; if (b < n) { if (pm.v[b] >= n) ++bad; else ++seen[pm.v[b]]; } else if (pm.v[b] != b) ++bad; }
+        if (w.nblk <= 256) for (int c = 0; c < n; ++c) if (seen[c] != 1) { printf("kind %d bpad %d: range %d placed %d times\n", kind, bpad, c, seen[c]); ++bad; }
+        if (kind == 1 && w.nblk == 256 && bpad >= 4096) {
+            int worst_span = 0;
+            for (int x = 0; x < 8; ++x) {
+                int lo = 1 << 30, hi = -1;
+                for (int b = x; b < 256; b += 8) {
+                    const int w0 = begin[pm.v[b]];
+                    if (w0 >= w.total) continue;
+                    int rb = 0;
+                    while (fwd_prefix(w, rb + 1) <= w0) ++rb;
+                    const int col = w.tpr * rb + (w0 - fwd_prefix(w, rb));
+                    lo = col < lo ? col : lo; hi = col > hi ? col : hi;
+                }
+                worst_span = hi - lo > worst_span ? hi - lo : worst_span;
+            }
+            if (verbose) printf("   XCD-aware placement: widest spread of start columns inside one XCD = %d of %d tiles\n", worst_span, w.NT);
+            if (worst_span > w.NT / 2) { printf("kind 1 bpad %d: an XCD's ranges start %d column tiles apart\n", bpad, worst_span); ++bad; }
+        }
+    }
     if (kind == 1 && w.nblk >= 8 && worst > mean + 6) { printf("kind 1 bpad %d: heaviest range %ld vs mean %.1f\n", bpad, worst, mean); ++bad; }
     return bad;
 }

@@ -19,7 +19,7 @@ SRC = r'''
 #include "crossclr_kernels_fast.h"
 namespace crossclr {
 #define BSIG (const bf16_t*, const unsigned char*, Geo, const float*, const float*, const float*, const float*, float*, int, int, const float*, const float*)
-#define FSIG (const bf16_t*, const bf16_t*, Geo, FwdWork, float*, float*, int*, const float*, const float*, unsigned char*)
+#define FSIG (const bf16_t*, const bf16_t*, Geo, FwdWork, float*, float*, int*, const float*, const float*, unsigned char*, FwdPerm)
 template __global__ void fast_bwd_dsl_kernel<8, false, 0> BSIG;      // local block: bodies M->M, M->D, D->D
 template __global__ void fast_bwd_dsl_kernel<8, true, 1> BSIG;       // rectangular (segment walk = real branches), sample weights
 template __global__ void fast_bwd_dsl_kernel<8, false, 2> BSIG;      // transposed rectangular (partner gradients)
