@@ -180,13 +180,13 @@ def sustained_series(step, dev, nsteps, chunk=100):
 
 
 def secondary_lines(dev):
-    """Short driver-timed measurements of the other configurations (each a handful of steps, < 1 s together): HIP-event median of
+    """Short driver-timed measurements of the other configurations (12 warm + 12 timed steps each, ~1 s together): HIP-event median of
     the step, loss against the reference golden where one exists, algorithmic rate of the dominant kernel."""
     import crossclr_amd
     from crossclr_amd import _profile
     out = {}
 
-    def timed(fn, n=8, warm=3):
+    def timed(fn, n=12, warm=12):      # (warm: plan, allocator and the one-off self-test of a new kernel instantiation settle in the first steps)
         for _ in range(warm):
             fn()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]

@@ -113,6 +113,9 @@ _SIGNATURES = {
                                              _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
     "crossclr_project_pack_wf": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
+    "crossclr_project_dw_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "crossclr_project_dw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_long, _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P, _P, _P]),
     "crossclr_project_backward_prep": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, _P, _P, _P, _P,
                                                       ctypes.c_long, _P]),
     # ABI version 3: two-pass soft-max for small temperatures

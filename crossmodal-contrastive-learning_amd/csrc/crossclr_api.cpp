@@ -437,6 +437,50 @@ extern "C" int crossclr_project_pack_wf(const crossclr_plan* plan, const void* x
                                   bias_video, bias_text, xhat, inv_norm, diag_cos, stream);
 }
 
+// the projection's weight gradient: split-K MFMA kernel + reduce (crossclr_kernels_project.h)
+static int project_dw_splits(int b, int D, int Din_v, int Din_t) {
+    const int Dp = round_up(D, 128), Dinp = round_up(Din_v > Din_t ? Din_v : Din_t, 128);
+    const int tiles = 2 * (Dp / 128) * (Dinp / 128);
+    int ns = (512 + tiles - 1) / tiles;                     // two thread blocks per CU: one wave per SIMD alone hides no latency
+    const int max_by_rows = b / 64 > 1 ? b / 64 : 1;        // at least two 32-row chunks per split
+    if (ns > max_by_rows) ns = max_by_rows;
+    if (ns > 32) ns = 32;
+    return ns < 1 ? 1 : ns;
+}
+extern "C" size_t crossclr_project_dw_ws_floats(int b, int D, int Din_video, int Din_text) {
+    if (b < 1 || D < 1 || Din_video < 1 || Din_text < 1) return 0;
+    const size_t Dp = round_up(D, 128), Dinp = round_up(Din_video > Din_text ? Din_video : Din_text, 128);
+    const size_t ns = project_dw_splits(b, D, Din_video, Din_text);
+    return 2 * ns * Dp * Dinp + 2 * ns * Dp;
+}
+template <typename TIN>
+static int project_dw_t(int b, int D, const void* gyv, const void* gyt, long ldgy, const void* xv, const void* xt, long ldxv, long ldxt,
+                        int Din_v, int Din_t, float* ws, float* dwv, float* dwt, long lddwv, long lddwt, float* dbv, float* dbt, void* stream) {
+    const int Dp = round_up(D, 128), Dinp = round_up(Din_v > Din_t ? Din_v : Din_t, 128);
+    const int ns = project_dw_splits(b, D, Din_v, Din_t);
+    float* partial = ws;
+    float* dbpart = ws + (size_t)2 * ns * Dp * Dinp;
+    LAUNCH((project_dw_kernel<TIN>), dim3(2 * ns, Dp / 128, Dinp / 128), dim3(256), stream, (const in_bf16*)gyv, (const in_bf16*)gyt, ldgy,
+           (const TIN*)xv, (const TIN*)xt, ldxv, ldxt, b, D, Din_v, Din_t, ns, partial, Dp, Dinp, dbpart);
+    LAUNCH(project_dw_reduce_kernel, dim3((Dinp + 255) / 256, D, 2), dim3(256), stream, (const float*)partial, (const float*)dbpart, ns, D, Dp, Dinp,
+           Din_v, Din_t, dwv, dwt, lddwv, lddwt, dbv, dbt);
+    return launch_status("project_dw_kernel");
+}
+extern "C" int crossclr_project_dw(int b, int D, const void* gy_video, const void* gy_text, long ld_gy, const void* x_video, const void* x_text,
+                                   long ld_xv, long ld_xt, int Din_video, int Din_text, int in_dtype, float* ws, float* dw_video, float* dw_text,
+                                   long ld_dwv, long ld_dwt, float* db_video, float* db_text, void* stream) {
+    if (!gy_video || !gy_text || !x_video || !x_text || !ws || !dw_video || !dw_text) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (b < 1 || D < 1 || Din_video < 1 || Din_text < 1 || ld_gy < D || ld_xv < Din_video || ld_xt < Din_text || ld_dwv < Din_video || ld_dwt < Din_text)
+        return fail(CROSSCLR_E_ARG, "crossclr_project_dw: bad sizes / strides");
+    switch (in_dtype) {
+        case CROSSCLR_IN_F32: return project_dw_t<float>(b, D, gy_video, gy_text, ld_gy, x_video, x_text, ld_xv, ld_xt, Din_video, Din_text, ws, dw_video, dw_text, ld_dwv, ld_dwt, db_video, db_text, stream);
+        case CROSSCLR_IN_F64: return project_dw_t<double>(b, D, gy_video, gy_text, ld_gy, x_video, x_text, ld_xv, ld_xt, Din_video, Din_text, ws, dw_video, dw_text, ld_dwv, ld_dwt, db_video, db_text, stream);
+        case CROSSCLR_IN_F16: return project_dw_t<in_f16>(b, D, gy_video, gy_text, ld_gy, x_video, x_text, ld_xv, ld_xt, Din_video, Din_text, ws, dw_video, dw_text, ld_dwv, ld_dwt, db_video, db_text, stream);
+        case CROSSCLR_IN_BF16: return project_dw_t<in_bf16>(b, D, gy_video, gy_text, ld_gy, x_video, x_text, ld_xv, ld_xt, Din_video, Din_text, ws, dw_video, dw_text, ld_dwv, ld_dwt, db_video, db_text, stream);
+    }
+    return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+}
+
 extern "C" int crossclr_project_backward_prep(const crossclr_plan* plan, const float* g_video, const float* g_text, long ld_gv,
                                               long ld_gt, const void* xhat, const float* inv_norm, float* gy_video, float* gy_text,
                                               long ld_out, void* stream) {

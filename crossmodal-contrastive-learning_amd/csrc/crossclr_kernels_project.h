@@ -238,6 +238,172 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The projection's weight gradient on the chip's terms (round 4): dW_m[D][Din_m] = sum_i g_y,m[i][:]^T x_m[i][:]  (+ db_m = column sums of
+// g_y,m) for both modalities in ONE launch.  Both operands carry the contraction index (the batch row) as their ROW index, i.e. neither is in
+// MFMA operand order: 32-row chunks of both are staged row-major in LDS (pitch 288 bytes: the four rows of a transposing read fall into
+// disjoint bank groups) and every A / B fragment is two ds_read_b64_tr_b16.  The library GEMM this replaces (hipBLASLt's choice for a
+// [512 x 8192] x [8192 x 1024] product: 128 tiles of 64 x 64, no split-K, 59 us) leaves half the chip idle; here the batch is SPLIT over
+// blockIdx.z so that ~256+ thread blocks exist, each split writes its own fp32 partial (no atomics: deterministic) and
+// project_dw_reduce_kernel adds them in split order.
+//   grid = (2 * nsplit, Dp / 128, Dinp / 128); block = 4 waves as 2 x 2, wave tile 64 x 64 (4 accumulator tuples).
+//   gy: bf16 [b][ldgy]; x: TIN [b][ldx]; partial: [2][nsplit][Dp][Dinp] floats; dbpart: [2][nsplit][Dp] floats (written by the blocks
+//   of the first Din tile).
+// ---------------------------------------------------------------------------------------------
+constexpr int kDwPitch = 288;                    // bytes per staged row: 128 bf16 + 32 bytes of padding
+constexpr int kDwTile = 32 * kDwPitch;           // one operand chunk: 32 batch rows x 128 columns
+template <typename TIN>
+__global__ void __launch_bounds__(256) project_dw_kernel(const in_bf16* gyv, const in_bf16* gyt, long ldgy, const TIN* xv, const TIN* xt, long ldxv,
+                                                         long ldxt, int b, int D, int Din_v, int Din_t, int nsplit, float* partial, int Dp,
+                                                         int Dinp, float* dbpart) {
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[4 * kDwTile];      // [2 buffers][A | B]   (36 KiB; the db reduction reuses it)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wr = wave & 1, wc = wave >> 1;
+    // blockIdx.x = (modality, split): block b runs on XCD b % 8, so the thread blocks of one XCD share ONE split's batch rows -- the
+    // (Dp / 128) x (Dinp / 128) tiles of that split re-read the same 32-row chunks of g_y and x at about the same time, out of that XCD's L2
+    // (with the tile index fastest, every re-read went to the Infinity Cache: 400 MB per launch, bandwidth-bound at 67 us)
+    const int m = blockIdx.x / nsplit, split = blockIdx.x - m * nsplit;
+    const int Din = m == 0 ? Din_v : Din_t;
+    const int d0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+    if (n0 >= Din) return;                                        // (the modality with the narrower input has fewer column tiles)
+    const in_bf16* gy = m == 0 ? gyv : gyt;
+    const TIN* x = m == 0 ? xv : xt;
+    const long ldx = m == 0 ? ldxv : ldxt;
+    const int rps = ((b + nsplit - 1) / nsplit + 31) / 32 * 32;   // batch rows per split (whole chunks)
+    const int r0 = split * rps, r1 = r0 + rps < b ? r0 + rps : b;
+    const bool want_db = blockIdx.z == 0;
+    constexpr bool F16IN = __is_same(TIN, in_f16);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float dbacc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dbacc[j] = 0.f;
+
+    // staging role: chunk row srow (0..31), 16 consecutive columns from 16 * spiece.  The raw registers of FOUR chunks rotate: the loads of
+    // chunk c + 3 are issued in iteration c and committed to LDS at the end of iteration c + 2 -- three iterations to come from HBM (with one
+    // chunk of look-ahead every iteration exposed a full memory latency: 8 MFMAs per wave against ~1 us)
+    const int srow = tid >> 3, spiece = tid & 7;
+    constexpr int NR = 4;
+    Raw16<in_bf16> ra[NR];
+    Raw16<TIN> rb[NR];
+    auto fetch = [&](auto kc, int r) {
+        constexpr int k = decltype(kc)::value;
+        const bool valid = r + srow < r1;
+        ra[k].load(gy + (size_t)(r + srow) * ldgy, d0 + 16 * spiece, D, valid);
+        rb[k].load(x + (size_t)(r + srow) * ldx, n0 + 16 * spiece, Din, valid);
+    };
+    auto commit = [&](auto kc, int buf) {
+        constexpr int k = decltype(kc)::value;
+        unsigned char* ta = lds + (2 * buf) * kDwTile + srow * kDwPitch + 32 * spiece;
+        unsigned char* tb = lds + (2 * buf + 1) * kDwTile + srow * kDwPitch + 32 * spiece;
+        *reinterpret_cast<u32x4*>(ta) = ra[k].v[0];            // g_y is bf16 already: the raw registers are the LDS image
+        *reinterpret_cast<u32x4*>(ta + 16) = ra[k].v[1];
+        if constexpr (sizeof(TIN) == 2 && !F16IN) {            // bf16 inputs: likewise
+            *reinterpret_cast<u32x4*>(tb) = rb[k].v[0];
+            *reinterpret_cast<u32x4*>(tb + 16) = rb[k].v[1];
+        } else {
+            struct { bf16_t e[8]; } pb[2];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) pb[j >> 3].e[j & 7] = f32_to_bf16_bits(rb[k].get(j));
+            *reinterpret_cast<u32x4*>(tb) = __builtin_bit_cast(u32x4, pb[0]);
+            *reinterpret_cast<u32x4*>(tb + 16) = __builtin_bit_cast(u32x4, pb[1]);
+        }
+        if (want_db) {                                          // (block-uniform: one block in Dinp / 128 sums the columns)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dbacc[j] += ra[k].get(j);
+        }
+    };
+    // transposing read of one fragment: in a 16-lane group lane 4 j + c addresses chunk row k0 + j, 8-byte piece c of the 16 columns the
+    // group covers; lane i then receives the 4 rows k0 .. k0 + 3 of column i (hip_emu.h / MI355X ISA: ds_read_b64_tr_b16)
+    const int grp = lane >> 4, i16 = lane & 15;
+    const int tr_off = (8 * (grp >> 1) + (i16 >> 2)) * kDwPitch + (16 * (grp & 1) + 4 * (i16 & 3)) * 2;
+    auto frag = [&](const unsigned char* tile, int col0, int ks) {
+        struct { s16x4 lo, hi; } p;
+        const unsigned char* a = tile + tr_off + 16 * ks * kDwPitch + col0 * 2;
+        p.lo = lds_read_tr16_b64(a);
+        p.hi = lds_read_tr16_b64(a + 4 * kDwPitch);
+        return __builtin_bit_cast(bf16x8, p);
+    };
+
+    if (r0 < r1) {
+        fetch(IdxC<0>{}, r0);
+        fetch(IdxC<1>{}, r0 + 32);          // (rows past r1 load nothing: zeros)
+        fetch(IdxC<2>{}, r0 + 64);
+        commit(IdxC<0>{}, 0);
+        __syncthreads();
+        for (int rr = r0; rr < r1; rr += 32 * NR) {
+            static_for<NR>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int r = rr + 32 * k;
+                if (r < r1) {                                     // (block-uniform)
+                    constexpr int buf = k & 1;
+                    fetch(IdxC<(k + 3) % NR>{}, r + 96);          // three chunks ahead
+                    const unsigned char* ta = lds + (2 * buf) * kDwTile;
+                    const unsigned char* tb = lds + (2 * buf + 1) * kDwTile;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        bf16x8 a[2], bq[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { a[i] = frag(ta, 64 * wr + 32 * i, ks); bq[i] = frag(tb, 64 * wc + 32 * i, ks); }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(a[i], bq[j], acc[i][j]);
+                    }
+                    if (r + 32 < r1) commit(IdxC<(k + 1) % NR>{}, buf ^ 1);
+                    __syncthreads();
+                }
+            });
+        }
+    }
+    // C fragment (i, j): lane (l31, half) holds dW[d0 + 64 wr + 32 i + frag_row(r, half)][n0 + 64 wc + 32 j + l31]
+    float* out = partial + ((size_t)(m * nsplit + split) * Dp + d0) * Dinp + n0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(size_t)(64 * wr + 32 * i + frag_row(r, half)) * Dinp + 64 * wc + 32 * j + l31] = acc[i][j][r];
+    if (want_db) {      // column sums of this block's g_y rows: thread (srow, spiece) holds 16 columns of every 32nd row
+        float* red = reinterpret_cast<float*>(lds);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[srow * 128 + 16 * spiece + j] = dbacc[j];
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+            for (int q = 0; q < 32; ++q) sum += red[q * 128 + tid];
+            dbpart[(size_t)(m * nsplit + split) * Dp + d0 + tid] = sum;
+        }
+    }
+}
+// dW_m[d][n] = sum_split partial[m][split][d][n] (split order: deterministic), db_m[d] likewise.  grid = (ceil(Dinp / 256), D, 2).
+__global__ void __launch_bounds__(256) project_dw_reduce_kernel(const float* partial, const float* dbpart, int nsplit, int D, int Dp, int Dinp,
+                                                                int Din_v, int Din_t, float* dwv, float* dwt, long lddwv, long lddwt,
+                                                                float* dbv, float* dbt) {
+    const int m = blockIdx.z, d = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    const int Din = m == 0 ? Din_v : Din_t;
+    if (n < Din) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[((size_t)(m * nsplit + k) * Dp + d) * Dinp + n];
+        (m == 0 ? dwv : dwt)[(size_t)d * (m == 0 ? lddwv : lddwt) + n] = s;
+    }
+    float* db = m == 0 ? dbv : dbt;
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += dbpart[(size_t)(m * nsplit + k) * Dp + d];
+        db[d] = s;
+    }
+}
+
 // one wave per row index i (both modalities): g_y = inv_norm (G - y^ (y^ . G)), written as fp32 [b, D] per modality
 __global__ void __launch_bounds__(256) project_backward_prep_kernel(const float* gv, const float* gt, long ldgv, long ldgt, Geo g,
                                                                     const bf16_t* X, const float* inv_norm, float* ov, float* ot,

@@ -57,14 +57,6 @@ def _weights_bf16(w: torch.Tensor, Dpad: int = 0) -> "tuple[torch.Tensor, int]":
     return out, ldw
 
 
-def _mm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """bf16 x bf16 library GEMM with fp32 accumulation; fp32 result where this torch build offers it (the sum over the batch in dW)."""
-    try:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    except (TypeError, RuntimeError):
-        return torch.mm(a, b)
-
-
 class _ProjectedFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xv, xt, wv, bv, wt, bt, temperature, negative_w, group):
@@ -100,13 +92,26 @@ class _ProjectedFunction(torch.autograd.Function):
             gyv, gyt = L._backward_impl(ws, packed[0, :b, :D], packed[1, :b, :D], grad_out)
             # the projection's own gradients: bf16 operands, fp32 accumulation (plain library GEMMs -- hipBLASLt)
             need = ctx.needs_input_grad
-            bf = torch.bfloat16
             dxv = torch.mm(gyv, _weights_bf16(wv)[0][:, :wv.shape[1]]).to(xv.dtype) if need[0] else None     # (the bf16 values the forward multiplied with)
             dxt = torch.mm(gyt, _weights_bf16(wt)[0][:, :wt.shape[1]]).to(xt.dtype) if need[1] else None
-            dwv = _mm_f32(gyv.t(), xv if xv.dtype == bf else xv.to(bf)).to(wv.dtype) if need[2] else None
-            dwt = _mm_f32(gyt.t(), xt if xt.dtype == bf else xt.to(bf)).to(wt.dtype) if need[4] else None
-            dbv = torch.sum(gyv, 0, dtype=torch.float32).to(ctx.bias_dtype[0]) if (need[3] and ctx.bias_dtype[0] is not None) else None
-            dbt = torch.sum(gyt, 0, dtype=torch.float32).to(ctx.bias_dtype[1]) if (need[5] and ctx.bias_dtype[1] is not None) else None
+            dwv = dwt = dbv = dbt = None
+            if need[2] or need[4] or need[3] or need[5]:
+                # dW = g_y^T x and db = column sums of g_y, both modalities: ONE split-K MFMA launch + a reduce (crossclr_project_dw) --
+                # hipBLASLt's pick for this shape (K = batch = 8192, 128 output tiles, no split-K) takes 59 us per modality, this ~1/4
+                lib = nat.library()
+                dinv, dint = wv.shape[1], wt.shape[1]
+                wsf = torch.empty(lib.crossclr_project_dw_ws_floats(b, D, dinv, dint), dtype=torch.float32, device=xv.device)
+                dwv32 = torch.empty(D, dinv, dtype=torch.float32, device=xv.device)
+                dwt32 = torch.empty(D, dint, dtype=torch.float32, device=xv.device)
+                dbv32 = torch.empty(D, dtype=torch.float32, device=xv.device) if ctx.bias_dtype[0] is not None else None
+                dbt32 = torch.empty(D, dtype=torch.float32, device=xv.device) if ctx.bias_dtype[1] is not None else None
+                nat.check(lib.crossclr_project_dw(b, D, L._ptr(gyv), L._ptr(gyt), gyv.stride(0), L._ptr(xv), L._ptr(xt), xv.stride(0), xt.stride(0),
+                                                  dinv, dint, L._IN_DTYPE[xv.dtype], L._ptr(wsf), L._ptr(dwv32), L._ptr(dwt32), dinv, dint,
+                                                  L._ptr(dbv32), L._ptr(dbt32), L._stream_for(xv)))
+                dwv = dwv32.to(wv.dtype) if need[2] else None
+                dwt = dwt32.to(wt.dtype) if need[4] else None
+                dbv = dbv32.to(ctx.bias_dtype[0]) if (need[3] and dbv32 is not None) else None
+                dbt = dbt32.to(ctx.bias_dtype[1]) if (need[5] and dbt32 is not None) else None
         return dxv, dxt, dwv, dbv, dwt, dbt, None, None, None
 
 

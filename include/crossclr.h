@@ -335,6 +335,15 @@ int crossclr_project_pack(const crossclr_plan* plan, const void* x_video, const 
 int crossclr_project_pack_wf(const crossclr_plan* plan, const void* x_video, const void* x_text, long ld_video, long ld_text, int Din_video,
                              int Din_text, int in_dtype, const void* wf_video, const void* wf_text, int ldw_video, int ldw_text,
                              const float* bias_video, const float* bias_text, void* xhat, float* inv_norm, float* diag_cos, void* stream);
+/* The projection's weight gradient (round 4): dW_m[D][Din_m] = g_y,m^T x_m (fp32, row-major = torch.nn.Linear.weight.grad layout) and
+ * db_m = column sums of g_y,m (NULL: not wanted) for both modalities -- one split-K MFMA launch + one reduce, deterministic.
+ *   gy_*  bf16 [b, D] (row stride ld_gy elements): what crossclr_backward_finish_p(prenormalized = 2) wrote
+ *   x_*   the projection's inputs [b, Din_*] in `in_dtype` (the same tensors crossclr_project_pack read)
+ *   ws    crossclr_project_dw_ws_floats(b, D, Din_video, Din_text) floats of scratch (caller-owned)                                  */
+size_t crossclr_project_dw_ws_floats(int b, int D, int Din_video, int Din_text);
+int crossclr_project_dw(int b, int D, const void* gy_video, const void* gy_text, long ld_gy, const void* x_video, const void* x_text,
+                        long ld_xv, long ld_xt, int Din_video, int Din_text, int in_dtype, float* ws, float* dw_video, float* dw_text,
+                        long ld_dwv, long ld_dwt, float* db_video, float* db_text, void* stream);
 int crossclr_project_backward_prep(const crossclr_plan* plan, const float* g_video, const float* g_text, long ld_gv, long ld_gt,
                                    const void* xhat, const float* inv_norm, float* gy_video, float* gy_text, long ld_out,
                                    void* stream);

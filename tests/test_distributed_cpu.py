@@ -90,6 +90,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        # wide operands (512 < D <= 1024): one 32-row half per wave, 128-row blocks,
                                                        # the backward in two column parts; pairs + saved remote blocks as well
                                                        (3, 24, 530, "bf16", 5e-3, 2e-2),
+                                                       # wide bf16 plans (D > 1024, Dpad = 1152): the local block saves its exponentials (generic
+                                                       # forward with bf16 records + D-slice backward in column parts), the remote blocks recompute
+                                                       # into the same gradient slices
+                                                       (2, 16, 1030, "bf16", 5e-3, 2e-2),
                                                        # CROSSCLR_EXCHANGE=p2p: the operands travel point to point in two batches, the slices
                                                        # the forward needs first; p2p_each ("each"): one pair of operations per peer
                                                        # distance, one forward launch per pair partner as its slice lands

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("B,D,mode,weighted", [(2048, 256, "bf16", False), (2048, 128, "bf16", False), (2048, 384, "bf16", True),
                                               (4096, 256, "bf16", False), (2048, 64, "bf16", False), (8192, 512, "bf16", False),
                                               (2048, 768, "bf16", False), (1024, 1024, "bf16", True), (1000, 300, "fp32", False),
-                                              (1536, 200, "fp32", True)])
+                                              (1536, 200, "fp32", True),
+                                              # wide bf16 plans: generic forward with bf16 records + the D-slice backward in 3 / 4 / 5 column parts
+                                              (2048, 1100, "bf16", False), (2048, 1536, "bf16", True), (1024, 2048, "bf16", False), (640, 2500, "bf16", False)])
 def test_every_step_is_bit_identical(B, D, mode, weighted):
     g = torch.Generator().manual_seed(B + D)
     v = torch.randn(B, D, generator=g).cuda().requires_grad_(True)

@@ -97,3 +97,24 @@ def test_packed_operand_equals_normalize_of_the_projection():
     nat.check(lib.crossclr_project_pack_wf(ctypes.byref(plan), xv.data_ptr(), xt.data_ptr(), din, din, din, din, nat.IN_F32, wvf.data_ptr(), wtf.data_ptr(),
                                            ldw, ldw, 0, 0, xhat2.data_ptr(), inv2.data_ptr(), diag2.data_ptr(), 0))
     assert torch.equal(xhat, xhat2) and torch.equal(inv[:b], inv2[:b]) and torch.equal(diag[:b], diag2[:b])
+
+
+@pytest.mark.parametrize("b,D,din_v,din_t,dtype", [(70, 48, 40, 100, torch.float32), (200, 130, 64, 24, torch.bfloat16)])
+def test_weight_gradient_kernel_equals_the_matrix_product(b, D, din_v, din_t, dtype):
+    """crossclr_project_dw (split-K MFMA kernel with transposing LDS reads + reduce): dW = g_y^T x and db = column sums of g_y for both
+    modalities, against float64 products of the same bf16-rounded operands."""
+    import ctypes
+    lib = nat.library()
+    g = torch.Generator().manual_seed(b + D)
+    gyv, gyt = (torch.randn(b, D, generator=g) * 0.1).bfloat16(), (torch.randn(b, D, generator=g) * 0.1).bfloat16()
+    xv, xt = torch.randn(b, din_v, generator=g).to(dtype), torch.randn(b, din_t, generator=g).to(dtype)
+    ws = torch.empty(lib.crossclr_project_dw_ws_floats(b, D, din_v, din_t))
+    dwv, dwt = torch.full((D, din_v), float("nan")), torch.full((D, din_t), float("nan"))
+    dbv, dbt = torch.full((D,), float("nan")), torch.full((D,), float("nan"))
+    in_dtype = nat.IN_F32 if dtype == torch.float32 else nat.IN_BF16
+    nat.check(lib.crossclr_project_dw(b, D, gyv.data_ptr(), gyt.data_ptr(), D, xv.data_ptr(), xt.data_ptr(), din_v, din_t, din_v, din_t, in_dtype,
+                                      ws.data_ptr(), dwv.data_ptr(), dwt.data_ptr(), din_v, din_t, dbv.data_ptr(), dbt.data_ptr(), 0))
+    for gy, x, dw, db in ((gyv, xv, dwv, dbv), (gyt, xt, dwt, dbt)):
+        want = gy.double().t() @ x.bfloat16().double()
+        assert (dw.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+        assert (db.double() - gy.double().sum(0)).abs().max().item() <= 1e-4
