@@ -57,7 +57,7 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
                                                                 p(gbuf), 0, stream))) if stash is not None else None,
         # (the fragment-major kernel with one tile per barrier interval, beside the pair kernel the step runs)
         "backward_saved_xf1": (lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k, p(gbuf), 0, stream))
-                              if (stash is not None and xf is not None and xf_name != "crossclr_backward_saved_xf") else None,
+                              if (stash is not None and xf is not None and xf_name != "crossclr_backward_saved_xf" and plan.Dpad <= 1024) else None,
         "backward_saved_lds": (lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(stash), t, w, p(ws.rz), p(ws.wrz), sw_k,
                                                                    p(gbuf), 0, stream)) if (stash is not None and xf is not None) else None,
         "backward_finish": lambda: lib.crossclr_backward_finish_w(pp, p(gbuf), p(video), p(text), video.stride(0),

@@ -240,13 +240,13 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
 #ifndef CROSSCLR_NO_FAST
     if (plan->fast_path && plan->fast_bwd && !env.disable_save) plan->stash_bytes = fast_stash_bytes(plan->bpad, plan->Dpad);
     if (wide) plan->stash_bytes = wide_stash_bytes(plan->bpad);
+    if (wide && plan->stash_bytes && !env.disable_xf && plan->operand_bytes < ((size_t)1 << 32)) plan->xf_bytes = plan->operand_bytes;
     // exact-fp32 mode: the whole stacked [2 bpad] x [2 bpad] matrix of fp32 exponentials (1 GiB at b = 8192), up to 16 GiB
     if (mode == CROSSCLR_MODE_FP32 && !env.disable_save && plan->operand_bytes < (1ull << 32)) {
         const size_t sb = (size_t)2 * plan->bpad * (size_t)2 * plan->bpad * 4;
         if (sb <= ((size_t)16 << 30)) plan->stash_bytes = sb;
     }
     // the fragment-major copy of the bf16 operand (crossclr_normalize_xf -> crossclr_backward_saved_xf): local block, Dpad <= 1024
-    plan->xf_bytes = 0;
     if (plan->fast_path && plan->fast_bwd && plan->stash_bytes && plan->Dpad <= 1024 && !env.disable_xf) plan->xf_bytes = plan->operand_bytes;
 #else
     plan->xf_bytes = 0;
@@ -341,6 +341,10 @@ static int normalize_xf_any(const crossclr_plan* plan, const void* video, const 
     return fail(CROSSCLR_E_ARG, "the fragment-major operand needs the register-resident path");
 #else
     if (!plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major operand (xf_bytes == 0): use crossclr_normalize / crossclr_pack");
+    if (plan->Dpad > 1024) {   // wide plans: the row kernel, then the packed rows re-laid fragment-major (1024 columns of a 32-row tile per block)
+        if (int rc = normalize_any<NORM>(plan, video, text, ld_video, ld_text, in_dtype, xhat, inv_norm, diag_cos, stream)) return rc;
+        return crossclr_pack_xf_from_packed(plan, xhat, 1, xf, stream);
+    }
     switch (in_dtype) {
         case CROSSCLR_IN_F32: return normalize_xf_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
         case CROSSCLR_IN_F64: return normalize_xf_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
@@ -1099,7 +1103,8 @@ extern "C" int crossclr_pack_xf_from_packed(const crossclr_plan* plan, const voi
     if (!plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major operand (xf_bytes == 0)");
     const size_t tiles = (size_t)nranks * 2 * plan->bpad / 32;
     if (tiles > 0x7fffffffull) return fail(CROSSCLR_E_ARG, "too many rows");
-    LAUNCH(xf_from_packed_kernel, dim3((unsigned)tiles), dim3(256), stream, (const bf16_t*)xhat_packed, (unsigned char*)xhat_xf, plan->Dpad);
+    LAUNCH(xf_from_packed_kernel, dim3((unsigned)tiles, (unsigned)((plan->Dpad + 1023) / 1024)), dim3(256), stream, (const bf16_t*)xhat_packed,
+           (unsigned char*)xhat_xf, plan->Dpad);
     return launch_status("xf_from_packed_kernel");
 #endif
 }

@@ -1076,6 +1076,7 @@ CROSSCLR_LEAF int launch_saved_lds(const SavedLaunch& a) {
 // generic forward saved (fwd_sums_kernel<bf16_t, ..., ST, SYM>)
 #ifndef CROSSCLR_DEF_SAVED_WIDE
 int launch_saved_wide(const SavedLaunch& a);
+int launch_saved_wide_xfp(const SavedLaunch& a);
 #else
 CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
     const crossclr_plan* p = a.p;
@@ -1108,6 +1109,39 @@ CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
     return CROSSCLR_OK;
 #endif
 }
+// the same on the fragment-major operand with the pair kernel (crossclr_kernels_dslp.h): what the module takes from 4096 padded rows on
+CROSSCLR_LEAF int launch_saved_wide_xfp(const SavedLaunch& a) {
+    const crossclr_plan* p = a.p;
+    const Geo& g = a.g;
+    dim3 block(256);
+    void* stream = a.stream;
+    const unsigned char* st = (const unsigned char*)a.stash;
+    const unsigned sb = (unsigned)a.stash_bytes;
+    const unsigned char* xfo = (const unsigned char*)a.cols;
+    const float *rz = a.rz, *wrz = a.wrz, *rz_cols = a.rz_cols, *wrz_cols = a.wrz_cols, *ks = a.ks, *kc = a.kc;
+    float* gbuf = a.gbuf;
+    const int accumulate = a.accumulate, tps2 = a.tps;
+    (void)block; (void)stream; (void)st; (void)sb; (void)xfo; (void)rz; (void)wrz; (void)rz_cols; (void)wrz_cols; (void)kc; (void)gbuf; (void)accumulate; (void)tps2;
+    if (a.mode != 0) return CROSSCLR_E_ARG;
+#ifdef CROSSCLR_DSL_MINIMAL
+    return CROSSCLR_E_ARG;
+#else
+#define CROSSCLR_LBWP(DK, XP) do { dim3 gridw(2 * p->bpad / 128, p->bwd_slices, XP);                                                            \
+                                   if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_xfp_kernel<DK, true, 0, XP, 4>), gridw, block, stream, xfo, st, sb, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps2, ks, kc); \
+                                   else CROSSCLR_FAST_LAUNCH((fast_bwd_xfp_kernel<DK, false, 0, XP, 4>), gridw, block, stream, xfo, st, sb, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps2, ks, kc); } while (0)
+    switch (p->Dpad) {
+        case 1152: CROSSCLR_LBWP(24, 3); break;
+        case 1536: CROSSCLR_LBWP(32, 3); break;
+        case 2048: CROSSCLR_LBWP(32, 4); break;
+        case 2560: CROSSCLR_LBWP(32, 5); break;
+        case 3072: CROSSCLR_LBWP(32, 6); break;
+        case 4096: CROSSCLR_LBWP(32, 8); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LBWP
+    return CROSSCLR_OK;
+#endif
+}
 #endif   // CROSSCLR_DEF_SAVED_WIDE
 
 // mode 0 / 1 / 2: the LDS-staged kernel on the row-major operand -- the local symmetric block, a rectangular block, the transpose of one
@@ -1135,9 +1169,9 @@ static inline int fast_backward_saved(const crossclr_plan* p, const Geo& g, cons
         a.stash_bytes = mode == 0 ? p->stash_bytes
                                   : (size_t)per_rank * (size_t)(mode == 1 ? ntiles : g.col_ranks * per_rank) * 2048;
         if (a.stash_bytes >= ((size_t)1 << 32)) return CROSSCLR_E_ARG;
-        return launch_saved_xfp(a);
+        return p->Dpad > 1024 ? launch_saved_wide_xfp(a) : launch_saved_xfp(a);
     }
-    if (p->Dpad > 1024) return launch_saved_wide(a);
+    if (p->Dpad > 1024) return xf ? CROSSCLR_E_ARG : launch_saved_wide(a);     // (wide plans: the pair kernel or the LDS-staged one)
     return xf ? launch_saved_xf1(a) : launch_saved_lds(a);
 }
 // which backward the fast path uses: 16-row wavefronts (rows per block 128 at Dpad <= 512, 64 above) or the

@@ -377,7 +377,7 @@ _MAX_STASH_BYTES = int(float(os.environ.get("CROSSCLR_MAX_STASH_GB", "8")) * (1 
 # crossclr_normalize_xf +1.5 us at D = 512 and +5 us at D = 1024 (+8 at B = 2048, where its 16-row blocks no longer fill the chip), so small
 # batches keep the plain pair: default = Dpad in {512, 768, 1024} with at least 2048 (D <= 512) / 4096 (wider) padded rows.
 # CROSSCLR_XF_WIDTHS="128,256,384,512" (or "" for none) overrides the widths and drops the row floor (tuning / tests).
-_XF_WIDTHS_DEFAULT = frozenset((512, 768, 1024))
+_XF_WIDTHS_DEFAULT = frozenset((512, 768, 1024, 1152, 1536, 2048, 2560, 3072, 4096))     # (beyond 1024: wide plans, pair kernel only)
 
 
 # The fragment-major backwards move their column tiles with hand-counted inline-asm loads, and two schedules of that idea that compiled
@@ -448,7 +448,7 @@ def _saved_backward_entry(ws, plan, dev) -> str:
     if ws.xf is None:
         return "crossclr_backward_saved"
     weighted = ws.k_rows is not None
-    cands = ["crossclr_backward_saved_xf"]
+    cands = ["crossclr_backward_saved_xf"] if plan.Dpad <= 1024 else []     # (wide plans: the pair kernel or the LDS-staged one)
     if plan.stash_bytes < (1 << 32) and os.environ.get("CROSSCLR_XFP", "1") != "0":
         cands.insert(0, "crossclr_backward_saved_xfp")
     for name in cands:

@@ -202,7 +202,7 @@ def test_plan_geometry():
     assert (p.Dpad, p.fast_path, p.fast_bwd) == (768, 1, 2)   # 512 < D <= 1024: 4-wave forward, 16-row-wave backward
     p = nat.make_plan(100, 1500, 1, 0, nat.MODE_BF16)
     assert (p.Dpad, p.fast_path, p.fast_bwd) == (1536, 0, 0)  # wider: generic tiled forward ...
-    assert p.stash_bytes > 0 and p.xf_bytes == 0              # ... that saves its exponentials for the D-slice backward (3 column parts)
+    assert p.stash_bytes > 0 and p.xf_bytes == p.operand_bytes   # ... that saves its exponentials for the D-slice backward (3 column parts, fragment-major copy available)
     assert [nat.make_plan(100, d, 1, 0, nat.MODE_BF16).Dpad for d in (1025, 1153, 2048, 2049, 3000, 4096)] == [1152, 1536, 2048, 2560, 3072, 4096]
     p = nat.make_plan(8192, 1536, 1, 0, nat.MODE_BF16)
     assert p.bwd_slices == 2 and p.gbuf_bytes == 2 * 2 * 8192 * 1536 * 4     # 128 row blocks x 3 parts x 2 slices = 3 rounds of 256
@@ -505,8 +505,17 @@ def test_wide_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
         loss.backward()
         return loss.item(), vv.grad, tt.grad
     plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
-    assert plan.stash_bytes > 0 and plan.fast_path == 0
+    assert plan.stash_bytes > 0 and plan.fast_path == 0 and plan.xf_bytes == plan.operand_bytes
     ls, gvs, gts = step()
+    # the same step with the column tiles taken as MFMA fragments from the fragment-major copy (pair kernel in 3 column parts; the
+    # module's policy takes it from 4096 padded rows on): bit-identical to the LDS-staged kernel
+    monkeypatch.setenv("CROSSCLR_XF_WIDTHS", str(plan.Dpad))
+    calls = []
+    real = nat.library().crossclr_backward_saved_xfp
+    monkeypatch.setattr(nat.library(), "crossclr_backward_saved_xfp", lambda *a: (calls.append(1), real(*a))[1], raising=False)
+    lx, gvx, gtx = step()
+    assert len(calls) == 1 and lx == ls and torch.equal(gvx, gvs) and torch.equal(gtx, gts)
+    monkeypatch.delenv("CROSSCLR_XF_WIDTHS")
     monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
     assert nat.make_plan(B, D, 1, 0, nat.MODE_BF16).stash_bytes == 0
     lr, gvr, gtr = step()
