@@ -555,6 +555,13 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
     const int nsplit = plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     dim3 grid(2 * plan->bpad / 128, nsplit);
+    if (stash && plan->mode == CROSSCLR_MODE_BF16) {   // two-pass regime of a bf16 plan: the full second pass leaves bf16 records (rectangular layout)
+        dim3 block(256);
+        if (mode != 2) return fail(CROSSCLR_E_ARG, "bf16 plans save through the generic forward in the two-pass regime only");
+        if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+        else LAUNCH((fwd_sums_kernel<bf16_t, false, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+        return launch_status("fwd_sums_kernel (save, bf16 records)");
+    }
     if (stash) {   // exact-fp32 forward that also saves its exponentials (local block; common shift, or per-row shifts: mode 2)
         dim3 block(256);
 #define CROSSCLR_LSV(SW, MODE) LAUNCH((fwd_sums_kernel<float, SW, MODE, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr)
@@ -878,8 +885,23 @@ extern "C" int crossclr_forward_s(const crossclr_plan* plan, const void* xhat_ro
 }
 
 // the two-pass regime's save-for-backward pair (exact-fp32 plans, local block): U and Ut, twice the single-pass stash
+// bf16 register-resident plans in the two-pass regime: the FULL matrix of bf16 records U[p][q] = exp2(x - shift[p]) in the rectangular layout
+// of a one-rank remote block, followed by 2 bpad floats of zeros (crossclr_backward_saved_s passes them as the statistics of the side a
+// launch must not weigh: W = U rz_p + U^T rz_q is formed as two launches of the saved backward, direct and transposed)
+static size_t rect_bytes_s(const crossclr_plan* plan) {
+#ifdef CROSSCLR_NO_FAST
+    (void)plan; return 0;
+#else
+    return (plan && plan->mode == CROSSCLR_MODE_BF16 && plan->fast_path && plan->stash_bytes) ? fast_stash_bytes_rect(plan->bpad, plan->Dpad, 1) : 0;
+#endif
+}
 static size_t stash_bytes_s(const crossclr_plan* plan) {
-    if (!plan || plan->fast_path || plan->mode != CROSSCLR_MODE_FP32 || !plan->stash_bytes) return 0;
+    if (!plan || !plan->stash_bytes) return 0;
+    if (plan->mode == CROSSCLR_MODE_BF16) {
+        const size_t rb = rect_bytes_s(plan);
+        return rb ? rb + (size_t)2 * plan->bpad * 4 : 0;
+    }
+    if (plan->fast_path || plan->mode != CROSSCLR_MODE_FP32) return 0;
     return 2 * plan->stash_bytes <= ((size_t)16 << 30) ? 2 * plan->stash_bytes : 0;
 }
 extern "C" size_t crossclr_stash_bytes_s(const crossclr_plan* plan) { return stash_bytes_s(plan); }
@@ -899,6 +921,13 @@ extern "C" int crossclr_forward_save_s(const crossclr_plan* plan, const void* xh
         return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
     float* out = part + (size_t)slot0 * 2 * plan->bpad;
     int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    if (plan->mode == CROSSCLR_MODE_BF16) {   // full (non-symmetric) second pass: bf16 records + the zero statistics behind them
+        rc = device_zero_header(header, stream);
+        if (rc) return rc;
+        rc = device_zero(static_cast<unsigned char*>(stash) + rect_bytes_s(plan), (size_t)2 * plan->bpad * 4, stream);
+        if (rc) return rc;
+        return forward_generic(plan, g, xhat, xhat, out, kcols, shift, 2, stream, static_cast<float*>(stash));
+    }
     if (!env_knobs().disable_symmetric)
         return forward_generic_sym<float>(plan, g, xhat, out, kcols, part + ws_colpart_off(plan), header, stream, static_cast<float*>(stash), shift);
     rc = device_zero_header(header, stream);
@@ -917,6 +946,20 @@ extern "C" int crossclr_backward_saved_s(const crossclr_plan* plan, const void* 
     Geo g;
     int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g, true);
     if (rc) return rc;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->mode == CROSSCLR_MODE_BF16) {
+        // W[p][q] = U[p][q] rz_p + U[q][p] rz_q: the direct launch weighs with the ROW statistics only (column side: zeros), the transposed
+        // launch with the statistics of the rows it contracts over (output side: zeros) and accumulates -- two 8 B^2 D launches of the saved
+        // backward instead of the 16 B^2 D (1 + ...) recompute of the generic kernel
+        const float* zeros = reinterpret_cast<const float*>(static_cast<const unsigned char*>(stash) + rect_bytes_s(plan));
+        rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, zeros, zeros, gbuf, accumulate, krows, krows, 1, stream);
+        if (rc) return fail(rc, "fast_backward_saved (two-pass, direct): unsupported Dpad %d", plan->Dpad);
+        Geo gt = g;
+        gt.col_ranks = 1; gt.skip_rank = 0; gt.col_rank0 = plan->rank; gt.col_wrap = 0; gt.row_rank = plan->rank;
+        rc = fast_backward_saved(plan, gt, xhat, stash, zeros, zeros, rz, wrz, gbuf, 1, krows, krows, 2, stream);
+        return rc ? fail(rc, "fast_backward_saved (two-pass, transposed): unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel (two-pass pair)");
+    }
+#endif
     const int NQ = 2 * plan->bpad / 32;
     const int tps = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
     const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;

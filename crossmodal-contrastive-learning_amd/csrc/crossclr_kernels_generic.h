@@ -294,7 +294,8 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                                                        float* part, const float* kcols, const float* shift, float* stash, int* header,
                                                        float* colpart) {
     static_assert(!ST || MODE == 0 || MODE == 2, "exponentials are saved by the passes that form sums");
-    static_assert(!(ST && sizeof(T) == 2) || MODE == 0, "bf16 records: the single-pass soft-max only");
+    static_assert(!(ST && sizeof(T) == 2) || (MODE == 0 && SYM) || (MODE == 2 && !SYM),
+                  "bf16 records: the symmetric single-pass forward (upper triangle) or the full second pass of the two-pass soft-max");
     static_assert(!SYM || MODE <= 3, "symmetric evaluation: the soft-max passes; MODE 3: one pass for both directions");
     // MODE 3 + SYM (score statistics in ONE pass): only the rows of modality 0 are walked (grid.x = bpad / 128), against the column
     // tiles of modality 1; every tile also yields, per column q, the hinge sum and the active count over the block's rows against
@@ -410,7 +411,8 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                     f32x4 kq = {1.f, 1.f, 1.f, 1.f};
                     if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
                     f32x4 ev = {0.f, 0.f, 0.f, 0.f}, etv = {0.f, 0.f, 0.f, 0.f}, shq = {0.f, 0.f, 0.f, 0.f};
-                    if ((MODE == 2 && (ST || SYM)) || (MODE == 3 && SYM))
+                    constexpr bool kNeedColShift = (MODE == 2 && (SYM || (ST && sizeof(T) == 4))) || (MODE == 3 && SYM);   // (bf16 records: U only)
+                    if (kNeedColShift)
                         shq = *reinterpret_cast<const f32x4*>(shift + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                             if (masked) e = 0.f;
                             ev[j] = e;
                             float et = e;            // relative to the COLUMN's shift (single pass: one shift, symmetric matrix)
-                            if (MODE == 2 && (ST || SYM)) { et = fast_exp2(x2 - shq[j]); if (masked) et = 0.f; }
+                            if (MODE == 2 && kNeedColShift) { et = fast_exp2(x2 - shq[j]); if (masked) et = 0.f; }
                             etv[j] = et;
                             if (SYM) es[qi][r] += pad_row ? 0.f : ((SW && same_mod) ? et * kp[pi] : et);
                             if (SW) e *= kq[j];
@@ -449,8 +451,18 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                         // [k-step th = r4 >> 1][lane][8 bf16], lane (p, half) holding E[p][16 th + 8 (r4 & 1) + 4 half + j] -- in the upper-
                         // triangle layout of the register-resident forward with 128-row blocks (stash_tile_index, tpr = 4): what
                         // fast_bwd_dsl_kernel<..., TPRF = 4> reads, the mirrored half through its transposing gather.  8 bytes per lane and r4.
+                        // MODE 2 (two-pass soft-max, bf16 register-resident plans): U[p][q] = exp2(x - shift[p]) is not symmetric, so the FULL matrix
+                        // is evaluated and every tile's record goes to the rectangular layout [row group][column tile] that
+                        // fast_bwd_dsl_kernel<..., MODE 1 / 2> read (crossclr_backward_saved_s: W = U rz_p + U^T rz_q as two launches).
                         const int p32 = (row0 + 64 * wr + 32 * pi) >> 5, q32 = (int)((ct.row0 + 64 * wc + 32 * qi) >> 5);
-                        if (q32 >= 4 * (p32 / 4)) {
+                        if constexpr (MODE == 2) {
+                            struct B4 { bf16_t e[4]; } pk;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(ev[j]);
+                            unsigned char* rec = reinterpret_cast<unsigned char*>(stash) + ((size_t)p32 * (size_t)(2 * g.bpad / 32) + (size_t)q32) * 2048 +
+                                                 1024 * (r4 >> 1) + 16 * lane + 8 * (r4 & 1);
+                            *reinterpret_cast<B4*>(rec) = pk;
+                        } else if (q32 >= 4 * (p32 / 4)) {
                             struct B4 { bf16_t e[4]; } pk;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(ev[j]);
