@@ -232,7 +232,10 @@ int crossclr_backward_saved_xfp(const crossclr_plan* plan, const void* xhat_xf, 
 /* Two-pass regime, save-for-backward pair (exact-fp32 plans, local block; ABI 3): the second pass also leaves
  * U[p][q] = exp2(x_pq - shift_p) and Ut[p][q] = U[q][p] behind (crossclr_stash_bytes_s = twice plan->stash_bytes, 0 = not
  * available), and the backward forms the weights U rz_p + Ut rz_q from them instead of recomputing the similarity product
- * (replaces autograd of loss.py:96-100, 59-60 like crossclr_backward_saved).  `shift` = the row maxima of crossclr_forward_rowmax. */
+ * (replaces autograd of loss.py:96-100, 59-60 like crossclr_backward_saved).  `shift` = the row maxima of crossclr_forward_rowmax.
+ * bf16 register-resident plans (round 4): the same three entry points; the stash is the FULL matrix of bf16 records U[p][q] in the
+ * rectangular layout of a one-rank remote block followed by 2 bpad floats of zeros (crossclr_stash_bytes_s says how much), and the backward
+ * is two launches of the saved D-slice kernel -- direct with the row statistics, transposed with the contracted rows' (accumulating).     */
 size_t crossclr_stash_bytes_s(const crossclr_plan* plan);
 int crossclr_forward_save_s(const crossclr_plan* plan, const void* xhat, float temperature, float negative_weight,
                             const crossclr_sample_weights* sw, const float* shift, float* part, int slot0, void* stash, void* stream);
