@@ -445,7 +445,7 @@ def main():
 
     # ---- per-kernel HIP-event timing of the single-GPU stages (roofline of the dominant kernel) ----
     sw = crossclr_amd.influential_sample_weights(xv, xt, 0.9, 0.0035) if args.influential else (None, None)
-    st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, args.mode, iters=10, warmup=2,
+    st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, args.mode, iters=20, warmup=3,
                               negative_scale=sw[0], loss_weight=sw[1])
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
     # algorithmic flops per launch: forward 6*b*b*D, backward 8*b*b*D for the local block
@@ -508,7 +508,7 @@ def main():
         "loss": loss_val,
         "roofline": {"bound": "mfma", "kernel": f"{dom_kernel_label} (crossclr_{dom}{entry_suffix if dom == 'backward_saved' else ''}; dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
-                     "source": "HIP events in this process (torch's current stream = the launch stream), average of 10 launches "
+                     "source": "HIP events in this process (torch's current stream = the launch stream), median of 20 launches "
                                "after the timed region; the rocprofv3 figure of the same command is under profiles/",
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": (traffic["source"] + " (rocprofv3 --pmc passes of tools/kbench.py, read from the committed "
@@ -517,7 +517,7 @@ def main():
                      "traffic_stale": (traffic["csrc_sha"] != csrc_sha()) if traffic else None,
                      "hbm_gbps_at_that_traffic": round(traffic["bytes"] / (st[dom] * 1e-3) / 1e9, 1) if traffic else None,
                      "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
-                     "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),
+                     "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),      # (the median of those launches)
                      "whole_step_algorithmic_tflops_per_gpu": round(step_tf, 2),
                      "whole_step_frac": round(step_tf / peak, 4),
                      },

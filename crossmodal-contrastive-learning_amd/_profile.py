@@ -16,7 +16,7 @@ from . import loss as L
 def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
                 compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None
                 ) -> Dict[str, float]:
-    """Average milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
+    """Median milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
     backward, backward_finish; forward_save / backward_saved when the plan has the save-for-backward pair -- those two
     are what a training step launches, `forward` / `backward` are the recomputing entry points);
     with sample weights the `_w` entry points are the ones timed."""
@@ -65,7 +65,11 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
                                                                   p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
     }
     out = {}
-    for name, fn in stages.items():
+    # the stages a training step runs first, the recomputing entry points (the long `backward`) last: they are what is compared
+    order = ["normalize", "normalize_plain", "forward_save", "forward_finish", "backward_saved", "backward_saved_xf1", "backward_saved_lds",
+             "backward_finish", "forward", "backward"]
+    for name in order:
+        fn = stages.get(name)
         if fn is None:
             continue
         for _ in range(warmup):
@@ -77,7 +81,8 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
             nat.check(fn())
             e1[i].record()
         torch.cuda.synchronize(dev)
-        out[name] = sum(a.elapsed_time(b) for a, b in zip(e0, e1)) / iters
+        ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
+        out[name] = ms[len(ms) // 2]          # median per launch (a mean over ten launches moved by 8 % with one slow launch)
     out["fast_path"] = float(plan.fast_path)
     out["saved_path"] = float(stash is not None)
     out["xf_path"] = float(xf is not None and xf_name != "crossclr_backward_saved")
