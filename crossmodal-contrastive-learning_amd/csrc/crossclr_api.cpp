@@ -384,7 +384,8 @@ static int project_pack_t(const crossclr_plan* p, const void* xv, const void* xt
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     // 64 rows per block up to Dpad = 512 when that still gives every CU a block; 32 rows otherwise (and always above 512: accumulators)
-    const bool rows32 = p->bpad / 64 < 256;
+    static const int rows_knob = [] { const char* e = getenv("CROSSCLR_PROJECT_ROWS"); return e ? atoi(e) : 0; }();      // 32 / 64: tuning knob (A/B)
+    const bool rows32 = rows_knob == 32 || (rows_knob != 64 && p->bpad / 64 < 256);
     dim3 grid(p->bpad / 64), grid32(p->bpad / 32), block(256);
 #define CROSSCLR_LPPX(DKP, RFV, GRID) LAUNCH((project_pack_kernel<TIN, DKP, RFV, WF>), GRID, block, stream, (const TIN*)xv, (const TIN*)xt, ldv, ldt, Din_v, Din_t, \
                                              (const bf16_t*)wv, (const bf16_t*)wt, ldw_v, ldw_t, bv, bt, g, (bf16_t*)xhat, inv_norm, diag)

@@ -126,37 +126,51 @@ __global__ void __launch_bounds__(256, 1) project_pack_kernel(const TIN* xv, con
     fetch(0);
     commit(0);
     __syncthreads();
+    // The weight fragments of k-step g (16 input columns; global index g = 4 c + ks) sit in slot g % 4 of a rotating register set and are
+    // requested THREE k-steps ahead of their MFMAs (with the loads right in front of their use every k-step exposed an L2 latency: 78 -> 61 us).
+    // Four k-steps per chunk = four slots, so a slot is a compile-time index.  (The same depth for the INPUT chunks -- raw registers of four
+    // chunks rotating -- measured slower, 61 -> 66 us: the inputs were not what the kernel waited for.)
+    constexpr int NSLOT = (2 * RF * CF <= 8) ? 4 : 2;      // (256-accumulator instantiations keep two slots: one k-step of look-ahead)
+    bf16x8 wb[NSLOT][2][CF];
+    auto load_w = [&](auto sc, int gk) {                   // slot sc <- k-step gk
+        constexpr int S = decltype(sc)::value;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const bf16_t* w = m == 0 ? wv : wt;
+            const int ldw = m == 0 ? ldw_v : ldw_t;
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf) {
+                const int d = CF * 32 * wave + 32 * cf + l31;
+                const int k = 16 * gk + 8 * half;          // (the weights are zero-padded to a multiple of 64 columns)
+                if constexpr (WF) {
+                    if (k < ldw) wb[S][m][cf] = *reinterpret_cast<const bf16x8*>(w + (((size_t)(CF * wave + cf) * (ldw / 16) + gk) * 64 + lane) * 8);
+                    else wb[S][m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+                } else if (d < g.D && k < ldw) wb[S][m][cf] = *reinterpret_cast<const bf16x8*>(w + (size_t)d * ldw + k);
+                else wb[S][m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+            }
+        }
+    };
+    static_for<NSLOT - 1>([&](auto sc) { load_w(sc, decltype(sc)::value); });
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) fetch((c + 1) * KC);     // in flight behind this chunk's MFMAs
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 a[2][RF], b[2][CF];
+        static_for<4>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            load_w(IdxC<(ks + NSLOT - 1) % NSLOT>{}, 4 * c + ks + NSLOT - 1);      // NSLOT - 1 k-steps ahead (past the end: zeros, never used)
+            bf16x8 a[2][RF];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const unsigned char* tile = lds + A0 + (buf * 2 + m) * ATILE;
 #pragma unroll
                 for (int rf = 0; rf < RF; ++rf) a[m][rf] = Operand<bf16_t>::load(tile, 32 * rf + l31, ks, half);
-                const bf16_t* w = m == 0 ? wv : wt;
-                const int ldw = m == 0 ? ldw_v : ldw_t;
-#pragma unroll
-                for (int cf = 0; cf < CF; ++cf) {
-                    const int d = CF * 32 * wave + 32 * cf + l31;
-                    const int k = c * KC + 16 * ks + 8 * half;             // (the weights are zero-padded to a multiple of 64 columns)
-                    if constexpr (WF) {
-                        if (k < ldw) b[m][cf] = *reinterpret_cast<const bf16x8*>(w + (((size_t)(CF * wave + cf) * (ldw / 16) + (c * 4 + ks)) * 64 + lane) * 8);
-                        else b[m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-                    } else if (d < g.D && k < ldw) b[m][cf] = *reinterpret_cast<const bf16x8*>(w + (size_t)d * ldw + k);
-                    else b[m][cf] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-                }
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-                    for (int cf = 0; cf < CF; ++cf) acc[m][rf][cf] = mfma_32x32x16_bf16(a[m][rf], b[m][cf], acc[m][rf][cf]);
-        }
+                    for (int cf = 0; cf < CF; ++cf) acc[m][rf][cf] = mfma_32x32x16_bf16(a[m][rf], wb[ks % NSLOT][m][cf], acc[m][rf][cf]);
+        });
         if (c + 1 < nchunks) commit(buf ^ 1);          // (the other buffer: its readers finished before the last barrier)
         __syncthreads();
     }
