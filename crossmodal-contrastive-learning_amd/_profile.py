@@ -14,7 +14,7 @@ from . import loss as L
 
 
 def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
-                compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None
+                compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None, settle: int = 0
                 ) -> Dict[str, float]:
     """Median milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
     backward, backward_finish; forward_save / backward_saved when the plan has the save-for-backward pair -- those two
@@ -64,6 +64,12 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
                                                                   text.stride(0), ws.in_dtype, p(ws.inv_norm), t, sw_lw,
                                                                   p(go), p(gv), p(gt), gv.stride(0), gt.stride(0), stream),
     }
+    # settle: untimed rounds of the two heavy kernels first (a freshly acquired MI355X runs its first ~20-50 steps ~9 % slower; bench.py has
+    # its own settle steps, the tuning tools ask for some here)
+    for _ in range(settle):
+        for name in ("forward_save", "backward_saved"):
+            if stages.get(name) is not None:
+                nat.check(stages[name]())
     out = {}
     # the stages a training step runs first, the recomputing entry points (the long `backward`) last: they are what is compared
     order = ["normalize", "normalize_plain", "forward_save", "forward_finish", "backward_saved", "backward_saved_xf1", "backward_saved_lds",

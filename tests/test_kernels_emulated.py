@@ -488,7 +488,7 @@ def test_double_backward_matches_the_reference_and_never_returns_a_constant():
     assert a.grad is not None
 
 
-@pytest.mark.parametrize("B,D,weighted", [(40, 1100, False), (150, 1030, True)])
+@pytest.mark.parametrize("B,D,weighted", [(40, 1100, False), (70, 1030, True)])
 def test_wide_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
     """1024 < D <= 4096, bf16: the generic symmetric forward leaves bf16 records in the register-resident layout (128-row blocks) and the
     D-slice saved backward runs as column parts of 384 / 512 columns -- against the streaming float64 oracle (reference: loss.py:83-112,

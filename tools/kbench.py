@@ -10,7 +10,7 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 mode = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 v, t = orc.make_inputs("randn", B, D, 1234)
 v, t = v.cuda(), t.cuda()
-st = _profile.stage_times(v, t, 0.03, 0.8, mode, iters=20, warmup=3)
+st = _profile.stage_times(v, t, 0.03, 0.8, mode, iters=20, warmup=3, settle=int(os.environ.get("KBENCH_SETTLE", "30")))
 peak = 2500.0 if mode == "bf16" else 157.3
 f = 6.0 * B * B * D / (st["step_forward"] * 1e-3) / 1e12
 b = 8.0 * B * B * D / (st["step_backward"] * 1e-3) / 1e12
