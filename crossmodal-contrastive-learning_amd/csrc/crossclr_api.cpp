@@ -57,6 +57,7 @@ extern "C" const char* crossclr_backend(void) {
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static const float* const kNoF = nullptr;     // (kernel arguments a launch does not use)
 
 // tuning knobs from the environment, read ONCE per process (not per call: crossclr_make_plan sits on the step's host path)
 struct EnvKnobs {
@@ -679,9 +680,9 @@ extern "C" int crossclr_backward_saved(const crossclr_plan* plan, const void* xh
 #define CROSSCLR_LS32(DC)                                                                                                              \
     do {                                                                                                                               \
         if (krows) LAUNCH((bwd_saved32_kernel<DC, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,            \
-                          (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                               \
+                          (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows, kNoF, kNoF, kNoF);                                               \
         else LAUNCH((bwd_saved32_kernel<DC, false>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,                 \
-                    (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                                     \
+                    (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows, kNoF, kNoF, kNoF);                                                     \
     } while (0)
         if (plan->Dpad % 256 == 0) CROSSCLR_LS32(256);
         else if (plan->Dpad % 128 == 0) CROSSCLR_LS32(128);
@@ -968,9 +969,9 @@ extern "C" int crossclr_backward_saved_s(const crossclr_plan* plan, const void* 
 #define CROSSCLR_LS32R(DC)                                                                                                             \
     do {                                                                                                                               \
         if (krows) LAUNCH((bwd_saved32_kernel<DC, true, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,      \
-                          (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                               \
+                          (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows, kNoF, kNoF, kNoF);                                               \
         else LAUNCH((bwd_saved32_kernel<DC, false, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat,           \
-                    (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows);                                                     \
+                    (const float*)stash, g, rz, wrz, gbuf, accumulate, tps, krows, kNoF, kNoF, kNoF);                                                     \
     } while (0)
     if (plan->Dpad % 256 == 0) CROSSCLR_LS32R(256);
     else if (plan->Dpad % 128 == 0) CROSSCLR_LS32R(128);
@@ -1081,7 +1082,12 @@ extern "C" size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nrank
 #ifdef CROSSCLR_NO_FAST
     return 0;
 #else
-    if (!plan || !plan->stash_bytes || !plan->fast_path || nranks < 1) return 0;
+    if (!plan || !plan->stash_bytes || nranks < 1) return 0;
+    if (!plan->fast_path && plan->mode == CROSSCLR_MODE_FP32) {   // exact-fp32 plans: fp32 fragments of the rectangular block, up to 16 GiB
+        const size_t sb = (size_t)(2 * plan->bpad / 32) * (size_t)(2 * plan->bpad / 32) * (size_t)nranks * 4096;
+        return sb <= ((size_t)16 << 30) && plan->operand_bytes * (size_t)plan->world < ((size_t)1 << 32) ? sb : 0;
+    }
+    if (!plan->fast_path) return 0;
     return fast_stash_bytes_rect(plan->bpad, plan->Dpad, nranks);
 #endif
 }
@@ -1094,6 +1100,22 @@ extern "C" int crossclr_forward_rect_save(const crossclr_plan* plan, const void*
 #ifdef CROSSCLR_NO_FAST
     return fail(CROSSCLR_E_ARG, "crossclr_forward_rect_save needs the register-resident path");
 #else
+    if (plan->stash_bytes && !plan->fast_path && plan->mode == CROSSCLR_MODE_FP32) {
+        // exact-fp32 plans: the generic forward over the rank range, leaving its fp32 fragments behind ([row group][fragments of the range])
+        if (with_colsums) return fail(CROSSCLR_E_ARG, "exact-fp32 plans have no pair scheme (with_colsums must be 0)");
+        if (!crossclr_rect_stash_bytes(plan, nranks)) return fail(CROSSCLR_E_ARG, "rectangular stash too large for this plan");
+        if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+            return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+        const float *kr32, *kc32;
+        if (int rk = unpack_k(sw, &kr32, &kc32)) return rk;
+        Geo g32;
+        int rc32 = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g32);
+        if (rc32) return rc32;
+        int* header32 = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+        rc32 = device_zero_header(header32, stream);
+        if (rc32) return rc32;
+        return forward_generic(plan, g32, xhat_rows, xhat_all, part + (size_t)slot0 * 2 * plan->bpad, kc32, nullptr, 0, stream, static_cast<float*>(stash));
+    }
     if (!plan->stash_bytes || !plan->fast_path) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
     if (with_colsums && nranks > (plan->world - 1) / 2) return fail(CROSSCLR_E_ARG, "a pair range holds at most (world-1)/2 ranks");
     if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
@@ -1126,6 +1148,29 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
 #ifdef CROSSCLR_NO_FAST
     return fail(CROSSCLR_E_ARG, "crossclr_backward_rect_saved needs the register-resident path");
 #else
+    if (plan->stash_bytes && !plan->fast_path && plan->mode == CROSSCLR_MODE_FP32) {   // exact-fp32 plans: bwd_saved32_kernel<..., RECT>
+        const float *kr32, *kc32;
+        if (int rk = unpack_k(sw, &kr32, &kc32)) return rk;
+        Geo g32;
+        int rc32 = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g32);
+        if (rc32) return rc32;
+        const int NQ = nranks * (2 * plan->bpad / 32);
+        const int tps32 = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
+        const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;
+        dim3 block(256);
+#define CROSSCLR_LS32X(DC)                                                                                                                    \
+    do {                                                                                                                                      \
+        if (kr32) LAUNCH((bwd_saved32_kernel<DC, true, false, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat_all,   \
+                         (const float*)stash, g32, rz_rows, wrz_rows, gbuf, accumulate, tps32, kr32, rz_all, wrz_all, kc32);                  \
+        else LAUNCH((bwd_saved32_kernel<DC, false, false, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat_all,       \
+                    (const float*)stash, g32, rz_rows, wrz_rows, gbuf, accumulate, tps32, kr32, rz_all, wrz_all, kc32);                       \
+    } while (0)
+        if (plan->Dpad % 256 == 0) CROSSCLR_LS32X(256);
+        else if (plan->Dpad % 128 == 0) CROSSCLR_LS32X(128);
+        else CROSSCLR_LS32X(64);
+#undef CROSSCLR_LS32X
+        return launch_status("bwd_saved32_kernel (rect)");
+    }
     if (!plan->stash_bytes || !plan->fast_path) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
     const float *krows, *kcols;
     if (int rk = unpack_k(sw, &krows, &kcols)) return rk;

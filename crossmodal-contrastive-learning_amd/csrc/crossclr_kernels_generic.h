@@ -471,12 +471,16 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                             *reinterpret_cast<B4*>(rec) = pk;
                         }
                     } else if constexpr (ST) {
-                        const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (ct.row0 + 64 * wc + 32 * qi) >> 5;
-                        const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);     // floats of one matrix
-                        *reinterpret_cast<f32x4*>(stash + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = ev;
-                        if (MODE == 2) *reinterpret_cast<f32x4*>(stash + nn + ((p32 * (size_t)(2 * g.bpad / 32) + q32) << 10) + 256 * r4 + 4 * lane) = etv;
+                        // fragment (p32, q32): q32 counts the 32-column fragments of THIS launch's column range (the local block: the stacked
+                        // operand; a rectangular launch over other ranks' columns -- exact-fp32 sharded runs, crossclr_forward_rect_save --:
+                        // its col_ranks segments in launch order), NQs fragments per row group
+                        const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (size_t)4 * t + 2 * wc + qi;
+                        const size_t NQs = (size_t)g.col_ranks * (size_t)(2 * g.bpad / 32);
+                        const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);     // floats of one matrix (local block)
+                        *reinterpret_cast<f32x4*>(stash + ((p32 * NQs + q32) << 10) + 256 * r4 + 4 * lane) = ev;
+                        if (MODE == 2) *reinterpret_cast<f32x4*>(stash + nn + ((p32 * NQs + q32) << 10) + 256 * r4 + 4 * lane) = etv;
                         if (SYM && mirror) {   // fragment (q32, p32): lane' = column q, element of row p at [p >> 3][half' = (p >> 2) & 1][p & 3]
-                            float* tf = stash + ((q32 * (size_t)(2 * g.bpad / 32) + p32) << 10) + 256 * (l31 >> 3) + 128 * ((l31 >> 2) & 1) + (l31 & 3);
+                            float* tf = stash + ((q32 * NQs + p32) << 10) + 256 * (l31 >> 3) + 128 * ((l31 >> 2) & 1) + (l31 & 3);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) tf[4 * (8 * r4 + 4 * half + j)] = pad_row ? 0.f : etv[j];      // U[q][p]
                             if (MODE == 2) {

@@ -12,16 +12,21 @@
 //   * the [32][DC] slice of X arrives by buffer-addressed LDS-DMA, two stages, one DMA-preserving barrier per tile;
 //   * the loads of tile t+1 (E, statistics, X slice) are issued before the 64 MFMAs of tile t;
 //   * 2 blocks per CU (<= 80 KiB of LDS, <= 256 registers): the other block's MFMAs cover this block's weight arithmetic.
-// Local block only (rows and columns are the same operand); blocks of other ranks keep the recomputing kernel.
+// RECT (round 4): the same product for a RECTANGULAR block -- this rank's rows against the columns of other ranks (g = the rank range of
+// crossclr_forward_rect_save, wrapping inside the gathered operand `xc`; column statistics from the gathered arrays) -- from the fp32
+// fragments the generic forward saved for that launch ([row group][fragments of the launch's column range]).
 #pragma once
 
 namespace crossclr {
 
 // RM (two-pass soft-max, small temperatures): the stash holds U[p][q] = exp2(x - shift_p) and, behind it, Ut[p][q] = U[q][p];
 // rz = omega / (row sum relative to the ROW's shift), so the weight is U[p][q] rz_p + Ut[p][q] rz_q.
-template <int DC, bool SW, bool RM = false>
+template <int DC, bool SW, bool RM = false, bool RECT = false>
 __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, const float* stash, Geo g, const float* rz, const float* wrz,
-                                                             float* gbuf, int accumulate, int tiles_per_slice, const float* k) {
+                                                             float* gbuf, int accumulate, int tiles_per_slice, const float* k,
+                                                             const float* rzc, const float* wrzc, const float* kc) {
+    static_assert(!(RM && RECT), "rectangular blocks: the single-pass soft-max only");
+    // (RECT: x = the gathered column operand, rz / wrz / k = this rank's ROW statistics, rzc / wrzc / kc = the gathered column statistics)
     constexpr int QT = 32;
     constexpr int STG = QT * DC * 4;          // bytes per stage: [32][DC] floats, rows contiguous
     constexpr int NR = DC / 32;               // DMA rounds per tile: 256 threads x 16 B = 4 KiB each
@@ -33,7 +38,7 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
     const int wr = wave & 1, wc = wave >> 1;
     const int row0 = blockIdx.x * 64, d0 = blockIdx.y * DC;
     const int rmod = row0 / g.bpad;
-    const int NQ = 2 * g.bpad / QT;
+    const int NQ = (RECT ? g.col_ranks : 1) * (2 * g.bpad / QT);
     const int t_begin = blockIdx.z * tiles_per_slice;
     int t_stop = t_begin + tiles_per_slice;
     if (t_stop > NQ) t_stop = NQ;
@@ -48,7 +53,7 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
     const float rzp_inter = rz[p], rzp_intra = wrz[p];
     const float kp = SW ? k[p] : 1.f;
     const size_t pitch = (size_t)g.Dpad * 4;
-    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * pitch));
+    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)(RECT ? (g.col_wrap > 0 ? g.col_wrap : g.col_ranks) : 1) * 2 * g.bpad * pitch));
     unsigned voff[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -59,21 +64,23 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
     auto issue_x = [&](int t, int stage) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-            lds_dma16_buf(rs_x, voff[r], (unsigned)((size_t)t * QT * pitch), lds + stage * STG + (4 * r + wave) * 1024);
+            lds_dma16_buf(rs_x, voff[r], (unsigned)((RECT ? col_tile(g, t, QT).row0 : (size_t)t * QT) * pitch), lds + stage * STG + (4 * r + wave) * 1024);
     };
     // fragment (p32, t) of the stash: [r4][lane][4]
     const float* frag_row0 = stash + (((size_t)(row0 / 32 + wr) * (size_t)NQ) << 10) + 4 * lane;
     f32x4 e[4], et[4], rq[4], kq[4];
     const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);
     auto fetch = [&](int t) {
-        const bool same = (t * QT >= g.bpad) == (rmod == 1);
-        const float* stat = (same ? wrz : rz) + t * QT + 4 * half;
+        const ColTile ct = RECT ? col_tile(g, t, QT) : ColTile{};
+        const bool same = RECT ? (ct.mod == rmod) : ((t * QT >= g.bpad) == (rmod == 1));
+        const size_t s0 = RECT ? ct.stat0 : (size_t)t * QT;
+        const float* stat = (same ? (RECT ? wrzc : wrz) : (RECT ? rzc : rz)) + s0 + 4 * half;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             e[r4] = *reinterpret_cast<const f32x4*>(frag_row0 + ((size_t)t << 10) + 256 * r4);
             if (RM) et[r4] = *reinterpret_cast<const f32x4*>(frag_row0 + nn + ((size_t)t << 10) + 256 * r4);
             rq[r4] = *reinterpret_cast<const f32x4*>(stat + 8 * r4);
-            if (SW) kq[r4] = *reinterpret_cast<const f32x4*>(k + t * QT + 4 * half + 8 * r4);
+            if (SW) kq[r4] = *reinterpret_cast<const f32x4*>((RECT ? kc : k) + s0 + 4 * half + 8 * r4);
         }
     };
     if (t_begin < t_stop) { issue_x(t_begin, 0); fetch(t_begin); }
@@ -82,7 +89,7 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
         wait_dma();                 // X slice of tile t (own pieces) and the E / statistics registers of tile t
         barrier_keep_dma();         // ... for every wave; and every wave is done with tile t-1's stage
         // weights of tile t: W[p][q] = E (rz_p + rz_q); sample weights: E (rz_p k_q + rz_q k_p) inside a modality
-        const bool same = (t * QT >= g.bpad) == (rmod == 1);
+        const bool same = RECT ? (col_tile(g, t, QT).mod == rmod) : ((t * QT >= g.bpad) == (rmod == 1));
         const float rzp = same ? rzp_intra : rzp_inter;
         float w[16];
 #pragma unroll

@@ -736,8 +736,22 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     elif sharded:
         gather.wait()
         k_cols_ready()
-        nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
-                                         ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, stream))
+        # exact-fp32 plans with a backward to follow: the block against the other world - 1 ranks saves its fp32 exponentials too
+        # (crossclr_forward_rect_save / crossclr_backward_rect_saved on the generic kernels: 1 GiB per rank-block at b = 8192), so that
+        # the backward of the remote blocks is the gradient product alone (2.3 instead of 6.8 ms per 8192^2 block)
+        rect_bytes = 0
+        if (mode == nat.MODE_FP32 and world >= 2 and ws.stash is not None and stash_everywhere and
+                os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1"):
+            rect_bytes = int(lib.crossclr_rect_stash_bytes(pp, world - 1))
+        st_r = _alloc_stash(rect_bytes, dev) if rect_bytes > 0 else None
+        if st_r is not None:
+            first = (rank + 1) % world
+            nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), first, world - 1, 0, ws.temperature, ws.negative_w,
+                                                     _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, None, _ptr(st_r), stream))
+            ws.saved_blocks, ws.recompute_ranges = [(first, world - 1, st_r)], []
+        else:
+            nat.check(lib.crossclr_forward_w(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature,
+                                             ws.negative_w, _sw(ws.k_rows, ws.k_cols, None), _ptr(part), plan.fwd_slots, stream))
     with _Range("crossclr.forward_finish"):
         nat.check(lib.crossclr_forward_finish_w(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), ws.temperature,
                                                 ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.logz), _ptr(ws.rz),

@@ -254,7 +254,10 @@ int crossclr_backward_saved_s(const crossclr_plan* plan, const void* xhat, const
  * crossclr_backward_rect_saved consumes it: gbuf += W . xhat over those ranks' columns without recomputing the similarity
  * product (rz_all / wrz_all / sw->neg_scale_cols: the gathered [world][2][bpad] statistics).  The blocks OTHER ranks
  * evaluated (ranks rank-1 .. rank-(world-1)/2) are not held here: crossclr_backward_ranks recomputes them
- * (crossclr_backward_w over a wrapping rank range).                                                                   */
+ * (crossclr_backward_w over a wrapping rank range).
+ * Exact-fp32 plans (round 4): the same three entry points with with_colsums = 0 -- the generic forward over the rank range leaves its fp32
+ * fragments (4 KiB per 32 x 32 fragment: 1 GiB per rank at b = 8192, up to 16 GiB; crossclr_rect_stash_bytes says 0 beyond) and
+ * crossclr_backward_rect_saved is the gradient product alone (bwd_saved32_kernel<..., RECT>).                            */
 size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nranks);
 int crossclr_forward_rect_save(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
                                int first_rank, int nranks, int with_colsums, float temperature, float negative_weight,

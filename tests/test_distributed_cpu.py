@@ -45,6 +45,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
             calls = []
             real = nat.library().crossclr_backward_saved_xfp      # (the pair kernel: what the module takes for a stash below 4 GiB)
             nat.library().crossclr_backward_saved_xfp = lambda *a: (calls.append(1), real(*a))[1]
+        rect_calls = []
+        if "rectsave" in knobs:  # exact-fp32 sharded run: the block against the other ranks saves its fp32 exponentials (crossclr_forward_rect_save
+            real_r = nat.library().crossclr_backward_rect_saved       # on the generic kernels) and the backward is the gradient product alone
+            nat.library().crossclr_backward_rect_saved = lambda *a: (rect_calls.append(1), real_r(*a))[1]
         v, t = orc.make_inputs("randn", B, D, 77)
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
@@ -54,6 +58,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         loss.backward()
         if "xf" in knobs:
             assert len(calls) == 1, "the local block did not take the fragment-major backward"
+        if "rectsave" in knobs:
+            assert len(rect_calls) == 1, "the remote blocks of the fp32 run did not take the saved backward"
         # forward only (no_grad): nothing is saved, no statistics gather; point-to-point exchange: nobody waits for the late
         # slices in a backward, the forward itself must; generic kernels: the local block takes the symmetric evaluation
         with torch.no_grad():
@@ -79,6 +85,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        (3, 18, 16, "fp32/0.002", 1e-4, 1e-3),
                                                        (2, 40, 48, "bf16", 5e-3, 2e-2),
                                                        (3, 18, 16, "fp32", 1e-5, 2e-4),
+                                                       # exact-fp32 sharded runs: the remote blocks from saved fp32 exponentials (rectangular stash);
+                                                       # 150 rows per rank: several 128-row blocks per modality, ragged
+                                                       (2, 24, 20, "fp32+rectsave", 1e-5, 2e-4),
+                                                       (3, 450, 24, "fp32+rectsave", 1e-5, 2e-4),
                                                        # bf16 with >= 3 ranks: pair scheme + PARTNER GRADIENTS (the evaluator of a pair block
                                                        # also forms its transposed contribution to the partner's gradient and ships it)
                                                        (3, 24, 16, "bf16", 5e-3, 2e-2),

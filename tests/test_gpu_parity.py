@@ -175,9 +175,12 @@ def test_properties_at_full_size():
     assert crossclr_amd.crossclr_loss(vd, td, 0.03, 0.8, compute_mode="bf16").item() == base
 
 
-def _shard_via_cabi(v, t, world, mode):
+def _shard_via_cabi(v, t, world, mode, saved=False):
     """Drive the C-ABI exactly like `world` ranks would, on one GPU: every rank normalises its rows
-    into its slice of the gathered operand, then forward/backward run against all column ranks."""
+    into its slice of the gathered operand, then forward/backward run against all column ranks.
+    saved (exact-fp32 plans): the local block and the block against the other ranks save their fp32 exponentials
+    (crossclr_forward_save / crossclr_forward_rect_save) and the backward is the gradient product alone (crossclr_backward_saved /
+    crossclr_backward_rect_saved on bwd_saved32_kernel)."""
     lib = nat.library()
     p = L._ptr
     B, D = v.shape
@@ -197,13 +200,22 @@ def _shard_via_cabi(v, t, world, mode):
     rz = torch.empty(world, 2 * pl.bpad, **f32)
     wrz = torch.empty(world, 2 * pl.bpad, **f32)
     total = torch.zeros(1, dtype=torch.float64, device=dev)
+    stashes = []
     for r in range(world):
         pp = ctypes.byref(plans[r])
         xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
         part = torch.empty(pl.fwd_ws_floats, **f32)
         # local block first, then every other rank's columns (skip_rank = r): the overlap schedule
-        nat.check(lib.crossclr_forward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(part), 0, stream))
-        nat.check(lib.crossclr_forward(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(part), pl.fwd_slots, stream))
+        if saved:
+            stashes.append((torch.empty(pl.stash_bytes, dtype=torch.uint8, device=dev),
+                            torch.empty(lib.crossclr_rect_stash_bytes(pp, world - 1), dtype=torch.uint8, device=dev)))
+            assert stashes[-1][1].numel() > 0
+            nat.check(lib.crossclr_forward_save(pp, p(xr), 0.03, 0.8, None, p(part), 0, p(stashes[-1][0]), stream))
+            nat.check(lib.crossclr_forward_rect_save(pp, p(xr), p(xall), (r + 1) % world, world - 1, 0, 0.03, 0.8, None, p(part), pl.fwd_slots,
+                                                     None, p(stashes[-1][1]), stream))
+        else:
+            nat.check(lib.crossclr_forward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(part), 0, stream))
+            nat.check(lib.crossclr_forward(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(part), pl.fwd_slots, stream))
         logz = torch.empty(2 * pl.bpad, **f32)
         ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device=dev)
         nat.check(lib.crossclr_forward_finish(pp, p(part), 2 * pl.fwd_slots, p(diag[r]), 0.03, 0.8, p(logz), p(rz[r]),
@@ -217,15 +229,36 @@ def _shard_via_cabi(v, t, world, mode):
         pp = ctypes.byref(plans[r])
         xr = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
         gbuf = torch.empty(pl.gbuf_bytes // 4, **f32)
-        nat.check(lib.crossclr_backward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz[r]), p(wrz[r]),
-                                        p(gbuf), 0, stream))
-        nat.check(lib.crossclr_backward(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
-                                        p(gbuf), 1, stream))
+        if saved:
+            nat.check(lib.crossclr_backward_saved(pp, p(xr), p(stashes[r][0]), 0.03, 0.8, p(rz[r]), p(wrz[r]), None, p(gbuf), 0, stream))
+            nat.check(lib.crossclr_backward_rect_saved(pp, p(xall), p(stashes[r][1]), (r + 1) % world, world - 1, 0.03, 0.8, p(rz[r]), p(wrz[r]),
+                                                       p(rz), p(wrz), None, p(gbuf), 1, stream))
+        else:
+            nat.check(lib.crossclr_backward(pp, p(xr), p(xr), 1, r, -1, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz[r]), p(wrz[r]),
+                                            p(gbuf), 0, stream))
+            nat.check(lib.crossclr_backward(pp, p(xr), p(xall), world, 0, r, 0.03, 0.8, p(rz[r]), p(wrz[r]), p(rz), p(wrz),
+                                            p(gbuf), 1, stream))
         nat.check(lib.crossclr_backward_finish(pp, p(gbuf), p(v[r * b:]), p(t[r * b:]), v.stride(0), t.stride(0),
                                                nat.IN_F32, p(inv[r]), 0.03, p(go), p(gv[r * b:]), p(gt[r * b:]),
                                                gv.stride(0), gt.stride(0), stream))
     torch.cuda.synchronize()
     return loss.item(), gv, gt
+
+
+@pytest.mark.parametrize("world,B,D", [(2, 512, 128), (3, 300, 96), (4, 2048, 512), (8, 1024, 200)])
+def test_fp32_sharded_blocks_from_saved_exponentials_equal_single_device(world, B, D):
+    """Exact-fp32 sharded runs (round 4): the remote blocks save their fp32 exponentials too (rectangular stash of the generic forward) and the
+    backward of those blocks is bwd_saved32_kernel<..., RECT>; one GPU plays every rank through the C-ABI; against the single-device module
+    and the streaming float64 oracle."""
+    v, t = orc.make_inputs("randn", B, D, 37)
+    loss1, gv1, gt1 = run_module(v, t, dict(temperature=0.03, negative_weight=0.8), "fp32")
+    lossN, gvN, gtN = _shard_via_cabi(v.cuda(), t.cuda(), world, nat.MODE_FP32, saved=True)
+    assert abs(lossN - loss1.item()) <= 1e-6 * max(1.0, abs(lossN))
+    scale = gv1.abs().max().item()
+    assert (gvN - gv1).abs().max().item() <= 1e-5 * scale and (gtN - gt1).abs().max().item() <= 1e-5 * scale
+    ref = orc.streaming_loss_and_grads(v, t, 0.03, 0.8)
+    assert abs(lossN - float(ref["loss"])) <= 1e-5
+    assert (gvN.double().cpu() - ref["grad_v"]).abs().max().item() <= 2e-4 * scale
 
 
 @pytest.mark.parametrize("world,B,D,mode", [(2, 512, 128, nat.MODE_FP32), (4, 1024, 512, nat.MODE_BF16),
