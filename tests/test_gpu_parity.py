@@ -421,11 +421,12 @@ def test_global_batch_scale_on_one_gpu():
     assert radial <= 1e-3 * v.grad.double().norm(dim=1).max().item() * v.detach().double().norm(dim=1).max().item()
 
 
-def test_step_is_hip_graph_capturable():
+@pytest.mark.parametrize("B,D,tau", [(512, 256, 0.03), (512, 1536, 0.03), (512, 256, 0.004)])
+def test_step_is_hip_graph_capturable(B, D, tau):
     """No entry point synchronises the host or allocates device memory itself, so a whole fwd+bwd step can be
-    captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new data."""
-    B, D = 512, 256
-    crit = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()
+    captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new data -- also a wide plan (generic forward that saves + the
+    D-slice backward in column parts) and a bf16 plan in the two-pass regime (whose forward zero-fills the statistics behind its stash)."""
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(tau, 0.8, compute_mode="bf16").cuda()
     v0, t0 = orc.make_inputs("randn", B, D, 1)
     v1, t1 = orc.make_inputs("randn", B, D, 2)
     sv = v0.cuda().requires_grad_(True)
