@@ -246,3 +246,71 @@ def test_mismatched_rows_per_rank_raise_a_clear_error():
         p.join(timeout=60)
     for rank, msg in results:
         assert "same number of rows" in msg, msg
+
+
+def _projected_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import torch.nn.functional as F
+        import crossclr_amd
+        from crossclr_amd import _native as nat
+        from emu import build_emu
+        from oracle import crossclr_oracle as orc
+        nat.use_library_for_testing(build_emu.OUT)
+        B, din_v, din_t, D = 24 * world, 24, 40, 32
+        g = torch.Generator().manual_seed(91)
+        xv, xt = torch.randn(B, din_v, generator=g), torch.randn(B, din_t, generator=g)
+        wv, wt = torch.randn(D, din_v, generator=g) / din_v ** 0.5, torch.randn(D, din_t, generator=g) / din_t ** 0.5
+        bv, bt = 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+        # reference: float64 autograd of the GLOBAL loss through both projections
+        ref_leaves = [a.double().clone().requires_grad_(True) for a in (xv, xt, wv, bv, wt, bt)]
+        ref_loss = orc.eager_loss(F.linear(ref_leaves[0], ref_leaves[2], ref_leaves[3]), F.linear(ref_leaves[1], ref_leaves[4], ref_leaves[5]), 0.05, 0.7)
+        ref_loss.backward()
+        b = B // world
+        leaves = [xv[rank * b:(rank + 1) * b].clone().requires_grad_(True), xt[rank * b:(rank + 1) * b].clone().requires_grad_(True),
+                  wv.clone().requires_grad_(True), bv.clone().requires_grad_(True), wt.clone().requires_grad_(True), bt.clone().requires_grad_(True)]
+        loss = crossclr_amd.projected_crossclr_loss(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], leaves[5], 0.05, 0.7,
+                                                    process_group=dist.group.WORLD)
+        loss.backward()
+        errs = []
+        # inputs: this rank's rows of the global gradient; weights / biases: the ranks' contributions add up to the global gradient
+        for k in (0, 1):
+            want = ref_leaves[k].grad[rank * b:(rank + 1) * b]
+            errs.append((leaves[k].grad.double() - want).abs().max().item() / want.abs().max().item())
+        for k in (2, 3, 4, 5):
+            tot = leaves[k].grad.double().clone()
+            dist.all_reduce(tot)
+            errs.append((tot - ref_leaves[k].grad).abs().max().item() / ref_leaves[k].grad.abs().max().item())
+        q.put((rank, loss.item(), ref_loss.item(), max(errs)))
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), 0.0))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fused_projection_in_a_sharded_run_over_gloo(world):
+    """ProjectedCrossCLR / projected_crossclr_loss with a process group: projection + pack per rank, the packed operands exchanged, the loss'
+    finish kernel writing g_y for the rank's rows, crossclr_project_dw over them -- inputs get their rows of the global gradient, the ranks'
+    weight / bias gradients add up to the global ones (what DDP's all-reduce forms)."""
+    from emu import build_emu
+    build_emu.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 40 + world
+    procs = [ctx.Process(target=_projected_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, loss, ref, err in sorted(results):
+        assert loss != "error", ref
+        assert abs(loss - ref) <= 2e-3 * max(1.0, abs(ref)), (rank, loss, ref)      # bf16 products in the projection AND the similarities
+        assert err <= 3e-2, (rank, err)
