@@ -16,10 +16,12 @@ lin_v.load_state_dict(fused.video_proj.state_dict()); lin_t.load_state_dict(fuse
 crit = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()
 
 def step_fused():
+    xv.grad = xt.grad = None
     fused.zero_grad(set_to_none=True)
     loss = fused(xv, xt); loss.backward(); return loss
 
 def step_unfused():
+    xv.grad = xt.grad = None
     lin_v.zero_grad(set_to_none=True); lin_t.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         yv, yt = lin_v(xv), lin_t(xt)
@@ -34,10 +36,11 @@ def timed(fn, warm=30, n=50):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n, last.item()
 
+xgrad = os.environ.get("PROJ_XGRAD") == "1"      # the projections' inputs require a gradient too (an encoder in front): dx = g_y W is formed
 only = os.environ.get("PROJ_BENCH")      # "fused" / "unfused": one path only (for a kernel trace of that path)
 for xdt in (torch.float32, torch.bfloat16):
-    xv, xt = xv.to(xdt), xt.to(xdt)
+    xv, xt = xv.detach().to(xdt).requires_grad_(xgrad), xt.detach().to(xdt).requires_grad_(xgrad)
     mf, lf = timed(step_fused) if only != "unfused" else (float("nan"), float("nan"))
     mu, lu = timed(step_unfused) if only != "fused" else (float("nan"), float("nan"))
-    print(f"b={b} Din={din} D={D} inputs {str(xdt).split('.')[-1]}: fused projection + loss {mf:.3f} ms/step (loss {lf:.5f}); "
+    print(f"b={b} Din={din} D={D} inputs {str(xdt).split('.')[-1]}{' (requiring grad)' if xgrad else ''}: fused projection + loss {mf:.3f} ms/step (loss {lf:.5f}); "
           f"nn.Linear (bf16 autocast) + loss {mu:.3f} ms/step (loss {lu:.5f})", flush=True)
