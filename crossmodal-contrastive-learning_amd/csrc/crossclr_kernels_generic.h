@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) xf_from_packed_kernel(const bf16_t* X, un
 //   mirrored tile's fragment belongs (16 scalar stores per lane and fragment: the stash stays the full matrix the backward reads).  The launch announces itself in `header` as kind 4 (dense slots +
 //   column sums of the row blocks above); fwd_finish_kernel adds them up in a fixed order.  4.06 B^2 D instead of 8 B^2 D executed.
 template <typename T, bool SW, int MODE, bool ST = false, bool SYM = false>
-__global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
+__global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T* cols, Geo g, int tiles_per_split,
                                                        float* part, const float* kcols, const float* shift, float* stash, int* header,
                                                        float* colpart) {
     static_assert(!ST || MODE == 0 || MODE == 2, "exponentials are saved by the passes that form sums");
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
     float myshift[2] = {0.f, 0.f};
     if (MODE == 2 || MODE == 3) { myshift[0] = shift[row0 + 64 * wr + l31]; myshift[1] = shift[row0 + 64 * wr + 32 + l31]; }
     float rowcnt[2] = {0.f, 0.f};   // MODE 3: active hinge terms
-    KTileStage<128, 256> sp, sq;
+    KTileStage<128, 256> sp, sq, sp2, sq2;
 
     for (int t = t_begin; t < t_end; t += t_step) {
         const ColTile ct = col_tile(g, t, 128);
@@ -362,15 +362,16 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-        sp.fetch(rbase, pitch, 0, tid);
-        sq.fetch(cbase, pitch, 0, tid);
-        for (int kc = 0; kc < nchunks; ++kc) {
-            sp.commit(tileP, tid);
-            sq.commit(tileQ, tid);
+        // Two chunks in flight: while chunk kc is multiplied, the loads of chunks kc + 1 and kc + 2 are outstanding (two
+        // register sets, alternating).  One chunk of look-ahead left a block waiting on HBM/L2 every chunk: 16 MFMAs of
+        // work per wave cover a quarter of a round trip.
+        auto chunk = [&](KTileStage<128, 256>& fp, KTileStage<128, 256>& fq, int kc) {
+            fp.commit(tileP, tid);
+            fq.commit(tileQ, tid);
             __syncthreads();
-            if (kc + 1 < nchunks) {
-                sp.fetch(rbase, pitch, (kc + 1) * 128, tid);
-                sq.fetch(cbase, pitch, (kc + 1) * 128, tid);
+            if (kc + 2 < nchunks) {
+                fp.fetch(rbase, pitch, (kc + 2) * 128, tid);
+                fq.fetch(cbase, pitch, (kc + 2) * 128, tid);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -386,6 +387,16 @@ __global__ void __launch_bounds__(256) fwd_sums_kernel(const T* rows, const T* c
                     for (int pi = 0; pi < 2; ++pi) acc[qi][pi] = Op::mma(a[qi], bfr[pi], acc[qi][pi]);
             }
             __syncthreads();
+        };
+        sp.fetch(rbase, pitch, 0, tid);
+        sq.fetch(cbase, pitch, 0, tid);
+        if (nchunks > 1) {
+            sp2.fetch(rbase, pitch, 128, tid);
+            sq2.fetch(cbase, pitch, 128, tid);
+        }
+        for (int kc = 0; kc < nchunks; kc += 2) {
+            chunk(sp, sq, kc);
+            if (kc + 1 < nchunks) chunk(sp2, sq2, kc + 1);
         }
         // epilogue: e = exp2(c*g - m2), masked, summed into the lane's row
         const bool same_mod = (ct.mod == rmod);
