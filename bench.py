@@ -237,6 +237,19 @@ def secondary_lines(dev):
     case("d1024_bf16_fwd_bwd", 8192, 1024, "bf16", False, False, None)
     case("d1024_influential", 8192, 1024, "bf16", False, True, None)
     case("d1536_bf16_fwd_bwd", 8192, 1536, "bf16", False, False, None)     # beyond the register-resident forward: generic forward + saved D-slice backward in 3 column parts
+    # exact-fp32 sharded run in the two-pass regime (tau = 0.005), rank 0 of 2 through the C-ABI: the block against the other rank from saved
+    # exponentials (U and Ut) -- the last shape whose remote blocks recomputed the similarity product
+    v, t = make_inputs(2 * 8192, 512, 1234)
+    rb = _profile.remote_block_times(v.to(dev), t.to(dev), 0.005, NEG_W, iters=5, warmup=2, recompute=True)
+    tf = 8.0 * 8192 * 8192 * 512 / (rb["backward_rect_saved"] * 1e-3) / 1e12
+    out["tau0005_fp32_sharded_block"] = {
+        "forward_rect_save_ms": round(rb["forward_rect_save"], 4), "backward_rect_saved_ms": round(rb["backward_rect_saved"], 4),
+        "forward_recompute_path_ms": round(rb["forward_recompute_path"], 4), "backward_recompute_ms": round(rb["backward_recompute"], 4),
+        "stash_gib": round(rb["stash_bytes"] / 2.0 ** 30, 3), "dominant_kernel": "backward of the remote block (saved exponentials U and Ut)",
+        "dominant_kernel_ms": round(rb["backward_rect_saved"], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
+        "dominant_kernel_frac_of_peak": round(tf / PEAK_F32_TFLOPS, 4), "peak_tflops": PEAK_F32_TFLOPS,
+        "workload": "rank 0 of 2 through the C-ABI on one GPU: b=8192 rows/rank, D=512, fp32, tau=0.005 (two-pass soft-max), the 16384 x 16384 block "
+                    "against the other rank: second forward pass that saves + saved backward; median of 5 launches"}
     return out
 
 

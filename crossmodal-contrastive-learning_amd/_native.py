@@ -93,6 +93,11 @@ _SIGNATURES = {
                                                   ctypes.c_float, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P, _P, _P]),
     "crossclr_backward_rect_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                     ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
+    "crossclr_rect_stash_bytes_s": (ctypes.c_size_t, [ctypes.POINTER(Plan), ctypes.c_int]),
+    "crossclr_forward_rect_save_s": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                    ctypes.POINTER(SampleWeights), _P, _P, _P, ctypes.c_int, _P, _P]),
+    "crossclr_backward_rect_saved_s": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                      ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, ctypes.c_int, _P]),
     "crossclr_backward_rect_saved_t": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                       ctypes.c_float, _P, _P, _P, _P, ctypes.POINTER(SampleWeights), _P, _P]),
     # ABI version 5: remote blocks on the fragment-major operand (pair kernel), the copy made from received slices

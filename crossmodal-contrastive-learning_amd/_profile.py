@@ -97,3 +97,68 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
     out["step_forward"] = out.get("forward_save", out["forward"])
     out["step_backward"] = out.get("backward_saved", out["backward"])
     return out
+
+
+def remote_block_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float, iters: int = 5, warmup: int = 2,
+                       recompute: bool = True) -> Dict[str, float]:
+    """Exact-fp32 sharded run, rank 0 of 2 driven through the C-ABI on one GPU (`video` / `text` = the rows of BOTH ranks): median
+    milliseconds per launch of the block against the other rank -- the forward that saves its exponentials and the saved backward
+    (single-pass regime: crossclr_forward_rect_save / crossclr_backward_rect_saved; two-pass regime: the `_s` pair, U and Ut), and with
+    `recompute` the recomputing pair beside them (crossclr_forward[_s] / crossclr_backward[_s] over the same columns)."""
+    lib, p = nat.library(), L._ptr
+    B, D = video.shape
+    world, b, dev, stream = 2, B // 2, video.device, L._stream_for(video)
+    plans = [nat.make_plan(b, D, world, r, nat.MODE_FP32) for r in range(world)]
+    pl, pp = plans[0], ctypes.byref(plans[0])
+    f32 = dict(dtype=torch.float32, device=dev)
+    xall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device=dev)
+    inv, diag = torch.empty(2 * pl.bpad, **f32), torch.empty(pl.bpad, **f32)
+    for r in range(world):
+        nat.check(lib.crossclr_normalize(ctypes.byref(plans[r]), p(video[r * b:]), p(text[r * b:]), video.stride(0), text.stride(0), nat.IN_F32,
+                                         p(xall[r * pl.operand_bytes:]), p(inv), p(diag), stream))
+    xr = xall[:pl.operand_bytes]
+    part = torch.empty(pl.fwd_ws_floats, **f32)
+    gbuf = torch.zeros(pl.gbuf_bytes // 4, **f32)
+    rz, wrz = torch.rand(world, 2 * pl.bpad, **f32) * 1e-4, torch.rand(world, 2 * pl.bpad, **f32) * 1e-4
+    T, w = float(temperature), float(negative_w)
+    two_pass = bool(lib.crossclr_needs_row_shift(T, w))
+    stages = {}
+    if two_pass:
+        shift = torch.empty(world, 2 * pl.bpad, **f32)
+        for r in range(world):   # every rank's row maxima over all columns ("gathered")
+            xs = xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes]
+            nat.check(lib.crossclr_forward_rowmax(ctypes.byref(plans[r]), p(xs), p(xall), world, 0, -1, T, w, None, p(part), p(shift[r]), 0, stream))
+        st = torch.empty(lib.crossclr_rect_stash_bytes_s(pp, 1), dtype=torch.uint8, device=dev)
+        stages["forward_rect_save"] = lambda: lib.crossclr_forward_rect_save_s(pp, p(xr), p(xall), 1, 1, T, w, None, p(shift[0]), p(shift), p(part),
+                                                                               pl.fwd_slots, p(st), stream)
+        stages["backward_rect_saved"] = lambda: lib.crossclr_backward_rect_saved_s(pp, p(xall), p(st), 1, 1, T, w, p(rz[0]), p(wrz[0]), p(rz), p(wrz),
+                                                                                   None, p(gbuf), 1, stream)
+        if recompute:
+            stages["forward_recompute_path"] = lambda: lib.crossclr_forward_s(pp, p(xr), p(xall), world, 0, 0, T, w, None, p(shift[0]), p(part),
+                                                                              pl.fwd_slots, stream)
+            stages["backward_recompute"] = lambda: lib.crossclr_backward_s(pp, p(xr), p(xall), world, 0, 0, T, w, p(rz[0]), p(wrz[0]), p(rz), p(wrz),
+                                                                           None, p(shift[0]), p(shift), p(gbuf), 1, stream)
+    else:
+        st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
+        stages["forward_rect_save"] = lambda: lib.crossclr_forward_rect_save(pp, p(xr), p(xall), 1, 1, 0, T, w, None, p(part), pl.fwd_slots, None,
+                                                                             p(st), stream)
+        stages["backward_rect_saved"] = lambda: lib.crossclr_backward_rect_saved(pp, p(xall), p(st), 1, 1, T, w, p(rz[0]), p(wrz[0]), p(rz), p(wrz),
+                                                                                 None, p(gbuf), 1, stream)
+        if recompute:
+            stages["forward_recompute_path"] = lambda: lib.crossclr_forward(pp, p(xr), p(xall), world, 0, 0, T, w, p(part), pl.fwd_slots, stream)
+            stages["backward_recompute"] = lambda: lib.crossclr_backward(pp, p(xr), p(xall), world, 0, 0, T, w, p(rz[0]), p(wrz[0]), p(rz), p(wrz),
+                                                                         p(gbuf), 1, stream)
+    if st.numel() == 0:
+        raise RuntimeError("remote_block_times: this plan has no saved path for remote blocks")
+    out: Dict[str, float] = {"two_pass": float(two_pass), "stash_bytes": float(st.numel())}
+    for name, fn in stages.items():
+        for _ in range(warmup):
+            nat.check(fn())
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, z in ev:
+            a.record()
+            nat.check(fn())
+            z.record()
+        torch.cuda.synchronize(dev)
+        out[name] = sorted(a.elapsed_time(z) for a, z in ev)[iters // 2]
+    return out

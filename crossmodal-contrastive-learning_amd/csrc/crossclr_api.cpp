@@ -88,7 +88,8 @@ static const EnvKnobs& env_knobs() {
 #endif
 }
 static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
-                           const float* kcols, const float* shift, int mode, void* stream, float* stash = nullptr);
+                           const float* kcols, const float* shift, int mode, void* stream, float* stash = nullptr,
+                           const float* shift_cols = nullptr);
 
 // forward workspace ("part") layout, in floats:
 //   [4 launch groups][fwd_slots][2*bpad] | colpart (symmetric launch) [<= 2*bpad/128 row blocks][2*bpad]
@@ -552,7 +553,7 @@ static int forward_generic_sym(const crossclr_plan* plan, const Geo& g, const vo
 }
 
 static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* rows, const void* cols, float* out,
-                           const float* kcols, const float* shift, int mode, void* stream, float* stash) {
+                           const float* kcols, const float* shift, int mode, void* stream, float* stash, const float* shift_cols) {
     const int ntiles = g.col_ranks * 2 * plan->bpad / 128;
     const int nsplit = plan->fwd_slots;
     const int tps = (ntiles + nsplit - 1) / nsplit;
@@ -566,7 +567,7 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
     }
     if (stash) {   // exact-fp32 forward that also saves its exponentials (local block; common shift, or per-row shifts: mode 2)
         dim3 block(256);
-#define CROSSCLR_LSV(SW, MODE) LAUNCH((fwd_sums_kernel<float, SW, MODE, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr)
+#define CROSSCLR_LSV(SW, MODE) LAUNCH((fwd_sums_kernel<float, SW, MODE, true>), grid, block, stream, (const float*)rows, (const float*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, const_cast<float*>(mode == 2 ? shift_cols : nullptr))
         if (mode == 2) { if (kcols) CROSSCLR_LSV(true, 2); else CROSSCLR_LSV(false, 2); }
         else { if (kcols) CROSSCLR_LSV(true, 0); else CROSSCLR_LSV(false, 0); }
 #undef CROSSCLR_LSV
@@ -1067,12 +1068,13 @@ extern "C" int crossclr_backward_s(const crossclr_plan* plan, const void* xhat_r
 
 // ---- rectangular blocks of the sharded step with saved exponentials ------------------------------------------------------
 // `first_rank`, `nranks`: column ranks first_rank .. first_rank+nranks-1 (mod plan->world) of the WHOLE gathered operand.
-static int rect_geo(const crossclr_plan* plan, int first_rank, int nranks, float temperature, float negative_weight, Geo* g) {
+static int rect_geo(const crossclr_plan* plan, int first_rank, int nranks, float temperature, float negative_weight, Geo* g,
+                    bool allow_row_shift = false) {
     if (first_rank < 0 || first_rank >= plan->world || nranks < 1 || nranks >= plan->world)
         return fail(CROSSCLR_E_ARG, "bad first_rank/nranks %d/%d for world %d", first_rank, nranks, plan->world);
     for (int i = 0; i < nranks; ++i)
         if ((first_rank + i) % plan->world == plan->rank) return fail(CROSSCLR_E_ARG, "the rank range must not contain this rank");
-    int rc = make_geo(plan, nranks, first_rank, -1, temperature, negative_weight, g);
+    int rc = make_geo(plan, nranks, first_rank, -1, temperature, negative_weight, g, allow_row_shift);
     if (rc) return rc;
     g->col_wrap = plan->world;
     return CROSSCLR_OK;
@@ -1181,6 +1183,65 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
     return rc ? fail(rc, "fast_backward_saved: unsupported Dpad %d", plan->Dpad) : launch_status("fast_bwd_dsl_kernel (rect)");
 #endif
 }
+
+// ---- the two-pass regime's rectangular blocks (exact-fp32 plans): U and Ut of this rank's rows against other ranks' columns ----------
+extern "C" size_t crossclr_rect_stash_bytes_s(const crossclr_plan* plan, int nranks) {
+    if (!plan || plan->fast_path || plan->mode != CROSSCLR_MODE_FP32) return 0;
+    const size_t one = crossclr_rect_stash_bytes(plan, nranks);
+    return one && 2 * one <= ((size_t)32 << 30) ? 2 * one : 0;
+}
+
+extern "C" int crossclr_forward_rect_save_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank,
+                                            int nranks, float temperature, float negative_weight, const crossclr_sample_weights* sw,
+                                            const float* shift_rows, const float* shift_all, float* part, int slot0, void* stash,
+                                            void* stream) {
+    if (!plan || !xhat_rows || !xhat_all || !shift_rows || !shift_all || !part || !stash) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (!crossclr_rect_stash_bytes_s(plan, nranks))
+        return fail(CROSSCLR_E_ARG, "this plan has no two-pass save-for-backward path for remote blocks (crossclr_rect_stash_bytes_s == 0)");
+    if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
+        return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
+    rc = device_zero_header(header, stream);
+    if (rc) return rc;
+    return forward_generic(plan, g, xhat_rows, xhat_all, part + (size_t)slot0 * 2 * plan->bpad, kcols, shift_rows, 2, stream,
+                           static_cast<float*>(stash), shift_all);
+}
+
+extern "C" int crossclr_backward_rect_saved_s(const crossclr_plan* plan, const void* xhat_all, const void* stash, int first_rank,
+                                              int nranks, float temperature, float negative_weight, const float* rz_rows,
+                                              const float* wrz_rows, const float* rz_all, const float* wrz_all,
+                                              const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream) {
+    if (!plan || !xhat_all || !stash || !rz_rows || !wrz_rows || !rz_all || !wrz_all || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (!crossclr_rect_stash_bytes_s(plan, nranks))
+        return fail(CROSSCLR_E_ARG, "this plan has no two-pass save-for-backward path for remote blocks (crossclr_rect_stash_bytes_s == 0)");
+    const float *krows, *kcols;
+    if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
+    Geo g;
+    int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g, true);
+    if (rc) return rc;
+    const int NQ = nranks * (2 * plan->bpad / 32);
+    const int tps = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
+    const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;
+    dim3 block(256);
+#define CROSSCLR_LS32XS(DC)                                                                                                                  \
+    do {                                                                                                                                     \
+        if (krows) LAUNCH((bwd_saved32_kernel<DC, true, true, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat_all,  \
+                          (const float*)stash, g, rz_rows, wrz_rows, gbuf, accumulate, tps, krows, rz_all, wrz_all, kcols);                  \
+        else LAUNCH((bwd_saved32_kernel<DC, false, true, true>), dim3(rb, plan->Dpad / DC, nz), block, stream, (const float*)xhat_all,       \
+                    (const float*)stash, g, rz_rows, wrz_rows, gbuf, accumulate, tps, krows, rz_all, wrz_all, kcols);                        \
+    } while (0)
+    if (plan->Dpad % 256 == 0) CROSSCLR_LS32XS(256);
+    else if (plan->Dpad % 128 == 0) CROSSCLR_LS32XS(128);
+    else CROSSCLR_LS32XS(64);
+#undef CROSSCLR_LS32XS
+    return launch_status("bwd_saved32_kernel (rect, two-pass)");
+}
+
 
 // The fragment-major copy of `nranks` consecutive packed operands (the slices of a gathered operand a rank received): what the pair
 // kernel's rectangular launches read their column tiles from.

@@ -306,6 +306,9 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
     // (weight U[p][q] rz_p + U[q][p] rz_q), need exp2(x - shift[q]) as well: a second exponential per element; ST keeps both
     // matrices -- U, and Ut[p][q] = U[q][p] behind it at stash + (2 bpad)^2 -- in the layout of the single-pass stash.
     typedef Operand<T> Op;
+    // MODE 2 over OTHER ranks' columns (rectangular launch, not SYM: `colpart` is free): the columns' shifts come from the gathered
+    // [world][2 bpad] array passed in its place, indexed like the gathered statistics; the rows' shifts stay `shift`
+    const float* shift_q = (!SYM && MODE == 2 && colpart != nullptr) ? colpart : shift;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
     unsigned char* tileQ = lds + 128 * 128;     // column operand chunk [128][128 B]
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                     f32x4 ev = {0.f, 0.f, 0.f, 0.f}, etv = {0.f, 0.f, 0.f, 0.f}, shq = {0.f, 0.f, 0.f, 0.f};
                     constexpr bool kNeedColShift = (MODE == 2 && (SYM || (ST && sizeof(T) == 4))) || (MODE == 3 && SYM);   // (bf16 records: U only)
                     if (kNeedColShift)
-                        shq = *reinterpret_cast<const f32x4*>(shift + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
+                        shq = *reinterpret_cast<const f32x4*>(shift_q + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * r4 + j;
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                         // its col_ranks segments in launch order), NQs fragments per row group
                         const size_t p32 = (size_t)(row0 + 64 * wr + 32 * pi) >> 5, q32 = (size_t)4 * t + 2 * wc + qi;
                         const size_t NQs = (size_t)g.col_ranks * (size_t)(2 * g.bpad / 32);
-                        const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);     // floats of one matrix (local block)
+                        const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad) * (size_t)(SYM ? 1 : g.col_ranks);   // floats of one matrix (local block; rectangular: its rank range)
                         *reinterpret_cast<f32x4*>(stash + ((p32 * NQs + q32) << 10) + 256 * r4 + 4 * lane) = ev;
                         if (MODE == 2) *reinterpret_cast<f32x4*>(stash + nn + ((p32 * NQs + q32) << 10) + 256 * r4 + 4 * lane) = etv;
                         if (SYM && mirror) {   // fragment (q32, p32): lane' = column q, element of row p at [p >> 3][half' = (p >> 2) & 1][p & 3]

@@ -20,12 +20,12 @@
 namespace crossclr {
 
 // RM (two-pass soft-max, small temperatures): the stash holds U[p][q] = exp2(x - shift_p) and, behind it, Ut[p][q] = U[q][p];
-// rz = omega / (row sum relative to the ROW's shift), so the weight is U[p][q] rz_p + Ut[p][q] rz_q.
+// rz = omega / (row sum relative to the ROW's shift), so the weight is U[p][q] rz_p + Ut[p][q] rz_q.  RM + RECT: the same for the block
+// against other ranks' columns (crossclr_forward_rect_save_s evaluated Ut with the gathered shifts of those ranks' rows).
 template <int DC, bool SW, bool RM = false, bool RECT = false>
 __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, const float* stash, Geo g, const float* rz, const float* wrz,
                                                              float* gbuf, int accumulate, int tiles_per_slice, const float* k,
                                                              const float* rzc, const float* wrzc, const float* kc) {
-    static_assert(!(RM && RECT), "rectangular blocks: the single-pass soft-max only");
     // (RECT: x = the gathered column operand, rz / wrz / k = this rank's ROW statistics, rzc / wrzc / kc = the gathered column statistics)
     constexpr int QT = 32;
     constexpr int STG = QT * DC * 4;          // bytes per stage: [32][DC] floats, rows contiguous
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256, 2) bwd_saved32_kernel(const float* x, con
     // fragment (p32, t) of the stash: [r4][lane][4]
     const float* frag_row0 = stash + (((size_t)(row0 / 32 + wr) * (size_t)NQ) << 10) + 4 * lane;
     f32x4 e[4], et[4], rq[4], kq[4];
-    const size_t nn = (size_t)(2 * g.bpad) * (size_t)(2 * g.bpad);
+    const size_t nn = (size_t)(2 * g.bpad) * (size_t)NQ * 32;      // floats of U (Ut behind it): rows x columns of the launch
     auto fetch = [&](int t) {
         const ColTile ct = RECT ? col_tile(g, t, QT) : ColTile{};
         const bool same = RECT ? (ct.mod == rmod) : ((t * QT >= g.bpad) == (rmod == 1));

@@ -796,6 +796,15 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
         k_cols_ready()
         nat.check(lib.crossclr_forward_rowmax(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(part),
                                               _ptr(ws.shift), 1, stream))
+    # exact-fp32 sharded run with a backward to follow: the block against the other world - 1 ranks saves U AND Ut (relative to the remote
+    # rows' shifts), so the ranks exchange their row maxima HERE, between the passes (2 bpad floats per rank; every rank takes this
+    # branch or none: the condition reads the plan and the environment only).  The backward then recomputes nothing at any temperature.
+    ws.saved_blocks, ws.recompute_ranges = None, None
+    shift_all = None
+    if (ws.sharded and needs_backward and plan.mode == nat.MODE_FP32 and os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1" and
+            int(lib.crossclr_rect_stash_bytes_s(pp, world - 1)) > 0 and int(lib.crossclr_stash_bytes_s(pp)) > 0):
+        shift_all = torch.empty(world * ws.shift.numel(), **f32)
+        dist.all_gather_into_tensor(shift_all, ws.shift, group=group)
     # second pass over the local block; with a backward to follow (exact-fp32 plans) it also saves the exponentials relative to the
     # row's and to the column's shift, and the backward does not recompute the similarity product
     ws.stash = _alloc_stash(lib.crossclr_stash_bytes_s(pp), dev) if needs_backward else None
@@ -805,8 +814,17 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
         nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xhat), 1, rank, -1, T, w, sw_loc, _ptr(ws.shift), _ptr(part), 0, stream))
     nlaunch = 1
     if ws.sharded:
-        nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(ws.shift), _ptr(part),
-                                         plan.fwd_slots, stream))
+        st_r = None
+        if shift_all is not None and ws.stash is not None:
+            st_r = _alloc_stash(int(lib.crossclr_rect_stash_bytes_s(pp, world - 1)), dev)
+        if st_r is not None:
+            first = (rank + 1) % world
+            nat.check(lib.crossclr_forward_rect_save_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), first, world - 1, T, w, sw_all, _ptr(ws.shift),
+                                                       _ptr(shift_all), _ptr(part), plan.fwd_slots, _ptr(st_r), stream))
+            ws.saved_blocks = [(first, world - 1, st_r)]
+        else:
+            nat.check(lib.crossclr_forward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(ws.shift), _ptr(part),
+                                             plan.fwd_slots, stream))
         nlaunch = 2
     nat.check(lib.crossclr_forward_finish_s(pp, _ptr(part), nlaunch * plan.fwd_slots, _ptr(ws.diag), T, w,
                                             _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(ws.shift), _ptr(ws.logz), _ptr(ws.rz), _ptr(ws.wrz),
@@ -867,9 +885,16 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
                 ws.rz_cols = both[:, 0].contiguous().view(-1)
                 ws.shift_cols = both[:, 1].contiguous().view(-1)
                 ws.wrz_cols = ws.rz_cols * ws.negative_w
-            nat.check(lib.crossclr_backward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature, ws.negative_w,
-                                              _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols),
-                                              _sw(ws.k_rows, ws.k_cols, None), _ptr(ws.shift), _ptr(ws.shift_cols), _ptr(gbuf), 1, stream))
+            if ws.saved_blocks:   # exact-fp32 plans: U and Ut of the block against the other ranks were saved (crossclr_forward_rect_save_s)
+                for first, n, st in ws.saved_blocks:
+                    nat.check(lib.crossclr_backward_rect_saved_s(pp, _ptr(ws.xcols), _ptr(st), first, n, ws.temperature, ws.negative_w,
+                                                                 _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols),
+                                                                 _sw(ws.k_rows, ws.k_cols, None), _ptr(gbuf), 1, stream))
+                ws.saved_blocks = None
+            else:
+                nat.check(lib.crossclr_backward_s(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, ws.temperature, ws.negative_w,
+                                                  _ptr(ws.rz), _ptr(ws.wrz), _ptr(ws.rz_cols), _ptr(ws.wrz_cols),
+                                                  _sw(ws.k_rows, ws.k_cols, None), _ptr(ws.shift), _ptr(ws.shift_cols), _ptr(gbuf), 1, stream))
     elif ws.stash is not None:
         with _Range("crossclr.backward"):
             entry = _saved_backward_entry(ws, plan, dev)

@@ -267,6 +267,19 @@ int crossclr_backward_rect_saved(const crossclr_plan* plan, const void* xhat_all
                                  int first_rank, int nranks, float temperature, float negative_weight,
                                  const float* rz_rows, const float* wrz_rows, const float* rz_all, const float* wrz_all,
                                  const crossclr_sample_weights* sw, float* gbuf, int accumulate, void* stream);
+/* Two-pass regime (round 4, ABI version 5), exact-fp32 plans: the block against other ranks' columns saves U[p][q] = exp2(x - shift_rows[p]) and,
+ * behind it, Ut[p][q] = exp2(x - shift_all[q]) (shift_all = the gathered [world][2][bpad] row maxima: the ranks exchange them between
+ * the two passes; twice crossclr_rect_stash_bytes, up to 32 GiB), and crossclr_backward_rect_saved_s forms
+ * W[p][q] = U rz_p + Ut rz_q from them (bwd_saved32_kernel<..., RM, RECT>): no remote block of an exact-fp32 run is recomputed at any
+ * temperature.  (bf16 plans: 0 -- their remote blocks in the two-pass regime stay on crossclr_backward_s.)                        */
+size_t crossclr_rect_stash_bytes_s(const crossclr_plan* plan, int nranks);
+int crossclr_forward_rect_save_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank, int nranks,
+                                 float temperature, float negative_weight, const crossclr_sample_weights* sw,
+                                 const float* shift_rows, const float* shift_all, float* part, int slot0, void* stash, void* stream);
+int crossclr_backward_rect_saved_s(const crossclr_plan* plan, const void* xhat_all, const void* stash, int first_rank, int nranks,
+                                   float temperature, float negative_weight, const float* rz_rows, const float* wrz_rows,
+                                   const float* rz_all, const float* wrz_all, const crossclr_sample_weights* sw, float* gbuf,
+                                   int accumulate, void* stream);
 /* The other half of a pair block (ABI version 3): the rank that evaluated block (r, s) in the forward holds its exponentials, so it
  * can also form what that block contributes to rank s's gradient -- sum over r's rows p of W[p][q] xhat_r[p] for every row q of s: the
  * TRANSPOSE of the block, read from the same stash (8 b^2 D flop) -- instead of rank s recomputing the block (16 b^2 D).

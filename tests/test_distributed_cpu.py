@@ -49,6 +49,8 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
         if "rectsave" in knobs:  # exact-fp32 sharded run: the block against the other ranks saves its fp32 exponentials (crossclr_forward_rect_save
             real_r = nat.library().crossclr_backward_rect_saved       # on the generic kernels) and the backward is the gradient product alone
             nat.library().crossclr_backward_rect_saved = lambda *a: (rect_calls.append(1), real_r(*a))[1]
+            real_rs = nat.library().crossclr_backward_rect_saved_s    # (two-pass regime: U and Ut of the block against the other ranks)
+            nat.library().crossclr_backward_rect_saved_s = lambda *a: (rect_calls.append(1), real_rs(*a))[1]
         v, t = orc.make_inputs("randn", B, D, 77)
         b = B // world
         vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
@@ -88,6 +90,9 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        # exact-fp32 sharded runs: the remote blocks from saved fp32 exponentials (rectangular stash);
                                                        # 150 rows per rank: several 128-row blocks per modality, ragged
                                                        (2, 24, 20, "fp32+rectsave", 1e-5, 2e-4),
+                                                       # ... and in the two-pass regime (row maxima exchanged between the passes, U and Ut saved)
+                                                       (2, 24, 20, "fp32+rectsave/0.004", 1e-4, 1e-3),
+                                                       (3, 450, 24, "fp32+rectsave/0.003", 1e-4, 1e-3),
                                                        (3, 450, 24, "fp32+rectsave", 1e-5, 2e-4),
                                                        # bf16 with >= 3 ranks: pair scheme + PARTNER GRADIENTS (the evaluator of a pair block
                                                        # also forms its transposed contribution to the partner's gradient and ships it)

@@ -261,6 +261,89 @@ def test_fp32_sharded_blocks_from_saved_exponentials_equal_single_device(world, 
     assert (gvN.double().cpu() - ref["grad_v"]).abs().max().item() <= 2e-4 * scale
 
 
+def _shard_two_pass_via_cabi(v, t, world, tau, w, saved):
+    """The two-pass regime (tau < 0.0078) of an exact-fp32 sharded run through the C-ABI, one GPU playing every rank: row maxima over the
+    local and the remote columns, the ranks' maxima "gathered", sums relative to them; saved: the local block and the block against the other
+    ranks leave U and Ut behind (crossclr_forward_save_s / crossclr_forward_rect_save_s) and the backward recomputes nothing
+    (crossclr_backward_saved_s / crossclr_backward_rect_saved_s); otherwise the recomputing pair (crossclr_forward_s / crossclr_backward_s)."""
+    lib, p = nat.library(), L._ptr
+    B, D = v.shape
+    b, dev, stream = B // world, v.device, L._stream_for(v)
+    plans = [nat.make_plan(b, D, world, r, nat.MODE_FP32) for r in range(world)]
+    pl = plans[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    xall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device=dev)
+    inv = [torch.empty(2 * pl.bpad, **f32) for _ in range(world)]
+    diag = [torch.empty(pl.bpad, **f32) for _ in range(world)]
+    xs = [xall[r * pl.operand_bytes:(r + 1) * pl.operand_bytes] for r in range(world)]
+    for r in range(world):
+        nat.check(lib.crossclr_normalize(ctypes.byref(plans[r]), p(v[r * b:]), p(t[r * b:]), v.stride(0), t.stride(0), nat.IN_F32, p(xs[r]),
+                                         p(inv[r]), p(diag[r]), stream))
+    shift = torch.empty(world, 2 * pl.bpad, **f32)      # the "gathered" row maxima
+    parts = [torch.empty(pl.fwd_ws_floats, **f32) for _ in range(world)]
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        nat.check(lib.crossclr_forward_rowmax(pp, p(xs[r]), p(xs[r]), 1, r, -1, tau, w, None, p(parts[r]), p(shift[r]), 0, stream))
+        nat.check(lib.crossclr_forward_rowmax(pp, p(xs[r]), p(xall), world, 0, r, tau, w, None, p(parts[r]), p(shift[r]), 1, stream))
+    rz, wrz = torch.empty(world, 2 * pl.bpad, **f32), torch.empty(world, 2 * pl.bpad, **f32)
+    total = torch.zeros(1, dtype=torch.float64, device=dev)
+    stashes = []
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        if saved:
+            nb = lib.crossclr_rect_stash_bytes_s(pp, world - 1)
+            assert nb == 2 * lib.crossclr_rect_stash_bytes(pp, world - 1) > 0
+            stashes.append((torch.empty(lib.crossclr_stash_bytes_s(pp), dtype=torch.uint8, device=dev), torch.empty(nb, dtype=torch.uint8, device=dev)))
+            nat.check(lib.crossclr_forward_save_s(pp, p(xs[r]), tau, w, None, p(shift[r]), p(parts[r]), 0, p(stashes[r][0]), stream))
+            nat.check(lib.crossclr_forward_rect_save_s(pp, p(xs[r]), p(xall), (r + 1) % world, world - 1, tau, w, None, p(shift[r]), p(shift),
+                                                       p(parts[r]), pl.fwd_slots, p(stashes[r][1]), stream))
+        else:
+            nat.check(lib.crossclr_forward_s(pp, p(xs[r]), p(xs[r]), 1, r, -1, tau, w, None, p(shift[r]), p(parts[r]), 0, stream))
+            nat.check(lib.crossclr_forward_s(pp, p(xs[r]), p(xall), world, 0, r, tau, w, None, p(shift[r]), p(parts[r]), pl.fwd_slots, stream))
+        logz = torch.empty(2 * pl.bpad, **f32)
+        ls = torch.empty(pl.loss_ws_doubles, dtype=torch.float64, device=dev)
+        nat.check(lib.crossclr_forward_finish_s(pp, p(parts[r]), 2 * pl.fwd_slots, p(diag[r]), tau, w, None, p(shift[r]), p(logz), p(rz[r]),
+                                                p(wrz[r]), p(ls), stream))
+        total += ls[:1]
+    loss = total / (2.0 * B)
+    gv, gt = torch.empty_like(v), torch.empty_like(t)
+    go = torch.ones(1, dtype=torch.float64, device=dev)
+    for r in range(world):
+        pp = ctypes.byref(plans[r])
+        gbuf = torch.empty(pl.gbuf_bytes // 4, **f32)
+        if saved:
+            nat.check(lib.crossclr_backward_saved_s(pp, p(xs[r]), p(stashes[r][0]), tau, w, p(rz[r]), p(wrz[r]), None, p(gbuf), 0, stream))
+            nat.check(lib.crossclr_backward_rect_saved_s(pp, p(xall), p(stashes[r][1]), (r + 1) % world, world - 1, tau, w, p(rz[r]), p(wrz[r]),
+                                                         p(rz), p(wrz), None, p(gbuf), 1, stream))
+        else:
+            nat.check(lib.crossclr_backward_s(pp, p(xs[r]), p(xs[r]), 1, r, -1, tau, w, p(rz[r]), p(wrz[r]), p(rz[r]), p(wrz[r]), None,
+                                              p(shift[r]), p(shift[r]), p(gbuf), 0, stream))
+            nat.check(lib.crossclr_backward_s(pp, p(xs[r]), p(xall), world, 0, r, tau, w, p(rz[r]), p(wrz[r]), p(rz), p(wrz), None,
+                                              p(shift[r]), p(shift), p(gbuf), 1, stream))
+        nat.check(lib.crossclr_backward_finish(pp, p(gbuf), p(v[r * b:]), p(t[r * b:]), v.stride(0), t.stride(0), nat.IN_F32, p(inv[r]), tau,
+                                               p(go), p(gv[r * b:]), p(gt[r * b:]), gv.stride(0), gt.stride(0), stream))
+    torch.cuda.synchronize()
+    return loss.item(), gv, gt
+
+
+@pytest.mark.parametrize("world,B,D,tau", [(2, 512, 128, 0.005), (3, 300, 96, 0.004), (4, 2048, 512, 0.005), (8, 1024, 200, 0.002)])
+def test_fp32_sharded_two_pass_blocks_from_saved_exponentials(world, B, D, tau):
+    """Exact-fp32 sharded runs in the two-pass regime: the block against the other ranks saves U and Ut (the latter relative to the REMOTE rows'
+    maxima) and its backward is bwd_saved32_kernel<..., RM, RECT>; against the recomputing pair of the same run, the single-device module and
+    the streaming float64 oracle."""
+    v, t = orc.make_inputs("randn", B, D, 41)
+    lossS, gvS, gtS = _shard_two_pass_via_cabi(v.cuda(), t.cuda(), world, tau, 0.8, saved=True)
+    lossR, gvR, gtR = _shard_two_pass_via_cabi(v.cuda(), t.cuda(), world, tau, 0.8, saved=False)
+    loss1, gv1, gt1 = run_module(v, t, dict(temperature=tau, negative_weight=0.8), "fp32")
+    scale = gv1.abs().max().item()
+    assert abs(lossS - lossR) <= 1e-6 * max(1.0, abs(lossR)) and abs(lossS - loss1.item()) <= 1e-6 * max(1.0, abs(lossS))
+    assert (gvS - gvR).abs().max().item() <= 1e-5 * scale and (gtS - gtR).abs().max().item() <= 1e-5 * scale
+    assert (gvS - gv1).abs().max().item() <= 1e-5 * scale and (gtS - gt1).abs().max().item() <= 1e-5 * scale
+    ref = orc.streaming_loss_and_grads(v, t, tau, 0.8)
+    assert abs(lossS - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"])))
+    assert (gvS.double().cpu() - ref["grad_v"]).abs().max().item() <= 1e-3 * scale
+
+
 @pytest.mark.parametrize("world,B,D,mode", [(2, 512, 128, nat.MODE_FP32), (4, 1024, 512, nat.MODE_BF16),
                                             (8, 2048, 512, nat.MODE_BF16), (3, 300, 96, nat.MODE_FP32)])
 def test_sharded_kernel_path_equals_single_device(world, B, D, mode):
