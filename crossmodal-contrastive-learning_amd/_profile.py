@@ -100,15 +100,15 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
 
 
 def remote_block_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float, iters: int = 5, warmup: int = 2,
-                       recompute: bool = True) -> Dict[str, float]:
-    """Exact-fp32 sharded run, rank 0 of 2 driven through the C-ABI on one GPU (`video` / `text` = the rows of BOTH ranks): median
+                       recompute: bool = True, mode: int = nat.MODE_FP32) -> Dict[str, float]:
+    """Sharded run of an exact-fp32 plan (or, mode = MODE_BF16, of a wide bf16 plan), rank 0 of 2 driven through the C-ABI on one GPU (`video` / `text` = the rows of BOTH ranks): median
     milliseconds per launch of the block against the other rank -- the forward that saves its exponentials and the saved backward
     (single-pass regime: crossclr_forward_rect_save / crossclr_backward_rect_saved; two-pass regime: the `_s` pair, U and Ut), and with
     `recompute` the recomputing pair beside them (crossclr_forward[_s] / crossclr_backward[_s] over the same columns)."""
     lib, p = nat.library(), L._ptr
     B, D = video.shape
     world, b, dev, stream = 2, B // 2, video.device, L._stream_for(video)
-    plans = [nat.make_plan(b, D, world, r, nat.MODE_FP32) for r in range(world)]
+    plans = [nat.make_plan(b, D, world, r, mode) for r in range(world)]
     pl, pp = plans[0], ctypes.byref(plans[0])
     f32 = dict(dtype=torch.float32, device=dev)
     xall = torch.empty(world * pl.operand_bytes, dtype=torch.uint8, device=dev)

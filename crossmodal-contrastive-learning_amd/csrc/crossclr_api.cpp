@@ -560,7 +560,12 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
     dim3 grid(2 * plan->bpad / 128, nsplit);
     if (stash && plan->mode == CROSSCLR_MODE_BF16) {   // two-pass regime of a bf16 plan: the full second pass leaves bf16 records (rectangular layout)
         dim3 block(256);
-        if (mode != 2) return fail(CROSSCLR_E_ARG, "bf16 plans save through the generic forward in the two-pass regime only");
+        if (mode == 0) {   // wide plans, this rank's rows against other ranks' columns: every tile's record, rectangular layout
+            if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true, 0, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+            else LAUNCH((fwd_sums_kernel<bf16_t, false, 0, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+            return launch_status("fwd_sums_kernel (rectangular, save, bf16 records)");
+        }
+        if (mode != 2) return fail(CROSSCLR_E_ARG, "bf16 plans save through the generic forward in modes 0 (rectangular) and 2 (two-pass)");
         if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
         else LAUNCH((fwd_sums_kernel<bf16_t, false, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
         return launch_status("fwd_sums_kernel (save, bf16 records)");
@@ -1089,6 +1094,8 @@ extern "C" size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nrank
         const size_t sb = (size_t)(2 * plan->bpad / 32) * (size_t)(2 * plan->bpad / 32) * (size_t)nranks * 4096;
         return sb <= ((size_t)16 << 30) && plan->operand_bytes * (size_t)plan->world < ((size_t)1 << 32) ? sb : 0;
     }
+    if (!plan->fast_path && plan->mode == CROSSCLR_MODE_BF16 && plan->Dpad > 1024)   // wide bf16 plans: bf16 records of the generic forward
+        return plan->operand_bytes * (size_t)plan->world < ((size_t)1 << 32) ? wide_stash_bytes_rect(plan->bpad, nranks) : 0;
     if (!plan->fast_path) return 0;
     return fast_stash_bytes_rect(plan->bpad, plan->Dpad, nranks);
 #endif
@@ -1102,9 +1109,10 @@ extern "C" int crossclr_forward_rect_save(const crossclr_plan* plan, const void*
 #ifdef CROSSCLR_NO_FAST
     return fail(CROSSCLR_E_ARG, "crossclr_forward_rect_save needs the register-resident path");
 #else
-    if (plan->stash_bytes && !plan->fast_path && plan->mode == CROSSCLR_MODE_FP32) {
-        // exact-fp32 plans: the generic forward over the rank range, leaving its fp32 fragments behind ([row group][fragments of the range])
-        if (with_colsums) return fail(CROSSCLR_E_ARG, "exact-fp32 plans have no pair scheme (with_colsums must be 0)");
+    if (plan->stash_bytes && !plan->fast_path && (plan->mode == CROSSCLR_MODE_FP32 || plan->Dpad > 1024)) {
+        // exact-fp32 plans: the generic forward over the rank range, leaving its fp32 fragments behind ([row group][fragments of the range]);
+        // wide bf16 plans (Dpad > 1024): the same launch leaves bf16 records ([row group][tile of the range]: fast_bwd_dsl_kernel<..., MODE 1>)
+        if (with_colsums) return fail(CROSSCLR_E_ARG, "plans on the generic forward have no pair scheme (with_colsums must be 0)");
         if (!crossclr_rect_stash_bytes(plan, nranks)) return fail(CROSSCLR_E_ARG, "rectangular stash too large for this plan");
         if (plan->fwd_slots <= 0 || slot0 < 0 || slot0 % plan->fwd_slots != 0 || slot0 / plan->fwd_slots >= kLaunchGroups)
             return fail(CROSSCLR_E_ARG, "slot0 must be L * plan->fwd_slots, L = 0..%d", kLaunchGroups - 1);
@@ -1173,7 +1181,8 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
 #undef CROSSCLR_LS32X
         return launch_status("bwd_saved32_kernel (rect)");
     }
-    if (!plan->stash_bytes || !plan->fast_path) return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
+    if (!plan->stash_bytes || !(plan->fast_path || (plan->mode == CROSSCLR_MODE_BF16 && plan->Dpad > 1024)))
+        return fail(CROSSCLR_E_ARG, "this plan has no save-for-backward path for remote blocks");
     const float *krows, *kcols;
     if (int rk = unpack_k(sw, &krows, &kcols)) return rk;
     Geo g;

@@ -922,6 +922,10 @@ static inline size_t wide_stash_bytes(int bpad) { return stash_tiles_total(4, 2 
 static inline size_t fast_stash_bytes_rect(int bpad, int Dpad, int nranks) {
     return Dpad <= 1024 ? (size_t)(2 * bpad / 32) * (size_t)(2 * bpad / 32) * (size_t)nranks * 2048 : 0;
 }
+// wide bf16 plans (Dpad > 1024): the same 2-KiB records, written by the generic forward over the rank range
+static inline size_t wide_stash_bytes_rect(int bpad, int nranks) {
+    return (size_t)(2 * bpad / 32) * (size_t)(2 * bpad / 32) * (size_t)nranks * 2048;
+}
 static inline int fast_forward_save(const crossclr_plan* p, const Geo& g, const void* x, float* part, float* colpart,
                                     int* header, const float* ks, void* stash, void* stream) {
     const FwdWork wk = fast_forward_work(p, 1, -1, true);
@@ -1089,13 +1093,15 @@ CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
     float* gbuf = a.gbuf;
     const int accumulate = a.accumulate, tps = a.tps;
     (void)block; (void)stream; (void)c; (void)st; (void)rz; (void)wrz; (void)rz_cols; (void)wrz_cols; (void)kc; (void)gbuf; (void)accumulate; (void)tps;
-    if (a.mode != 0) return CROSSCLR_E_ARG;
+    const int mode = a.mode;
+    if (mode != 0 && mode != 1) return CROSSCLR_E_ARG;       // (1: a rectangular block against other ranks' columns, crossclr_backward_rect_saved)
 #ifdef CROSSCLR_DSL_MINIMAL
     return CROSSCLR_E_ARG;
 #else
+#define CROSSCLR_LBW2(DK, XP, SW) do { if (mode == 0) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 0, XP, 4>), gridw, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
+                                       else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, SW, 1, XP, 4>), gridw, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
 #define CROSSCLR_LBW(DK, XP) do { dim3 gridw(2 * p->bpad / 128, p->bwd_slices, XP);                                                            \
-                                  if (ks) CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, true, 0, XP, 4>), gridw, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); \
-                                  else CROSSCLR_FAST_LAUNCH((fast_bwd_dsl_kernel<DK, false, 0, XP, 4>), gridw, block, stream, c, st, g, rz, wrz, rz_cols, wrz_cols, gbuf, accumulate, tps, ks, kc); } while (0)
+                                  if (ks) CROSSCLR_LBW2(DK, XP, true); else CROSSCLR_LBW2(DK, XP, false); } while (0)
     switch (p->Dpad) {
         case 1152: CROSSCLR_LBW(24, 3); break;
         case 1536: CROSSCLR_LBW(32, 3); break;
@@ -1106,6 +1112,7 @@ CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_LBW
+#undef CROSSCLR_LBW2
     return CROSSCLR_OK;
 #endif
 }

@@ -294,8 +294,8 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                                                        float* part, const float* kcols, const float* shift, float* stash, int* header,
                                                        float* colpart) {
     static_assert(!ST || MODE == 0 || MODE == 2, "exponentials are saved by the passes that form sums");
-    static_assert(!(ST && sizeof(T) == 2) || (MODE == 0 && SYM) || (MODE == 2 && !SYM),
-                  "bf16 records: the symmetric single-pass forward (upper triangle) or the full second pass of the two-pass soft-max");
+    static_assert(!(ST && sizeof(T) == 2) || MODE == 0 || (MODE == 2 && !SYM),
+                  "bf16 records: the single-pass forward (symmetric: upper triangle; rectangular: every tile) or the full second pass of the two-pass soft-max");
     static_assert(!SYM || MODE <= 3, "symmetric evaluation: the soft-max passes; MODE 3: one pass for both directions");
     // MODE 3 + SYM (score statistics in ONE pass): only the rows of modality 0 are walked (grid.x = bpad / 128), against the column
     // tiles of modality 1; every tile also yields, per column q, the hinge sum and the active count over the block's rows against
@@ -474,6 +474,16 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
 #pragma unroll
                             for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(ev[j]);
                             unsigned char* rec = reinterpret_cast<unsigned char*>(stash) + ((size_t)p32 * (size_t)(2 * g.bpad / 32) + (size_t)q32) * 2048 +
+                                                 1024 * (r4 >> 1) + 16 * lane + 8 * (r4 & 1);
+                            *reinterpret_cast<B4*>(rec) = pk;
+                        } else if constexpr (!SYM) {
+                            // wide bf16 plans, this rank's rows against OTHER ranks' columns (crossclr_forward_rect_save): the rectangular layout
+                            // [row group][tile of the launch's rank range, in launch order] that fast_bwd_dsl_kernel<..., MODE 1> reads
+                            struct B4 { bf16_t e[4]; } pk;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(ev[j]);
+                            const size_t q32l = (size_t)4 * t + 2 * wc + qi, NQl = (size_t)g.col_ranks * (size_t)(2 * g.bpad / 32);
+                            unsigned char* rec = reinterpret_cast<unsigned char*>(stash) + ((size_t)p32 * NQl + q32l) * 2048 +
                                                  1024 * (r4 >> 1) + 16 * lane + 8 * (r4 & 1);
                             *reinterpret_cast<B4*>(rec) = pk;
                         } else if (q32 >= 4 * (p32 / 4)) {

@@ -736,11 +736,13 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     elif sharded:
         gather.wait()
         k_cols_ready()
+        # wide bf16 plans (D > 1024) with a backward to follow: the block against the other world - 1 ranks saves its bf16 records too (the
+        # generic forward in the rectangular layout the D-slice backward reads: 0.5 GiB per rank-block at b = 8192);
         # exact-fp32 plans with a backward to follow: the block against the other world - 1 ranks saves its fp32 exponentials too
         # (crossclr_forward_rect_save / crossclr_backward_rect_saved on the generic kernels: 1 GiB per rank-block at b = 8192), so that
         # the backward of the remote blocks is the gradient product alone (2.3 instead of 6.8 ms per 8192^2 block)
         rect_bytes = 0
-        if (mode == nat.MODE_FP32 and world >= 2 and ws.stash is not None and stash_everywhere and
+        if ((mode == nat.MODE_FP32 or plan.Dpad > 1024) and world >= 2 and ws.stash is not None and stash_everywhere and
                 os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1"):
             rect_bytes = int(lib.crossclr_rect_stash_bytes(pp, world - 1))
         st_r = _alloc_stash(rect_bytes, dev) if rect_bytes > 0 else None
@@ -851,6 +853,8 @@ def _remote_xfp(ws, plan, lib, pp, dev) -> bool:
     local fragment-major copy (ws.xf: the step took the fragment-major pair), the pair kernel verified on this device for the local
     block, and a gathered operand / rectangular stashes below 4 GiB (32-bit offsets).  CROSSCLR_REMOTE_XFP=0 keeps the LDS-staged kernels."""
     if ws.xf is None or os.environ.get("CROSSCLR_REMOTE_XFP", "1") == "0":
+        return False
+    if plan.Dpad > 1024:      # wide plans: the rectangular launches exist on the LDS-staged kernel only
         return False
     if ws.world * plan.operand_bytes >= (1 << 32):
         return False

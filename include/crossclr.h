@@ -257,7 +257,10 @@ int crossclr_backward_saved_s(const crossclr_plan* plan, const void* xhat, const
  * (crossclr_backward_w over a wrapping rank range).
  * Exact-fp32 plans (round 4): the same three entry points with with_colsums = 0 -- the generic forward over the rank range leaves its fp32
  * fragments (4 KiB per 32 x 32 fragment: 1 GiB per rank at b = 8192, up to 16 GiB; crossclr_rect_stash_bytes says 0 beyond) and
- * crossclr_backward_rect_saved is the gradient product alone (bwd_saved32_kernel<..., RECT>).                            */
+ * crossclr_backward_rect_saved is the gradient product alone (bwd_saved32_kernel<..., RECT>).
+ * Wide bf16 plans (1024 < D <= 4096, round 4): the same three entry points with with_colsums = 0 as well -- the generic forward over the rank
+ * range leaves bf16 records in the rectangular layout (2 KiB per 32 x 32 tile: 0.5 GiB per rank at b = 8192) and the backward is the
+ * D-slice kernel in column parts (fast_bwd_dsl_kernel<..., MODE 1, XP, 4>): 13.9 ms of recompute per 8192 x 8192 block at D = 1536 gone.   */
 size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nranks);
 int crossclr_forward_rect_save(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all,
                                int first_rank, int nranks, int with_colsums, float temperature, float negative_weight,

@@ -109,6 +109,10 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        # forward with bf16 records + D-slice backward in column parts), the remote blocks recompute
                                                        # into the same gradient slices
                                                        (2, 16, 1030, "bf16", 5e-3, 2e-2),
+                                                       # ... and the remote blocks from saved bf16 records as well (rectangular layout written by the
+                                                       # generic forward, D-slice backward in column parts, MODE 1)
+                                                       (2, 16, 1030, "bf16+rectsave", 5e-3, 2e-2),
+                                                       (3, 420, 1040, "bf16+rectsave", 5e-3, 2e-2),
                                                        # CROSSCLR_EXCHANGE=p2p: the operands travel point to point in two batches, the slices
                                                        # the forward needs first; p2p_each ("each"): one pair of operations per peer
                                                        # distance, one forward launch per pair partner as its slice lands

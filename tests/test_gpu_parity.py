@@ -261,6 +261,24 @@ def test_fp32_sharded_blocks_from_saved_exponentials_equal_single_device(world, 
     assert (gvN.double().cpu() - ref["grad_v"]).abs().max().item() <= 2e-4 * scale
 
 
+@pytest.mark.parametrize("world,B,D", [(2, 512, 1100), (3, 768, 1536), (4, 2048, 2048), (8, 1024, 1300)])
+def test_wide_bf16_sharded_blocks_from_saved_exponentials(world, B, D):
+    """Wide bf16 plans (D > 1024) in a sharded run: the block against the other ranks saves bf16 records too (generic forward, rectangular
+    layout) and its backward is the D-slice kernel in column parts (MODE 1); one GPU plays every rank through the C-ABI; against the
+    recomputing pair of the same run and the streaming float64 oracle."""
+    v, t = orc.make_inputs("randn", B, D, 43)
+    lossS, gvS, gtS = _shard_via_cabi(v.cuda(), t.cuda(), world, nat.MODE_BF16, saved=True)
+    lossR, gvR, gtR = _shard_via_cabi(v.cuda(), t.cuda(), world, nat.MODE_BF16, saved=False)
+    ref = orc.streaming_loss_and_grads(v, t, 0.03, 0.8)
+    scale = ref["grad_v"].abs().max().item()
+    assert abs(lossS - lossR) <= 1e-5 * max(1.0, abs(lossR))            # the same exponentials, summed in another order
+    assert abs(lossS - float(ref["loss"])) <= 1e-3
+    # saved weights are rounded to bf16 before the product, recomputed ones are not: both within the bf16 bar of the oracle
+    assert (gvS.double().cpu() - ref["grad_v"]).abs().max().item() <= 1e-2 * scale
+    assert (gtS.double().cpu() - ref["grad_t"]).abs().max().item() <= 1e-2 * scale
+    assert (gvS - gvR).abs().max().item() <= 1e-2 * scale
+
+
 def _shard_two_pass_via_cabi(v, t, world, tau, w, saved):
     """The two-pass regime (tau < 0.0078) of an exact-fp32 sharded run through the C-ABI, one GPU playing every rank: row maxima over the
     local and the remote columns, the ranks' maxima "gathered", sums relative to them; saved: the local block and the block against the other
