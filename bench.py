@@ -250,6 +250,19 @@ def secondary_lines(dev):
         "dominant_kernel_frac_of_peak": round(tf / PEAK_F32_TFLOPS, 4), "peak_tflops": PEAK_F32_TFLOPS,
         "workload": "rank 0 of 2 through the C-ABI on one GPU: b=8192 rows/rank, D=512, fp32, tau=0.005 (two-pass soft-max), the 16384 x 16384 block "
                     "against the other rank: second forward pass that saves + saved backward; median of 5 launches"}
+    # wide bf16 plan (D = 1536) in a sharded run, rank 0 of 2 through the C-ABI: the block against the other rank from saved bf16 records
+    v, t = make_inputs(2 * 8192, 1536, 1234)
+    from crossclr_amd import _native as nat
+    rb = _profile.remote_block_times(v.to(dev), t.to(dev), TAU, NEG_W, iters=5, warmup=2, recompute=True, mode=nat.MODE_BF16)
+    tf = 8.0 * 8192 * 8192 * 1536 / (rb["backward_rect_saved"] * 1e-3) / 1e12
+    out["d1536_bf16_sharded_block"] = {
+        "forward_rect_save_ms": round(rb["forward_rect_save"], 4), "backward_rect_saved_ms": round(rb["backward_rect_saved"], 4),
+        "forward_recompute_path_ms": round(rb["forward_recompute_path"], 4), "backward_recompute_ms": round(rb["backward_recompute"], 4),
+        "stash_gib": round(rb["stash_bytes"] / 2.0 ** 30, 3), "dominant_kernel": "backward of the remote block (saved bf16 records, D-slice kernel in 3 column parts)",
+        "dominant_kernel_ms": round(rb["backward_rect_saved"], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
+        "dominant_kernel_frac_of_peak": round(tf / PEAK_BF16_TFLOPS, 4), "peak_tflops": PEAK_BF16_TFLOPS,
+        "workload": "rank 0 of 2 through the C-ABI on one GPU: b=8192 rows/rank, D=1536, bf16, tau=0.03, the 16384 x 16384 block against the other "
+                    "rank: generic forward that saves + saved backward; median of 5 launches"}
     return out
 
 

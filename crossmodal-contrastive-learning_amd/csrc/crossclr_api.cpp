@@ -566,8 +566,8 @@ static int forward_generic(const crossclr_plan* plan, const Geo& g, const void* 
             return launch_status("fwd_sums_kernel (rectangular, save, bf16 records)");
         }
         if (mode != 2) return fail(CROSSCLR_E_ARG, "bf16 plans save through the generic forward in modes 0 (rectangular) and 2 (two-pass)");
-        if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
-        else LAUNCH((fwd_sums_kernel<bf16_t, false, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, (float*)nullptr);
+        if (kcols) LAUNCH((fwd_sums_kernel<bf16_t, true, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, const_cast<float*>(shift_cols));
+        else LAUNCH((fwd_sums_kernel<bf16_t, false, 2, true>), grid, block, stream, (const bf16_t*)rows, (const bf16_t*)cols, g, tps, out, kcols, shift, stash, (int*)nullptr, const_cast<float*>(shift_cols));
         return launch_status("fwd_sums_kernel (save, bf16 records)");
     }
     if (stash) {   // exact-fp32 forward that also saves its exponentials (local block; common shift, or per-row shifts: mode 2)
@@ -1194,9 +1194,15 @@ extern "C" int crossclr_backward_rect_saved(const crossclr_plan* plan, const voi
 }
 
 // ---- the two-pass regime's rectangular blocks (exact-fp32 plans): U and Ut of this rank's rows against other ranks' columns ----------
+// bf16 register-resident plans: two arrays of bf16 records (U, Ut) in the rectangular layout + (world + 1) x 2 bpad floats of zeros (the statistics
+// of the side a launch must not weigh: W = U rz_p + Ut rz_q is formed as two rectangular launches of the saved backward)
+static size_t rect_zero_floats(const crossclr_plan* plan) { return (size_t)(plan->world + 1) * 2 * plan->bpad; }
 extern "C" size_t crossclr_rect_stash_bytes_s(const crossclr_plan* plan, int nranks) {
-    if (!plan || plan->fast_path || plan->mode != CROSSCLR_MODE_FP32) return 0;
+    if (!plan) return 0;
     const size_t one = crossclr_rect_stash_bytes(plan, nranks);
+    if (plan->mode == CROSSCLR_MODE_BF16)
+        return (one && plan->fast_path && rect_bytes_s(plan)) ? 2 * one + rect_zero_floats(plan) * 4 : 0;
+    if (plan->fast_path || plan->mode != CROSSCLR_MODE_FP32) return 0;
     return one && 2 * one <= ((size_t)32 << 30) ? 2 * one : 0;
 }
 
@@ -1217,6 +1223,10 @@ extern "C" int crossclr_forward_rect_save_s(const crossclr_plan* plan, const voi
     int* header = reinterpret_cast<int*>(part + ws_flag_off(plan)) + 4 * (slot0 / plan->fwd_slots);
     rc = device_zero_header(header, stream);
     if (rc) return rc;
+    if (plan->mode == CROSSCLR_MODE_BF16) {
+        rc = device_zero(static_cast<unsigned char*>(stash) + 2 * crossclr_rect_stash_bytes(plan, nranks), rect_zero_floats(plan) * 4, stream);
+        if (rc) return rc;
+    }
     return forward_generic(plan, g, xhat_rows, xhat_all, part + (size_t)slot0 * 2 * plan->bpad, kcols, shift_rows, 2, stream,
                            static_cast<float*>(stash), shift_all);
 }
@@ -1233,6 +1243,20 @@ extern "C" int crossclr_backward_rect_saved_s(const crossclr_plan* plan, const v
     Geo g;
     int rc = rect_geo(plan, first_rank, nranks, temperature, negative_weight, &g, true);
     if (rc) return rc;
+#ifndef CROSSCLR_NO_FAST
+    if (plan->mode == CROSSCLR_MODE_BF16) {
+        // W[p][q] = U[p][q] rz_p + Ut[p][q] rz_q: the launch over U weighs with the ROW statistics only (column side: zeros), the launch over Ut
+        // with the COLUMN statistics only (row side: zeros) and accumulates -- two rectangular launches of the saved backward, no recompute
+        const size_t one = crossclr_rect_stash_bytes(plan, nranks);
+        const unsigned char* U = static_cast<const unsigned char*>(stash);
+        const float* zeros = reinterpret_cast<const float*>(U + 2 * one);       // [world][2 bpad] for the column side, [2 bpad] of it for the rows
+        rc = fast_backward_saved(plan, g, xhat_all, U, rz_rows, wrz_rows, zeros, zeros, gbuf, accumulate, krows, kcols, 1, stream);
+        if (rc) return fail(rc, "fast_backward_saved (two-pass, rows' side): unsupported Dpad %d", plan->Dpad);
+        rc = fast_backward_saved(plan, g, xhat_all, U + one, zeros, zeros, rz_all, wrz_all, gbuf, 1, krows, kcols, 1, stream);
+        return rc ? fail(rc, "fast_backward_saved (two-pass, columns' side): unsupported Dpad %d", plan->Dpad)
+                  : launch_status("fast_bwd_dsl_kernel (rect, two-pass pair)");
+    }
+#endif
     const int NQ = nranks * (2 * plan->bpad / 32);
     const int tps = (NQ + plan->bwd_slices - 1) / plan->bwd_slices;
     const unsigned rb = 2 * plan->bpad / 64, nz = (unsigned)plan->bwd_slices;

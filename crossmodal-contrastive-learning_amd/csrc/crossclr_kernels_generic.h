@@ -426,7 +426,9 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                     if (SW && same_mod) kq = *reinterpret_cast<const f32x4*>(kcols + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
                     f32x4 ev = {0.f, 0.f, 0.f, 0.f}, etv = {0.f, 0.f, 0.f, 0.f}, shq = {0.f, 0.f, 0.f, 0.f};
                     constexpr bool kNeedColShift = (MODE == 2 && (SYM || (ST && sizeof(T) == 4))) || (MODE == 3 && SYM);   // (bf16 records: U only)
-                    if (kNeedColShift)
+                    // bf16 records of a rectangular second pass (other ranks' columns: shift_q is its own array): Ut as well, at run time
+                    const bool ut_records = ST && sizeof(T) == 2 && MODE == 2 && !SYM && colpart != nullptr;   // (not `shift_q != shift`: rank 0's rows may BE the head of the gathered array)
+                    if (kNeedColShift || ut_records)
                         shq = *reinterpret_cast<const f32x4*>(shift_q + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                             if (masked) e = 0.f;
                             ev[j] = e;
                             float et = e;            // relative to the COLUMN's shift (single pass: one shift, symmetric matrix)
-                            if (MODE == 2 && kNeedColShift) { et = fast_exp2(x2 - shq[j]); if (masked) et = 0.f; }
+                            if (MODE == 2 && (kNeedColShift || ut_records)) { et = fast_exp2(x2 - shq[j]); if (masked) et = 0.f; }
                             etv[j] = et;
                             if (SYM) es[qi][r] += pad_row ? 0.f : ((SW && same_mod) ? et * kp[pi] : et);
                             if (SW) e *= kq[j];
@@ -473,9 +475,16 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                             struct B4 { bf16_t e[4]; } pk;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(ev[j]);
-                            unsigned char* rec = reinterpret_cast<unsigned char*>(stash) + ((size_t)p32 * (size_t)(2 * g.bpad / 32) + (size_t)q32) * 2048 +
+                            // (tile index in launch order: the local block's own position; a rectangular launch over other ranks: its range)
+                            const size_t q32l = (size_t)4 * t + 2 * wc + qi, NQl = (size_t)g.col_ranks * (size_t)(2 * g.bpad / 32);
+                            unsigned char* rec = reinterpret_cast<unsigned char*>(stash) + ((size_t)p32 * NQl + q32l) * 2048 +
                                                  1024 * (r4 >> 1) + 16 * lane + 8 * (r4 & 1);
                             *reinterpret_cast<B4*>(rec) = pk;
+                            if (ut_records) {   // Ut[p][q] = exp2(x - shift_all[q]) behind U: crossclr_backward_rect_saved_s weighs it with the columns' statistics
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) pk.e[j] = f32_to_bf16_bits(etv[j]);
+                                *reinterpret_cast<B4*>(rec + (size_t)(2 * g.bpad / 32) * NQl * 2048) = pk;
+                            }
                         } else if constexpr (!SYM) {
                             // wide bf16 plans, this rank's rows against OTHER ranks' columns (crossclr_forward_rect_save): the rectangular layout
                             // [row group][tile of the launch's rank range, in launch order] that fast_bwd_dsl_kernel<..., MODE 1> reads

@@ -798,12 +798,12 @@ def _forward_row_shift(lib, ws, part, gather, group, stream, b, world, rank, dev
         k_cols_ready()
         nat.check(lib.crossclr_forward_rowmax(pp, _ptr(ws.xhat), _ptr(ws.xcols), world, 0, rank, T, w, sw_all, _ptr(part),
                                               _ptr(ws.shift), 1, stream))
-    # exact-fp32 sharded run with a backward to follow: the block against the other world - 1 ranks saves U AND Ut (relative to the remote
-    # rows' shifts), so the ranks exchange their row maxima HERE, between the passes (2 bpad floats per rank; every rank takes this
+    # sharded run with a backward to follow (exact-fp32 plans: fp32 fragments; bf16 register-resident plans: bf16 records): the block against
+    # the other world - 1 ranks saves U AND Ut (relative to the remote rows' shifts), so the ranks exchange their row maxima HERE, between the passes (2 bpad floats per rank; every rank takes this
     # branch or none: the condition reads the plan and the environment only).  The backward then recomputes nothing at any temperature.
     ws.saved_blocks, ws.recompute_ranges = None, None
     shift_all = None
-    if (ws.sharded and needs_backward and plan.mode == nat.MODE_FP32 and os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1" and
+    if (ws.sharded and needs_backward and os.environ.get("CROSSCLR_DISABLE_REMOTE_SAVE") != "1" and
             int(lib.crossclr_rect_stash_bytes_s(pp, world - 1)) > 0 and int(lib.crossclr_stash_bytes_s(pp)) > 0):
         shift_all = torch.empty(world * ws.shift.numel(), **f32)
         dist.all_gather_into_tensor(shift_all, ws.shift, group=group)

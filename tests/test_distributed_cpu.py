@@ -93,6 +93,9 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        # ... and in the two-pass regime (row maxima exchanged between the passes, U and Ut saved)
                                                        (2, 24, 20, "fp32+rectsave/0.004", 1e-4, 1e-3),
                                                        (3, 450, 24, "fp32+rectsave/0.003", 1e-4, 1e-3),
+                                                       # bf16 register-resident plans there: bf16 records of U and Ut, two rectangular launches
+                                                       (2, 40, 48, "bf16+rectsave/0.005", 2e-2, 5e-2),
+                                                       (3, 420, 40, "bf16+rectsave/0.005", 2e-2, 5e-2),
                                                        (3, 450, 24, "fp32+rectsave", 1e-5, 2e-4),
                                                        # bf16 with >= 3 ranks: pair scheme + PARTNER GRADIENTS (the evaluator of a pair block
                                                        # also forms its transposed contribution to the partner's gradient and ships it)
