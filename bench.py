@@ -221,7 +221,7 @@ def secondary_lines(dev):
             return loss
         ms, loss = timed(step)
         sw = crossclr_amd.influential_sample_weights(extra[0], extra[1], 0.9, 0.0035) if influential else (None, None)
-        st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, mode, iters=3, warmup=1, negative_scale=sw[0], loss_weight=sw[1])
+        st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, mode, iters=7, warmup=2, negative_scale=sw[0], loss_weight=sw[1])   # (median of 7: 3 gave outliers)
         peak = PEAK_BF16_TFLOPS if mode == "bf16" else PEAK_F32_TFLOPS
         dom = "step_forward" if fwd_only else "step_backward"
         flops = (6.0 if fwd_only else 8.0) * rows * rows * dim
