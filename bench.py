@@ -223,10 +223,14 @@ def secondary_lines(dev):
         sw = crossclr_amd.influential_sample_weights(extra[0], extra[1], 0.9, 0.0035) if influential else (None, None)
         st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, mode, iters=7, warmup=2, negative_scale=sw[0], loss_weight=sw[1])   # (median of 7: 3 gave outliers)
         peak = PEAK_BF16_TFLOPS if mode == "bf16" else PEAK_F32_TFLOPS
-        dom = "step_forward" if fwd_only else "step_backward"
+        dom = "forward" if fwd_only else "step_backward"      # (under no_grad nothing is saved: crossclr_forward, not crossclr_forward_save)
         flops = (6.0 if fwd_only else 8.0) * rows * rows * dim
         tf = flops / (st[dom] * 1e-3) / 1e12
+        ex_frac = None
+        if fwd_only:   # (symmetric forward: 4.06 b^2 D executed for 6 b^2 D algorithmic -- the algorithmic fraction can pass 1)
+            ex_frac = round(4.0 * rows * rows * dim * (1.0 + (256.0 if st["fast_path"] else 128.0) / (2.0 * rows)) / (st[dom] * 1e-3) / 1e12 / peak, 4)
         out[name] = {"ms_per_step_event_median": round(ms, 4), "pairs_per_s": rows * rows / (ms * 1e-3), "loss": float(loss.detach()),
+                     "dominant_kernel_frac_executed": ex_frac,
                      "loss_delta_vs_reference": abs(float(loss) - golden) if golden is not None else None,
                      "dominant_kernel": ("forward" if fwd_only else "backward") + (" (saved exponentials)" if st.get("saved_path") and not fwd_only else ""),
                      "dominant_kernel_ms": round(st[dom], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
@@ -472,7 +476,7 @@ def main():
     # ---- per-kernel HIP-event timing of the single-GPU stages (roofline of the dominant kernel) ----
     sw = crossclr_amd.influential_sample_weights(xv, xt, 0.9, 0.0035) if args.influential else (None, None)
     st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, args.mode, iters=20, warmup=3,
-                              negative_scale=sw[0], loss_weight=sw[1])
+                              negative_scale=sw[0], loss_weight=sw[1], in_step=50, forward_only=args.fwd_only)
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
     # algorithmic flops per launch: forward 6*b*b*D, backward 8*b*b*D for the local block
     # forward_save / backward_saved are what a training step launches when the plan has the save-for-backward pair
@@ -490,6 +494,11 @@ def main():
         if k in alg:
             tf = alg[k] / (st[k] * 1e-3) / 1e12
             kernels[k].update(algorithmic_tflops=round(tf, 2), frac=round(tf / peak, 4))
+            if k in ("forward", "forward_save") and world == 1:
+                # the forward evaluates the upper triangle of the stacked 2b x 2b matrix only (row blocks of 256 / 128 rows on the diagonal):
+                # 4 b^2 D (1 + RB / 2b) executed for the 6 b^2 D the reference's three GEMMs count -- `frac` is ALGORITHMIC and can pass 1
+                ex = 4.0 * b * b * d * (1.0 + (256.0 if st["fast_path"] else 128.0) / (2.0 * b)) / (st[k] * 1e-3) / 1e12
+                kernels[k].update(executed_tflops=round(ex, 2), frac_executed=round(ex / peak, 4))
     saved = bool(st.get("saved_path"))
     if args.fwd_only:
         dom, dom_kernel = "forward", ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel<float, false, 0, false>")
@@ -497,7 +506,18 @@ def main():
         dom = "backward_saved" if saved else "backward"
         dom_kernel = (("fast_bwd_dsl_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
                       else ("fast_bwd" if st["fast_path"] else "bwd_kernel"))
-    dom_tf = alg[dom] / (st[dom] * 1e-3) / 1e12
+    # the dominant kernel's duration IN ITS PLACE in the step (median over 50 passes of the step's kernel sequence, events between the
+    # launches); `kernels[dom].ms` keeps the back-to-back figure (the kernel alone at the package power limit: a few per cent slower)
+    in_step_key = "in_step_forward" if args.fwd_only else "in_step_backward"
+    dom_ms = st.get(in_step_key, st[dom])
+    dom_tf = alg[dom] / (dom_ms * 1e-3) / 1e12
+    for k_in, k_iso in (("in_step_normalize", "normalize"), ("in_step_forward", "forward" if (args.fwd_only or not saved) else "forward_save"),
+                        ("in_step_forward_finish", "forward_finish"), ("in_step_backward", "backward_saved" if saved else "backward"),
+                        ("in_step_backward_finish", "backward_finish")):
+        if k_in in st and k_iso in kernels:
+            kernels[k_iso]["in_step_ms"] = round(st[k_in], 4)
+    if "in_step_total" in st:
+        kernels["in_step_sequence_total"] = {"ms": round(st["in_step_total"], 4)}
     # the saved backward of the local block has three kernels per width: the pair kernel on the fragment-major operand (fast_bwd_xfp_kernel:
     # what the step runs when stage_times reports xfp_path), the one-tile-per-barrier kernel on the same operand (fast_bwd_dsl_kernel<...,
     # true>) and the one that stages the column tiles through LDS (..., false>)
@@ -534,21 +554,29 @@ def main():
         "loss": loss_val,
         "roofline": {"bound": "mfma", "kernel": f"{dom_kernel_label} (crossclr_{dom}{entry_suffix if dom == 'backward_saved' else ''}; dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
-                     "source": "HIP events in this process (torch's current stream = the launch stream), median of 20 launches "
-                               "after the timed region; the rocprofv3 figure of the same command is under profiles/",
+                     "source": "HIP events in this process (torch's current stream = the launch stream): median over 50 passes of the step's own "
+                               "kernel sequence (normalize, forward + save, finish, saved backward, finish) right after the timed region, events "
+                               "between the launches -- the kernel in its place in the step, which is what the rocprofv3 trace of the same command "
+                               "(profiles/) shows; `back_to_back_launch_ms` = the median of 20 launches of the kernel alone (package power limit: slower)",
+                     "back_to_back_launch_ms": round(st[dom], 4),
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": (traffic["source"] + " (rocprofv3 --pmc passes of tools/kbench.py, read from the committed "
                                         "summary -- bench.py cannot profile itself)") if traffic else None,
                      "traffic_csrc_sha": traffic["csrc_sha"] if traffic else None, "csrc_sha": csrc_sha(),
                      "traffic_stale": (traffic["csrc_sha"] != csrc_sha()) if traffic else None,
-                     "hbm_gbps_at_that_traffic": round(traffic["bytes"] / (st[dom] * 1e-3) / 1e9, 1) if traffic else None,
+                     "hbm_gbps_at_that_traffic": round(traffic["bytes"] / (dom_ms * 1e-3) / 1e9, 1) if traffic else None,
                      "algorithmic_hbm_bytes_per_launch": 2.0 * b * d * 2 + 2.0 * b * d * 4 + 6.0 * b * 4,
-                     "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(st[dom], 4),      # (the median of those launches)
+                     "algorithmic_flops_per_launch": alg[dom], "avg_launch_ms": round(dom_ms, 4),      # (the in-step median)
                      "whole_step_algorithmic_tflops_per_gpu": round(step_tf, 2),
                      "whole_step_frac": round(step_tf / peak, 4),
                      },
         "kernels": kernels,
     }
+    if args.fwd_only and world == 1:
+        ex = 4.0 * b * b * d * (1.0 + (256.0 if st["fast_path"] else 128.0) / (2.0 * b)) / (dom_ms * 1e-3) / 1e12
+        out["roofline"].update(executed_tflops=round(ex, 2), frac_executed=round(ex / peak, 4),
+                               note="symmetric forward: the upper triangle of the stacked matrix is evaluated, 4.06 b^2 D executed for the 6 b^2 D "
+                                    "algorithmic flops -- `frac` (algorithmic, the contract's definition) can pass 1, `frac_executed` cannot")
     if args.mode == "bf16":
         # what a loop of nothing but MFMAs sustains on this device, measured NOW (the package sits at its power limit with toggling
         # operands: DESIGN.md 3.1) -- not a constant carried over from an earlier round

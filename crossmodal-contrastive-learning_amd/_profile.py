@@ -14,12 +14,16 @@ from . import loss as L
 
 
 def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
-                compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None, settle: int = 0
-                ) -> Dict[str, float]:
+                compute_mode: str, iters: int = 10, warmup: int = 2, negative_scale=None, loss_weight=None, settle: int = 0,
+                in_step: int = 0, forward_only: bool = False) -> Dict[str, float]:
     """Median milliseconds per launch of each single-GPU stage (normalize, forward, forward_finish,
     backward, backward_finish; forward_save / backward_saved when the plan has the save-for-backward pair -- those two
     are what a training step launches, `forward` / `backward` are the recomputing entry points);
-    with sample weights the `_w` entry points are the ones timed."""
+    with sample weights the `_w` entry points are the ones timed.
+    in_step > 0: additionally `in_step` passes of the step's own kernel SEQUENCE (normalize, forward [+ save], forward_finish, [saved] backward,
+    backward_finish; forward_only: the first three), events between the launches: `in_step_<stage>` = the median duration of each kernel IN ITS
+    PLACE in the step.  Back-to-back launches of one MFMA kernel alone keep the package at its power limit without the row kernels' pauses and
+    run a few per cent slower than the same kernel inside a step: the in-step figure is the one that adds up to the step time."""
     lib = nat.library()
     _, ws = L._forward_impl(video, text, temperature, negative_w, compute_mode, None, negative_scale, loss_weight,
                             save_for_backward=True)
@@ -89,6 +93,28 @@ def stage_times(video: torch.Tensor, text: torch.Tensor, temperature: float, neg
         torch.cuda.synchronize(dev)
         ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
         out[name] = ms[len(ms) // 2]          # median per launch (a mean over ten launches moved by 8 % with one slow launch)
+    if in_step > 0:
+        seq = [("normalize", stages["normalize"]),
+               ("forward", stages["forward"] if (forward_only or stages.get("forward_save") is None) else stages["forward_save"]),
+               ("forward_finish", stages["forward_finish"])]
+        if not forward_only:
+            seq += [("backward", stages["backward_saved"] if stages.get("backward_saved") is not None else stages["backward"]),
+                    ("backward_finish", stages["backward_finish"])]
+        for _ in range(3):
+            for _, fn in seq:
+                nat.check(fn())
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)] for _ in range(in_step)]
+        for row in evs:
+            row[0].record()
+            for k, (_, fn) in enumerate(seq):
+                nat.check(fn())
+                row[k + 1].record()
+        torch.cuda.synchronize(dev)
+        for k, (name, _) in enumerate(seq):
+            ms = sorted(row[k].elapsed_time(row[k + 1]) for row in evs)
+            out["in_step_" + name] = ms[len(ms) // 2]
+        tot = sorted(row[0].elapsed_time(row[-1]) for row in evs)
+        out["in_step_total"] = tot[len(tot) // 2]
     out["fast_path"] = float(plan.fast_path)
     out["saved_path"] = float(stash is not None)
     out["xf_path"] = float(xf is not None and xf_name != "crossclr_backward_saved")
