@@ -900,14 +900,19 @@ static size_t rect_bytes_s(const crossclr_plan* plan) {
 #ifdef CROSSCLR_NO_FAST
     (void)plan; return 0;
 #else
-    return (plan && plan->mode == CROSSCLR_MODE_BF16 && plan->fast_path && plan->stash_bytes) ? fast_stash_bytes_rect(plan->bpad, plan->Dpad, 1) : 0;
+    if (!plan || plan->mode != CROSSCLR_MODE_BF16 || !plan->stash_bytes) return 0;
+    if (plan->fast_path) return fast_stash_bytes_rect(plan->bpad, plan->Dpad, 1);
+    return plan->Dpad > 1024 ? wide_stash_bytes_rect(plan->bpad, 1) : 0;      // wide plans: the generic second pass writes U AND Ut (below)
 #endif
 }
+// wide bf16 plans (Dpad > 1024) have no transposed launch of the saved backward: their second pass writes Ut behind U (like a remote block's)
+// and the backward is two DIRECT launches, over U with the rows' statistics and over Ut with the columns'
+static bool wide_two_pass(const crossclr_plan* plan) { return plan && plan->mode == CROSSCLR_MODE_BF16 && !plan->fast_path && plan->Dpad > 1024; }
 static size_t stash_bytes_s(const crossclr_plan* plan) {
     if (!plan || !plan->stash_bytes) return 0;
     if (plan->mode == CROSSCLR_MODE_BF16) {
         const size_t rb = rect_bytes_s(plan);
-        return rb ? rb + (size_t)2 * plan->bpad * 4 : 0;
+        return rb ? (wide_two_pass(plan) ? 2 : 1) * rb + (size_t)2 * plan->bpad * 4 : 0;
     }
     if (plan->fast_path || plan->mode != CROSSCLR_MODE_FP32) return 0;
     return 2 * plan->stash_bytes <= ((size_t)16 << 30) ? 2 * plan->stash_bytes : 0;
@@ -932,9 +937,9 @@ extern "C" int crossclr_forward_save_s(const crossclr_plan* plan, const void* xh
     if (plan->mode == CROSSCLR_MODE_BF16) {   // full (non-symmetric) second pass: bf16 records + the zero statistics behind them
         rc = device_zero_header(header, stream);
         if (rc) return rc;
-        rc = device_zero(static_cast<unsigned char*>(stash) + rect_bytes_s(plan), (size_t)2 * plan->bpad * 4, stream);
+        rc = device_zero(static_cast<unsigned char*>(stash) + (wide_two_pass(plan) ? 2 : 1) * rect_bytes_s(plan), (size_t)2 * plan->bpad * 4, stream);
         if (rc) return rc;
-        return forward_generic(plan, g, xhat, xhat, out, kcols, shift, 2, stream, static_cast<float*>(stash));
+        return forward_generic(plan, g, xhat, xhat, out, kcols, shift, 2, stream, static_cast<float*>(stash), wide_two_pass(plan) ? shift : nullptr);
     }
     if (!env_knobs().disable_symmetric)
         return forward_generic_sym<float>(plan, g, xhat, out, kcols, part + ws_colpart_off(plan), header, stream, static_cast<float*>(stash), shift);
@@ -959,6 +964,16 @@ extern "C" int crossclr_backward_saved_s(const crossclr_plan* plan, const void* 
         // W[p][q] = U[p][q] rz_p + U[q][p] rz_q: the direct launch weighs with the ROW statistics only (column side: zeros), the transposed
         // launch with the statistics of the rows it contracts over (output side: zeros) and accumulates -- two 8 B^2 D launches of the saved
         // backward instead of the 16 B^2 D (1 + ...) recompute of the generic kernel
+        if (wide_two_pass(plan)) {   // U rz_p from the first array, Ut rz_q from the second: two direct launches of the D-slice kernel in column parts
+            const unsigned char* U = static_cast<const unsigned char*>(stash);
+            const size_t rb = rect_bytes_s(plan);
+            const float* zw = reinterpret_cast<const float*>(U + 2 * rb);
+            rc = fast_backward_saved(plan, g, xhat, U, rz, wrz, zw, zw, gbuf, accumulate, krows, krows, 1, stream);
+            if (rc) return fail(rc, "fast_backward_saved (two-pass, wide, rows' side): unsupported Dpad %d", plan->Dpad);
+            rc = fast_backward_saved(plan, g, xhat, U + rb, zw, zw, rz, wrz, gbuf, 1, krows, krows, 1, stream);
+            return rc ? fail(rc, "fast_backward_saved (two-pass, wide, columns' side): unsupported Dpad %d", plan->Dpad)
+                      : launch_status("fast_bwd_dsl_kernel (two-pass pair, wide)");
+        }
         const float* zeros = reinterpret_cast<const float*>(static_cast<const unsigned char*>(stash) + rect_bytes_s(plan));
         rc = fast_backward_saved(plan, g, xhat, stash, rz, wrz, zeros, zeros, gbuf, accumulate, krows, krows, 1, stream);
         if (rc) return fail(rc, "fast_backward_saved (two-pass, direct): unsupported Dpad %d", plan->Dpad);
@@ -1201,7 +1216,7 @@ extern "C" size_t crossclr_rect_stash_bytes_s(const crossclr_plan* plan, int nra
     if (!plan) return 0;
     const size_t one = crossclr_rect_stash_bytes(plan, nranks);
     if (plan->mode == CROSSCLR_MODE_BF16)
-        return (one && plan->fast_path && rect_bytes_s(plan)) ? 2 * one + rect_zero_floats(plan) * 4 : 0;
+        return (one && rect_bytes_s(plan)) ? 2 * one + rect_zero_floats(plan) * 4 : 0;
     if (plan->fast_path || plan->mode != CROSSCLR_MODE_FP32) return 0;
     return one && 2 * one <= ((size_t)32 << 30) ? 2 * one : 0;
 }

@@ -276,7 +276,8 @@ int crossclr_backward_rect_saved(const crossclr_plan* plan, const void* xhat_all
  * W[p][q] = U rz_p + Ut rz_q from them (bwd_saved32_kernel<..., RM, RECT>): no remote block of an exact-fp32 run is recomputed at any
  * temperature.  bf16 register-resident plans (D <= 1024): two arrays of bf16 records (U, Ut: 2 x crossclr_rect_stash_bytes) followed by
  * (world + 1) x 2 bpad floats of zeros, and the backward is two rectangular launches of the saved D-slice kernel (U with the rows'
- * statistics, Ut with the columns').  Wide bf16 plans: 0 (crossclr_backward_s recomputes there).                                      */
+ * statistics, Ut with the columns').  Wide bf16 plans (D > 1024): the same -- and their LOCAL block's pair (crossclr_forward_save_s /
+ * crossclr_backward_saved_s) works that way too: crossclr_stash_bytes_s = 2 x records (U, Ut) + 2 bpad zeros, two direct launches.       */
 size_t crossclr_rect_stash_bytes_s(const crossclr_plan* plan, int nranks);
 int crossclr_forward_rect_save_s(const crossclr_plan* plan, const void* xhat_rows, const void* xhat_all, int first_rank, int nranks,
                                  float temperature, float negative_weight, const crossclr_sample_weights* sw,

@@ -362,7 +362,8 @@ def test_fp32_sharded_two_pass_blocks_from_saved_exponentials(world, B, D, tau):
     assert (gvS.double().cpu() - ref["grad_v"]).abs().max().item() <= 1e-3 * scale
 
 
-@pytest.mark.parametrize("world,B,D,tau", [(2, 512, 128, 0.005), (3, 300, 96, 0.004), (4, 2048, 512, 0.005), (8, 1024, 1000, 0.003)])
+@pytest.mark.parametrize("world,B,D,tau", [(2, 512, 128, 0.005), (3, 300, 96, 0.004), (4, 2048, 512, 0.005), (8, 1024, 1000, 0.003),
+                                           (2, 512, 1100, 0.005), (4, 1024, 1536, 0.004)])       # (the last two: wide plans, U and Ut for the local block too)
 def test_bf16_sharded_two_pass_blocks_from_saved_exponentials(world, B, D, tau):
     """bf16 register-resident plans in the two-pass regime of a sharded run: the block against the other ranks saves bf16 records of U and of Ut
     and its backward is two rectangular launches of the saved D-slice kernel (rows' side, columns' side); against the recomputing pair of the

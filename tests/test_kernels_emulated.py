@@ -530,6 +530,44 @@ def test_wide_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
         assert (gts.double() - ref["grad_t"]).abs().max().item() <= 1e-2 * scale
 
 
+@pytest.mark.parametrize("B,D,weighted", [(40, 1100, False), (70, 1030, True)])
+def test_two_pass_regime_wide_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
+    """tau = 0.004 on a wide bf16 plan (D > 1024: generic forward): there is no transposed launch of the D-slice kernel in column parts, so the
+    second pass writes bf16 records of U AND of Ut[p][q] = exp2(x - shift_q) and the backward is two DIRECT launches (U with the rows'
+    statistics, Ut with the columns') instead of the recomputing generic backward: same loss, gradients within the bf16 rounding."""
+    plan = nat.make_plan(B, D, 1, 0, nat.MODE_BF16)
+    n32 = 2 * plan.bpad // 32
+    assert plan.fast_path == 0 and plan.Dpad == 1152
+    assert nat.library().crossclr_stash_bytes_s(ctypes.byref(plan)) == 2 * n32 * n32 * 2048 + 2 * plan.bpad * 4
+    v, t = orc.make_inputs("randn", B, D, 33)
+    kw = {}
+    if weighted:
+        g = torch.Generator().manual_seed(9)
+        keep = lambda: (torch.rand(B, generator=g) > 0.3).float()
+        kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+    calls = []
+    real = nat.library().crossclr_backward_saved_s
+    monkeypatch.setattr(nat.library(), "crossclr_backward_saved_s", lambda *a: (calls.append(1), real(*a))[1], raising=False)
+
+    def step():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.004, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    ls, gvs, gts = step()
+    assert len(calls) == 1
+    monkeypatch.setenv("CROSSCLR_DISABLE_SAVE", "1")
+    lr, gvr, gtr = step()
+    assert len(calls) == 1          # (the recomputing path)
+    assert abs(ls - lr) <= 1e-5 * max(1.0, abs(lr))
+    scale = max(gvr.abs().max().item(), gtr.abs().max().item())
+    assert (gvs - gvr).abs().max().item() <= 1e-2 * scale and (gts - gtr).abs().max().item() <= 1e-2 * scale
+    if not weighted:
+        ref = orc.streaming_loss_and_grads(v, t, 0.004, 0.8)
+        assert abs(ls - float(ref["loss"])) <= 2e-2 * max(1.0, abs(float(ref["loss"])))
+        assert (gvs.double() - ref["grad_v"]).abs().max().item() <= 3e-2 * scale
+
+
 @pytest.mark.parametrize("B,D,weighted", [(70, 24, False), (150, 40, True), (40, 600, False)])
 def test_two_pass_regime_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
     """tau = 0.004, compute_mode="bf16" (register-resident plans): the full second pass leaves bf16 records U[p][q] = exp2(x - shift_p) in

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import crossclr_amd
 from bench import make_inputs
 CASES = [(8192, 512, 0.03, "bf16"), (8192, 1024, 0.03, "bf16"), (8192, 1536, 0.03, "bf16"), (8192, 2048, 0.03, "bf16"),
-         (8192, 512, 0.005, "bf16"), (8192, 512, 0.005, "fp32"), (8192, 1100, 0.03, "bf16")]
+         (8192, 512, 0.005, "bf16"), (8192, 512, 0.005, "fp32"), (8192, 1100, 0.03, "bf16"), (8192, 1536, 0.005, "bf16")]
 for B, D, tau, mode in CASES:
     v, t = make_inputs(B, D, 1234)
     v, t = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
