@@ -290,6 +290,10 @@ def main():
     ap.add_argument("--selftest-emu", action="store_true",
                     help="TESTS ONLY (tests/test_bench_cpu.py): CPU tensors, gloo, the host-emulation build of the kernels -- "
                          "exercises the multi-rank plumbing, the timing fences and the JSON line without a GPU")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TESTS ONLY (tests/test_gpu_ranks_share_gpu.py): all N ranks on cuda:0, collectives over gloo on device tensors "
+                         "(RCCL refuses two ranks on one device) -- the sharded host path, the three operand exchanges and this file's "
+                         "multi-rank diagnostics with the REAL kernels in separate processes on a one-GPU box; not a measurement")
     ap.add_argument("--influential", action="store_true",
                     help="BASELINE config 5: influential-sample pruning + loss weighting from synthetic input-space "
                          "features (crossclr_amd.CrossCLR); not the default workload")
@@ -330,12 +334,12 @@ def main():
         dev = torch.device("cpu")
     else:
         assert nat.backend() == "hip-gfx950", "bench needs the HIP library"
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(0 if args.share_gpu else local_rank)
+        dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if emu:
+        if emu or args.share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -544,7 +548,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
         "samples_per_s": B / t_step,
-        "config": {"workload": ("CrossCLR (influential-sample pruning + weighting) " if args.influential else "CrossCLR_onlyIntraModality ") +
+        "config": {"workload": (f"PLUMBING CHECK, NOT A MEASUREMENT ({world} ranks share ONE GPU, collectives over gloo): " if args.share_gpu else "") +
+                               ("CrossCLR (influential-sample pruning + weighting) " if args.influential else "CrossCLR_onlyIntraModality ") +
                                f"{what}, b={b} rows/GPU, global B={B}, D={d}, "
                                f"tau={TAU}, negative_weight={NEG_W}, {args.mode} operands / fp32 accumulate, "
                                f"randn features seed 1234+rank, {max(0, args.prewarm)} untimed settle steps before the warm-up",
