@@ -290,6 +290,9 @@ def main():
     ap.add_argument("--selftest-emu", action="store_true",
                     help="TESTS ONLY (tests/test_bench_cpu.py): CPU tensors, gloo, the host-emulation build of the kernels -- "
                          "exercises the multi-rank plumbing, the timing fences and the JSON line without a GPU")
+    ap.add_argument("--exchange-deadline", type=float, default=None,
+                    help="N >= 3: seconds each operand-exchange form after the first may take before the run is ended with the line of "
+                         "the forms that finished (default 120; 0 = no watchdog, the default on the host emulation)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TESTS ONLY (tests/test_gpu_ranks_share_gpu.py): all N ranks on cuda:0, collectives over gloo on device tensors "
                          "(RCCL refuses two ranks on one device) -- the sharded host path, the three operand exchanges and this file's "
@@ -327,6 +330,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     emu = args.selftest_emu
+    if args.exchange_deadline is None:
+        args.exchange_deadline = 0.0 if emu else 120.0
     if emu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from emu import build_emu
@@ -441,9 +446,50 @@ def main():
     per_exchange = None
     if world >= 3 and args.mode == "bf16" and os.environ.get("CROSSCLR_EXCHANGE") is None and not args.fwd_only:
         per_exchange, runs = {}, {}
+        # The first form (one standard all_gather_into_tensor) is the line's safety net: should a later form hang or raise on some rank
+        # of a node this code has never seen (its peers would then sit in their collectives), every rank's watchdog ends the process
+        # after `--exchange-deadline` seconds and rank 0 prints the line of the forms that did finish, the failure named in `per_exchange`.
+        import threading
+        state = {"trying": None}
+
+        def give_up():
+            if rank == 0:
+                best = min(runs, key=lambda k: runs[k]["t_step"])
+                r = runs[best]
+                table = {k: {"ms_per_step": round(x["t_step"] * 1e3, 5), "winner": k == best} for k, x in runs.items()}
+                table[state["trying"]] = {"error": f"did not finish within {args.exchange_deadline} s (hung or raised on some rank: see stderr)"}
+                line = {"metric": "contrastive-pairs/sec (fwd+bwd)", "value": (b * world) ** 2 / r["t_step"], "unit": "pairs/s",
+                        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["t_step"] * 1e3,
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                        "config": {"workload": f"CrossCLR_onlyIntraModality fwd+bwd, b={b} rows/GPU, global B={b * world}, D={d}, tau={TAU}, "
+                                               f"negative_weight={NEG_W}, bf16 operands / fp32 accumulate (REDUCED LINE: an operand-exchange "
+                                               f"form failed, the per-kernel section was not reached)",
+                                   "global_batch": b * world, "rows_per_gpu": b, "dim": d, "parallelism": f"row-sharded x{world}",
+                                   "operand_exchange": best},
+                        "loss": r["loss"], "per_rank": r["per_rank"], "per_exchange": table}
+                os.write(result_fd, (json.dumps(line) + "\n").encode())
+            os._exit(0)
+
         for xm in ("allgather", "p2p", "p2p_each"):
             L.set_exchange_for_benchmark(xm)
-            r = runs[xm] = timed_run()
+            state["trying"] = xm
+            dog = None
+            if runs and args.exchange_deadline > 0:
+                dog = threading.Timer(args.exchange_deadline, give_up)
+                dog.daemon = True
+                dog.start()
+            try:
+                if os.environ.get("CROSSCLR_BENCH_INJECT_FAILURE") == xm and rank == world - 1:     # (tests only)
+                    raise RuntimeError(f"injected failure in the {xm} exchange")
+                r = runs[xm] = timed_run()
+            except Exception:
+                if dog is None:
+                    raise
+                import traceback
+                traceback.print_exc()
+                threading.Event().wait()     # (the peers hang in their collectives: every rank leaves through its watchdog)
+            if dog is not None:
+                dog.cancel()
             exposed = [pr.get("exposed_comm_ms") for pr in (r["per_rank"] or []) if pr.get("exposed_comm_ms") is not None]
             per_exchange[xm] = {"ms_per_step": round(r["t_step"] * 1e3, 5),
                                 "ms_per_step_event_median_rank0": round(r["ev_ms"][len(r["ev_ms"]) // 2], 5) if r["ev_ms"] else None,

@@ -88,3 +88,13 @@ def test_bench_gpus8_selftest_measures_the_three_exchanges():
     vs, ts = zip(*[orc.make_inputs("randn", 8, 16, 1234 + r) for r in range(8)])
     ref = float(orc.bf16_operand_model_loss(torch.cat(vs), torch.cat(ts), 0.03, 0.8))
     assert abs(out["loss"] - ref) < 5e-3 * max(1.0, abs(ref))
+
+
+def test_a_failing_exchange_form_still_yields_a_line():
+    """N >= 3 runs the three operand-exchange forms back to back; if one of the later ones raises on a rank (its peers then hang in
+    their collectives) every rank leaves through the watchdog and rank 0 prints the line of the forms that finished."""
+    out = _run(["--gpus", "3", "--selftest-emu", "--rows", "8", "--dim", "16", "--steps", "1", "--warmup", "0", "--prewarm", "0",
+                "--mode", "bf16", "--exchange-deadline", "30"], env_extra={"CROSSCLR_BENCH_INJECT_FAILURE": "p2p"}, timeout=900)
+    assert out["n_gpus"] == 3 and out["config"]["operand_exchange"] == "allgather"
+    assert out["per_exchange"]["allgather"]["winner"] and "error" in out["per_exchange"]["p2p"]
+    assert out["value"] > 0 and out["config"]["global_batch"] == 24
