@@ -1421,8 +1421,16 @@ static int backward_finish_t(const crossclr_plan* p, const float* gbuf, const vo
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((2 * p->b + 3) / 4), block(256);
     if (p->D <= 256 * kRowCache) {      // row pairs: each raw row read once
-        LAUNCH((bwd_finish_pair_kernel<TIN>), dim3((p->b + 3) / 4), block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
-               inv_norm, 1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw, prenormalized);
+#define CROSSCLR_FINISH_PAIR(KC)                                                                                                        \
+    LAUNCH((bwd_finish_pair_kernel<TIN, KC>), dim3((p->b + 3) / 4), block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, \
+           g, inv_norm, 1.0f / temperature, p->b * p->world, grad_out, (TIN*)gv, (TIN*)gt, ldgv, ldgt, lw, prenormalized)
+        switch ((p->D + 255) / 256) {      // (one instantiation per number of 256-element stretches a lane caches)
+            case 1: CROSSCLR_FINISH_PAIR(1); break;
+            case 2: CROSSCLR_FINISH_PAIR(2); break;
+            case 3: CROSSCLR_FINISH_PAIR(3); break;
+            default: CROSSCLR_FINISH_PAIR(4); break;
+        }
+#undef CROSSCLR_FINISH_PAIR
         return launch_status("bwd_finish_pair_kernel");
     }
     LAUNCH((bwd_finish_kernel<TIN>), grid, block, stream, gbuf, p->bwd_slices, (const TIN*)v, (const TIN*)t, ldv, ldt, g, inv_norm,

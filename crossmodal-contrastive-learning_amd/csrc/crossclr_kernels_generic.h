@@ -176,6 +176,31 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
     CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[2][16][256 * KC];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 16;
+    // fp32 rows made of whole, 16-byte aligned stretches (uniform over the launch): the raw loads of BOTH row pairs of the wave are issued
+    // up front, without the per-lane alignment branches of row_load4 (each of which ends in a wait); same values, same order of sums
+    bool whole = false;
+    if constexpr (sizeof(TIN) == 4)
+        whole = (g.D & 3) == 0 && (ldv & 3) == 0 && (ldt & 3) == 0 &&
+                ((reinterpret_cast<uintptr_t>(video) | reinterpret_cast<uintptr_t>(text)) & 15) == 0;
+    f32x4 ra[2][KC], rc[2][KC];
+    if (whole) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int i = i0 + 2 * wave + rr;
+            if (i < g.b) {
+                const float* pv = reinterpret_cast<const float*>(video + (size_t)i * ldv);
+                const float* pt = reinterpret_cast<const float*>(text + (size_t)i * ldt);
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int d = 4 * lane + 256 * k;
+                    if (d < g.D) {
+                        ra[rr][k] = *reinterpret_cast<const f32x4*>(pv + d);
+                        rc[rr][k] = *reinterpret_cast<const f32x4*>(pt + d);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {     // (unrolled: the second pair's loads are in flight while the first pair is reduced)
         const int r = 2 * wave + rr, i = i0 + r;     // (bpad is a multiple of 128: every i < bpad)
@@ -192,8 +217,13 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cv[k][j] = 0.0; ct[k][j] = 0.0; }
             if (valid && d < g.D) {
-                row_load4(pv, d, g.D, cv[k]);
-                row_load4(pt, d, g.D, ct[k]);
+                if (whole) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cv[k][j] = (double)ra[rr][k][j]; ct[k][j] = (double)rc[rr][k][j]; }
+                } else {
+                    row_load4(pv, d, g.D, cv[k]);
+                    row_load4(pt, d, g.D, ct[k]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ssv += cv[k][j] * cv[k][j]; sst += ct[k][j] * ct[k][j]; dot += cv[k][j] * ct[k][j]; }
             }
@@ -1094,7 +1124,9 @@ __global__ void __launch_bounds__(256) bwd_finish_kernel(const float* gbuf, int 
 // Rows of at most 256 * kRowCache elements: ONE wave finishes the video row i AND the text row i (each is the other's positive
 // pair), so both raw rows are read from HBM once instead of twice (as own row and as partner): 134 MB instead of 168 MB per
 // launch at B = 8192, D = 512.  Same arithmetic, term by term, as bwd_finish_kernel above.
-template <typename TIN>
+// KC = stretches of 256 elements a lane caches = ceil(D / 256) <= kRowCache: one instantiation per count, so that a D = 512 launch
+// carries the registers of two stretches, not four (169 -> NN VGPRs: more rows in flight per CU for a kernel that only streams).
+template <typename TIN, int KC>
 __global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf, int nslices, const TIN* video, const TIN* text, long ldv,
                                                               long ldt, Geo g, const float* inv_norm, float inv_tau,
                                                               int Bglobal, const double* grad_out, TIN* gvideo,
@@ -1114,29 +1146,83 @@ __global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf,
     const double pc = (double)inv_tau / (double)Bglobal * (lw ? 0.5 * ((double)lw[i] + (double)lw[g.bpad + i]) : 1.0);
     const bool clamped_v = iv >= 9.99e11 || prenormalized == 1, clamped_t = it >= 9.99e11 || prenormalized == 1;
     const double go = grad_out[0];
-    double ghv[kRowCache][4], ght[kRowCache][4], xv[kRowCache][4], xt[kRowCache][4];
+    double ghv[KC][4], ght[KC][4], xv[KC][4], xt[KC][4];
     double dotv = 0.0, dott = 0.0;
+    f32x4 sv[KC], st[KC];
+    double a[KC][4], c[KC][4];
+    // fp32 rows made of whole, 16-byte aligned stretches (uniform over the launch): EVERY load of the row pair -- first slice, raw rows,
+    // then the other slices, stretch by stretch -- is issued before the first value is used (12 KiB in flight per wave at D = 512 with two
+    // slices; the per-stretch form below waits after every pair of loads).  Same additions in the same order: bit-identical results.
+    bool whole = false;
+    if constexpr (sizeof(TIN) == 4)
+        whole = (g.D & 3) == 0 && (ldv & 3) == 0 && (ldt & 3) == 0 &&
+                ((reinterpret_cast<uintptr_t>(video) | reinterpret_cast<uintptr_t>(text)) & 15) == 0;
+    if (whole) {
+        f32x4 ra[KC], rc[KC];
 #pragma unroll
-    for (int k = 0; k < kRowCache; ++k) {
+        for (int k = 0; k < KC; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.D) {
+                // (the slices are read exactly once: streaming loads)
+                sv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + d));
+                st[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + d));
+                ra[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pv) + d);
+                rc[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pt) + d);
+            }
+        }
+        for (int sl = 1; sl < nslices; ++sl) {
+            f32x4 uv[KC], ut[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int d = 4 * lane + 256 * k;
+                if (d < g.D) {
+                    uv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + sl * slice + d));
+                    ut[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + sl * slice + d));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int d = 4 * lane + 256 * k;
+                if (d < g.D) {
+                    sv[k] += uv[k];
+                    st[k] += ut[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[k][j] = (double)ra[k][j];
+                c[k][j] = (double)rc[k][j];
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int d = 4 * lane + 256 * k;
+            if (d < g.D) {
+                sv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + d));
+                st[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + d));
+                for (int sl = 1; sl < nslices; ++sl) {
+                    sv[k] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + sl * slice + d));
+                    st[k] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + sl * slice + d));
+                }
+                row_load4(pv, d, g.D, a[k]);
+                row_load4(pt, d, g.D, c[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
         const int d = 4 * lane + 256 * k;
         if (d < g.D) {
-            // (the slices are read exactly once: streaming loads)
-            f32x4 sv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + d));
-            f32x4 st = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + d));
-            for (int sl = 1; sl < nslices; ++sl) {
-                sv += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grv + sl * slice + d));
-                st += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grt + sl * slice + d));
-            }
-            double a[4], c[4];
-            row_load4(pv, d, g.D, a);
-            row_load4(pt, d, g.D, c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool in = d + j < g.D;
-                ghv[k][j] = in ? ((double)sv[j] * sc - c[j] * ixt * pc) : 0.0;
-                ght[k][j] = in ? ((double)st[j] * sc - a[j] * ixv * pc) : 0.0;
-                xv[k][j] = a[j] * ixv;
-                xt[k][j] = c[j] * ixt;
+                ghv[k][j] = in ? ((double)sv[k][j] * sc - c[k][j] * ixt * pc) : 0.0;
+                ght[k][j] = in ? ((double)st[k][j] * sc - a[k][j] * ixv * pc) : 0.0;
+                xv[k][j] = a[k][j] * ixv;
+                xt[k][j] = c[k][j] * ixt;
                 dotv += xv[k][j] * ghv[k][j];
                 dott += xt[k][j] * ght[k][j];
             }
@@ -1147,7 +1233,7 @@ __global__ void __launch_bounds__(256) bwd_finish_pair_kernel(const float* gbuf,
     TIN* ov = gvideo + (size_t)i * ldgv;
     TIN* ot = gtext + (size_t)i * ldgt;
 #pragma unroll
-    for (int k = 0; k < kRowCache; ++k) {
+    for (int k = 0; k < KC; ++k) {
         const int d = 4 * lane + 256 * k;
         if (d < g.D) {
             double a[4], c[4];
