@@ -176,31 +176,6 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
     CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[2][16][256 * KC];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 16;
-    // fp32 rows made of whole, 16-byte aligned stretches (uniform over the launch): the raw loads of BOTH row pairs of the wave are issued
-    // up front, without the per-lane alignment branches of row_load4 (each of which ends in a wait); same values, same order of sums
-    bool whole = false;
-    if constexpr (sizeof(TIN) == 4)
-        whole = (g.D & 3) == 0 && (ldv & 3) == 0 && (ldt & 3) == 0 &&
-                ((reinterpret_cast<uintptr_t>(video) | reinterpret_cast<uintptr_t>(text)) & 15) == 0;
-    f32x4 ra[2][KC], rc[2][KC];
-    if (whole) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int i = i0 + 2 * wave + rr;
-            if (i < g.b) {
-                const float* pv = reinterpret_cast<const float*>(video + (size_t)i * ldv);
-                const float* pt = reinterpret_cast<const float*>(text + (size_t)i * ldt);
-#pragma unroll
-                for (int k = 0; k < KC; ++k) {
-                    const int d = 4 * lane + 256 * k;
-                    if (d < g.D) {
-                        ra[rr][k] = *reinterpret_cast<const f32x4*>(pv + d);
-                        rc[rr][k] = *reinterpret_cast<const f32x4*>(pt + d);
-                    }
-                }
-            }
-        }
-    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {     // (unrolled: the second pair's loads are in flight while the first pair is reduced)
         const int r = 2 * wave + rr, i = i0 + r;     // (bpad is a multiple of 128: every i < bpad)
@@ -217,13 +192,8 @@ __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cv[k][j] = 0.0; ct[k][j] = 0.0; }
             if (valid && d < g.D) {
-                if (whole) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { cv[k][j] = (double)ra[rr][k][j]; ct[k][j] = (double)rc[rr][k][j]; }
-                } else {
-                    row_load4(pv, d, g.D, cv[k]);
-                    row_load4(pt, d, g.D, ct[k]);
-                }
+                row_load4(pv, d, g.D, cv[k]);
+                row_load4(pt, d, g.D, ct[k]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ssv += cv[k][j] * cv[k][j]; sst += ct[k][j] * ct[k][j]; dot += cv[k][j] * ct[k][j]; }
             }

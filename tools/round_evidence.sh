@@ -4,7 +4,7 @@
 TAG=$1
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/${TAG}_gputests.txt
+python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputests_full.txt 2>&1; grep -E "passed|failed|error" gpurun_out/${TAG}_gputests_full.txt | tail -3 > gpurun_out/${TAG}_gputests.txt
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.txt 2>&1
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
 cat gpurun_out/${TAG}_gputests.txt; tail -2 gpurun_out/${TAG}_smoke.txt
