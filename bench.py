@@ -159,6 +159,31 @@ def sustained_mfma(dev):
     return res
 
 
+def library_gemm(dev, n2, d):
+    """The same-box practical roof of the dominant kernel's product: torch.matmul (hipBLASLt / rocBLAS) of a bf16 [n2, n2] matrix with a
+    bf16 [n2, d] one, fp32 accumulation -- G = W X of the saved backward (n2 = 2 b stacked rows, 8 b^2 D flop) WITHOUT forming W from the
+    saved exponentials and the statistics.  Random operands (toggling data: the package power limit applies to the library too), median of
+    20 launches after 5, HIP events."""
+    g = torch.Generator(device="cpu").manual_seed(99)
+    a = torch.randn(n2, n2, generator=g, dtype=torch.float32).to(dev).to(torch.bfloat16)
+    x = torch.randn(n2, d, generator=g, dtype=torch.float32).to(dev).to(torch.bfloat16)
+    out = torch.empty(n2, d, dtype=torch.bfloat16, device=dev)
+    for _ in range(5):
+        torch.matmul(a, x, out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for s, e in ev:
+        s.record()
+        torch.matmul(a, x, out=out)
+        e.record()
+    torch.cuda.synchronize(dev)
+    ms = sorted(s.elapsed_time(e) for s, e in ev)[10]
+    flop = 2.0 * n2 * n2 * d
+    del a, x, out
+    return {"ms": round(ms, 4), "tflops": round(flop / (ms * 1e-3) / 1e12, 1),
+            "what": f"torch.matmul bf16 [{n2},{n2}] @ [{n2},{d}] -> bf16, fp32 accumulate (the library's kernel for the dominant kernel's "
+                    f"product, operands ready-made), median of 20"}
+
+
 def sustained_series(step, dev, nsteps, chunk=100):
     """`nsteps` more steps of the same workload, HIP events around every `chunk` steps: does the step time hold for a second or
     more on a part that runs at its package power limit?"""
@@ -281,6 +306,9 @@ def main():
     ap.add_argument("--prewarm", type=int, default=40,
                     help="untimed device settle steps BEFORE the --warmup steps (GPU clocks / allocator reach steady state "
                          "only after ~20-50 steps: 0.79 -> 0.72 ms/step); reported in the JSON line")
+    ap.add_argument("--settle-cap", type=int, default=400,
+                    help="after --prewarm: further untimed 20-step chunks until three consecutive ones agree within 1 %% (at most this many "
+                         "steps; 0 = none); reported as settle_steps_used")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary measurements (fp32, config 2, D = 1024)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
@@ -440,6 +468,23 @@ def main():
 
     for _ in range(max(0, args.prewarm)):
         step()
+    # The timed window starts only once the device has settled: chunks of 20 steps (each between synchronize fences, like the timed
+    # region itself) until three consecutive chunks agree within 1 % -- at most `--settle-cap` steps (a freshly leased MI355X ramps its
+    # clocks for 50-200 steps; a 20-step window taken before that reads 5-7 % slow).  Single-rank runs only: every rank would have to take
+    # the same decision.  Reported as `settle_steps_used`.
+    settle_used, settle_chunks = 0, []
+    if world == 1 and not emu and args.settle_cap > 0:
+        while settle_used < args.settle_cap:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize(dev)
+            settle_chunks.append((time.perf_counter() - t0) / 20 * 1e3)
+            settle_used += 20
+            last = settle_chunks[-3:]
+            if len(last) == 3 and max(last) <= 1.01 * min(last):
+                break
     # From 3 ranks on the packed operands can travel three ways (loss._OperandExchange); which one wins is a property of the node, so the
     # timed region is run once per form, back to back (each with its own warm-up), and the line reports all three: `value` / `ms_per_step`
     # are the fastest form's K steps, `per_exchange` the table.  CROSSCLR_EXCHANGE pins one form (then only that one is run).
@@ -588,6 +633,7 @@ def main():
     out = {
         "metric": f"contrastive-pairs/sec ({what})", "value": B * B / t_step, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm),
+        "settle_steps_used": settle_used, "settle_chunk_ms_per_step": [round(x, 5) for x in settle_chunks[-6:]],
         "ms_per_step": t_step * 1e3,
         "ms_per_step_event_median": ev_ms[len(ev_ms) // 2] if ev_ms else None,
         "ms_per_step_event_min_max": [ev_ms[0], ev_ms[-1]] if ev_ms else None,
@@ -634,6 +680,10 @@ def main():
         sm = sustained_mfma(dev)
         out["roofline"]["sustained_mfma"] = sm
         out["roofline"]["frac_of_sustained_random_operands"] = round(dom_tf / sm["random_operands"]["tflops"], 4)
+        if world == 1 and not args.fwd_only:
+            lg = library_gemm(dev, 2 * b, d)
+            out["roofline"]["library_gemm"] = lg
+            out["roofline"]["frac_of_library_gemm"] = round(dom_tf / lg["tflops"], 4)
     if world == 1 and args.sustained_steps > 0:
         out["sustained"] = sustained_series(step, dev, args.sustained_steps)
     if per_rank is not None:

@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # saved backward -2.7 %, forward ~-2 % (profiles/r04_ab_noslp.txt, A/B on one box)
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 FLAGS = COMMON + ["-shared", "-x", "hip"]          # (the single-translation-unit form: tools/build_variant.py, tools/isa_loop_stats.py)
-UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_saved_wide.cpp", "tu_recomp.cpp"]
+UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_fwdp.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_saved_wide.cpp", "tu_recomp.cpp"]
 
 
 def sources():
@@ -33,7 +33,11 @@ def sources():
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
-    with tempfile.TemporaryDirectory(prefix="crossclr_build_") as tmp:
+    keep = os.environ.get("CROSSCLR_KEEP_OBJS")      # tools/build_variant_tu.py re-links one re-compiled leaf against these objects
+    if keep:
+        os.makedirs(keep, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="crossclr_build_") as tmpdir:
+        tmp = keep or tmpdir
         procs = []
         for u in UNITS:
             obj = os.path.join(tmp, u.replace(".cpp", ".o"))

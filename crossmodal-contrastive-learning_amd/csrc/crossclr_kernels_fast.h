@@ -767,6 +767,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) fast_bwd16_kernel(const bf16_
 #include "crossclr_kernels_sym.h"
 #include "crossclr_kernels_dsl.h"
 #include "crossclr_kernels_dslp.h"
+#include "crossclr_kernels_symp.h"
 namespace crossclr {
 
 // ---------------------------------------------------------------------------------------------
@@ -792,6 +793,9 @@ namespace crossclr {
 #if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_FWD)
 #define CROSSCLR_DEF_FWD 1
 #endif
+#if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_FWDP)
+#define CROSSCLR_DEF_FWDP 1
+#endif
 #if !defined(CROSSCLR_SPLIT) || defined(CROSSCLR_TU_SAVED_LDS)
 #define CROSSCLR_DEF_SAVED_LDS 1
 #endif
@@ -814,6 +818,36 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
     const int usable = (col_ranks - (skip_rank >= 0 ? 1 : 0)) * (2 * p->bpad / 32);
     return fwd_make_work(symmetric ? 1 : (pairs ? 3 : 2), p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
 }
+
+// the symmetric forward of whole batches (crossclr_kernels_symp.h: one unbroken MFMA stream per wave): Dpad <= 512, b a multiple of 128,
+// no sample weights, a stash below 4 GiB
+#ifndef CROSSCLR_DEF_FWDP
+int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, float* part, float* colpart, int* header,
+                      void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream);
+#else
+CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, float* part, float* colpart,
+                                    int* header, void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream) {
+    const bf16_t* r = (const bf16_t*)rows;
+    unsigned char* st = (unsigned char*)stash;
+    const unsigned sb = (unsigned)stash_bytes;
+    dim3 grid(wk.nblk), block(256);
+    (void)r; (void)st; (void)sb; (void)grid; (void)block;
+#define CROSSCLR_LZ(DK)                                                                                                                    \
+    do {                                                                                                                                   \
+        if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm);  \
+    } while (0)
+    switch (p->Dpad) {
+        case 128: CROSSCLR_LZ(8); break;
+        case 256: CROSSCLR_LZ(16); break;
+        case 384: CROSSCLR_LZ(24); break;
+        case 512: CROSSCLR_LZ(32); break;
+        default: return CROSSCLR_E_ARG;
+    }
+#undef CROSSCLR_LZ
+    return CROSSCLR_OK;
+}
+#endif   // CROSSCLR_DEF_FWDP
 
 // the software-pipelined forward (Dpad <= 512), all three kinds, with or without saving the exponentials
 #ifndef CROSSCLR_DEF_FWD
@@ -847,6 +881,15 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
         permp = &e.perm;
     }
     const FwdPerm perm = *permp;
+    // whole batches of the local block without sample weights: the kernel with one unbroken MFMA stream per wave (crossclr_kernels_symp.h;
+    // the same bits as the kernel below, CROSSCLR_FWD_PAIR=0 keeps that one: A/B)
+    const char* pair_env = getenv("CROSSCLR_FWD_PAIR");      // (read per launch: the bit-identity tests flip it inside one process)
+    const bool pair_kernel = !(pair_env && pair_env[0] == '0');
+    if (pair_kernel && kind == 1 && !sw && g.b == g.bpad && p->Dpad <= 512 && wk.tpr == 8) {
+        const size_t sbytes = st ? stash_tiles_total(8, 2 * p->bpad / 32) * 2048 : 0;
+        if (sbytes < ((size_t)1 << 32) && (size_t)wk.NB * wk.NT * 128 < ((size_t)1 << 32))
+            return fast_forward_pair(p, g, wk, rows, part, colpart, header, stash, sbytes, perm, stream);
+    }
 #define CROSSCLR_LP3(DK, KIND, SW, ST) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st, perm)
 #define CROSSCLR_LP2(DK, KIND)                                   \

@@ -1,0 +1,477 @@
+// crossclr_kernels_symp.h -- the symmetric forward of the local block (Dpad <= 512, whole 128-row batches, no sample weights), rebuilt
+// around ONE unbroken MFMA stream per wave.
+//
+// Same math, same work list, same workspace / stash layout and the same summation order as fast_fwd_pipe_kernel<DK, 1, false, ST>
+// (crossclr_kernels_sym.h; reference trainer/loss.py:83-100, 59-60): the two kernels produce the same bits
+// (tests/test_gpu_fwd_pair.py).  What changed is everything BETWEEN the 64 MFMAs of consecutive tiles.  Round 4's kernel left the
+// matrix pipe idle for ~300 instructions per tile (profiles/r05_fwd_seam.txt: 32 v_accvgpr_read copies of the finished tile, the 32 row-sum
+// adds hipcc had sunk below the loop, a 5-field cursor queue, the barrier, the flush, the descriptor of the stash tile, and the
+// full LDS latency of the first fragment reads): MFMA-busy 0.51.  Here:
+//
+//   two accumulator sets   tile i accumulates into set i & 1 (VGPRs, not AGPRs: the epilogue reads them in place -- no copies) while the
+//                          epilogue of tile i - 1 works on the other set in the MFMA shadow; the loop body is unrolled by two so that the
+//                          sets are static.  All 256 B-fragment registers of the wave's 64 rows live in AGPRs.
+//   barrier mid-tile       barrier B_i sits between k-steps DK/2 - 1 and DK/2 of tile i and proves "tile i + 1 has landed everywhere, tile
+//                          i - 1 is read by everybody": the first fragment reads of tile i + 1 are issued in the LAST k-steps of tile i
+//                          and are complete when its last MFMA issues -- the seam between two tiles is the loop branch and ~12 scalar
+//                          instructions.  The DMA of tile i + 3 goes out behind B_i into the stage tile i - 1 left (4-stage ring).
+//   counted everything     every LDS read is asm with a counted lgkmcnt (one wait per two k-steps); all reads of a tile are issued by k-step
+//                          DK - 5, so the closing lgkmcnt(0) in front of the back edge costs nothing; s_waitcnt vmcnt(NXO) in front of the
+//                          barrier counts the LOADS younger than tile i + 1's pieces only (stores may retire out of order with loads).
+//   scalars                the stash is ONE buffer descriptor with 32-bit scalar offsets bumped by 2 KiB per tile (the host takes this kernel
+//                          for stashes below 4 GiB), the column sums leave through one descriptor as well; the work cursor is (row block,
+//                          tile, tiles left in the segment) and the DMA cursor (tile, tiles left in its row block).
+//   flush without branches the 32 column sums a tile publishes are added up by every wave (two ds_read2_b32) and stored by ONE of them: the
+//                          other waves' store carries an out-of-range offset and is dropped by the descriptor's range check -- no divergent
+//                          branch inside the MFMA stream (asm-loaded registers must not be live across control flow: tools/asm_audit.py).
+//
+// Tiles that need a mask (the TPR tiles of a row block's own diagonal block) run the bare MFMA stream and a plain epilogue behind it; the last
+// tile of a segment (a maximal run of one row block's tiles inside the thread block's range) is finished the same way.  Everything else --
+// ragged batches, padding rows, sample weights, rectangular / pair launches, Dpad > 512 -- stays with fast_fwd_pipe_kernel.
+#pragma once
+
+namespace crossclr {
+
+#ifndef CROSSCLR_ZABL
+#define CROSSCLR_ZABL 0   // timing ablations (WRONG results): bit0 no overlapped epilogue chores, bit1 no stash stores, bit2 no DMA,
+                          // bit3 no barrier, bit4 no MFMA, bit5 no fragment reads after the first tile, bit6 no butterfly
+#endif
+
+#ifndef CROSSCLR_EMU
+// accumulators in VGPRs (the epilogue reads them with plain VALU), B fragments in AGPRs (256 of them: the whole accumulation-register half)
+__device__ __forceinline__ void mfma_first_va(f32x16& acc, bf16x8 a, bf16x8 b) {
+    if (CROSSCLR_ZABL & 16) { asm volatile("" : "=v"(acc) : "v"(a), "a"(b)); return; }
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_va(f32x16& acc, bf16x8 a, bf16x8 b) {
+    if (CROSSCLR_ZABL & 16) { asm volatile("" : "+v"(acc) : "v"(a), "a"(b)); return; }
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+// a finished accumulator may be read by VALU 19 wait states after the MFMA that wrote it (16-pass XDL write -> VALU read); the asm MFMAs are
+// invisible to hipcc's hazard recognizer, so the plain epilogues (which follow a tile's last MFMA directly) open with this
+__device__ __forceinline__ void mfma_results_visible() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+__device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// two dwords per lane from LDS, `OFF0` and `OFF1` in units of 4 bytes from the lane's address
+template <int OFF0, int OFF1> __device__ __forceinline__ u32x2 lds_read2_b32_async(unsigned addr) {
+    u32x2 r;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(OFF0), "n"(OFF1));
+    return r;
+}
+#else
+__device__ __forceinline__ void mfma_first_va(f32x16& acc, bf16x8 a, bf16x8 b) {
+    f32x16 z;
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    acc = mfma_32x32x16_bf16(a, b, z);
+}
+__device__ __forceinline__ void mfma_va(f32x16& acc, bf16x8 a, bf16x8 b) { acc = mfma_32x32x16_bf16(a, b, acc); }
+__device__ __forceinline__ void mfma_results_visible() {}
+__device__ __forceinline__ void barrier_only() { __syncthreads(); }
+template <int N> __device__ __forceinline__ void wait_lgkm_n() {}
+template <int OFF0, int OFF1> __device__ __forceinline__ u32x2 lds_read2_b32_async(unsigned long addr) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(addr);
+    u32x2 r;
+    r[0] = p[OFF0];
+    r[1] = p[OFF1];
+    return r;
+}
+#endif
+
+// ---- the fragment-read schedule of one tile (compile-time) ----
+// Read q = 0 .. DK-1 of a step: q < DK - PF fetches the A fragment of k-step q + PF of THIS tile, the last PF ones the fragments of k-steps
+// 0 .. PF-1 of the NEXT tile.  One read per k-step up to k-step DK - 9, two per k-step in k-steps DK - 8 .. DK - 5, none in the last four.
+struct FwdReadPlan {
+    static constexpr int PF = 4;
+    static constexpr int kstep_of(int DK, int q) { return q < DK - 8 ? q : (DK - 8) + (q - (DK - 8)) / 2; }
+    static constexpr int reads_before(int DK, int k) {        // reads issued in k-steps < k
+        return k <= DK - 8 ? k : ((DK - 8) + 2 * (k - (DK - 8)) < DK ? (DK - 8) + 2 * (k - (DK - 8)) : DK);
+    }
+    // LDS operations issued before the wait at the head of k-step k (the flush's two reads go out at the head of k-step DK / 2)
+    static constexpr int ops_before(int DK, int k) { return reads_before(DK, k) + (k > DK / 2 ? 2 : 0); }
+    static constexpr int seq_of(int DK, int q) { return q + (kstep_of(DK, q) >= DK / 2 ? 2 : 0); }
+    // younger operations that may stay in flight when fragment k' (k' >= PF) of this tile is needed at the head of k-step k <= k'
+    static constexpr int keep_for(int DK, int k, int kfrag) { return ops_before(DK, k) - seq_of(DK, kfrag - PF) - 1; }
+    // the flush's second read is consumed in k-step DK / 2 + 2, behind that k-step's wait
+    static constexpr int flush_seq(int DK) { return reads_before(DK, DK / 2) + 1; }
+};
+
+template <int DK, bool ST>
+__global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, Geo g, FwdWork wk, float* part, float* colpart, int* header,
+                                                               unsigned char* stash, unsigned stash_bytes, FwdPerm perm) {
+    constexpr int RB = DK * 32;            // bytes per operand row
+    constexpr int QT = 32;
+    constexpr int TILE = QT * RB;
+    constexpr int TPR = 8;                 // 32-row groups per row block
+    constexpr int RBLK = 256;
+    constexpr int NST = 4;
+    constexpr int NXO = DK / 4;            // DMA pieces per wave and tile
+    constexpr int PF = FwdReadPlan::PF;
+    constexpr int H = 2 * DK, H1 = H / 2, H2 = 3 * H / 4;     // MFMA slots of a tile: exp + row sums | sums of halves, pack, stash | butterfly
+    constexpr int KB = DK / 2;             // the k-step the barrier sits in front of
+    constexpr int CS0 = NST * TILE;        // two column-sum slots [4 waves][32] floats, then a dump slot for the lanes that publish nothing
+    static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512}");
+    static_assert(NST * TILE + 2 * 4 * QT * 4 + 256 <= 160 * 1024, "LDS budget");
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[CS0 + 2 * 4 * QT * 4 + 256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    timing_mark(0);
+    if (blockIdx.x == 0 && tid == 0) { header[0] = wk.kind; header[1] = TPR; header[2] = wk.NT; header[3] = wk.per; }
+    const int NT = wk.NT;
+    const int per_mod = g.bpad / QT;
+
+    const int vb = uniform(blockIdx.x < 256 ? (int)perm.v[blockIdx.x < 256 ? blockIdx.x : 0] : (int)blockIdx.x);
+    int w = fwd_block_begin(wk, vb);
+    const int w_end = fwd_block_begin(wk, vb + 1);
+    if (w >= w_end) return;
+
+    // ---- descriptors and per-lane offsets ----
+    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * RB));
+    const BufRsrc rs_st = make_rsrc(stash, stash_bytes);
+    const BufRsrc rs_cp = make_rsrc(colpart, (unsigned)((size_t)wk.NB * NT * QT * 4));
+    unsigned voffx[NXO];
+#pragma unroll
+    for (int k = 0; k < NXO; ++k) {
+        const int L = (wave + 4 * k) * 1024 + lane * 16;
+        const int row = L / RB, slot = (L - row * RB) >> 4;
+        voffx[k] = (unsigned)(row * RB + (swz_slot(slot, row) << 4));
+    }
+    int off8[8];  // byte offset of logical chunk (2j + half) of this lane's tile row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
+    float* cs = reinterpret_cast<float*>(lds + CS0);
+    // publish: lanes l31 < 16 write their column sum to cs[buf][wave][frag_row(elem, half)], the others into the dump slot
+    const unsigned pub_addr = (unsigned)(l31 < 16 ? (wave * QT + frag_row(halving_elem16(l31), half)) * 4 : 2 * 4 * QT * 4 + lane * 4);
+    const unsigned pub_flip = l31 < 16 ? (unsigned)(4 * QT * 4) : 0u;      // the second buffer, for publishing lanes only
+    const unsigned st_voff = (unsigned)(lane * 16);
+
+    // ---- DMA cursor: item w + 3 ahead of the compute cursor after the prologue ----
+    int d_rb, d_mt, d_left;
+    {
+        int rb = 0;
+        while (fwd_prefix(wk, rb + 1) <= w) ++rb;
+        const int j0 = w - fwd_prefix(wk, rb);
+        d_rb = rb;
+        d_mt = TPR * rb + j0;
+        d_left = NT - d_mt;
+    }
+    int rb = d_rb, j = d_mt - TPR * d_rb;        // compute cursor: row block, tile inside its list (column tile = TPR rb + j)
+    unsigned dstage = 0;                          // LDS byte offset of the stage the next DMA fills
+    auto dma_tile = [&]() { return (unsigned)(d_mt < NT - 1 ? d_mt : NT - 1) * (unsigned)TILE; };
+    auto ring_next = [&](unsigned o) {            // next stage of the ring (a power of two of bytes except at DK = 24)
+        if constexpr ((NST * TILE & (NST * TILE - 1)) == 0) return (o + (unsigned)TILE) & (unsigned)(NST * TILE - 1);
+        else { const unsigned nx = o + (unsigned)TILE; return nx == (unsigned)(NST * TILE) ? 0u : nx; }
+    };
+    auto dma_advance = [&]() {
+        ++d_mt;
+        if (--d_left == 0) {
+            ++d_rb;
+            d_mt = TPR * d_rb;
+            d_left = NT - d_mt;
+            if (d_left <= 0) d_left = 1 << 30;   // past the last row block: clamped re-fetches of the last tile, never consumed
+        }
+        dstage = ring_next(dstage);
+    };
+    auto issue_piece = [&](int k, unsigned tile_off, unsigned stage_off) {
+        if (CROSSCLR_ZABL & 4) return;
+        lds_dma16_buf(rs_x, voffx[k], tile_off, lds + stage_off + (wave + 4 * k) * 1024);
+    };
+    // prologue: tiles of items w, w + 1, w + 2 into stages 0, 1, 2
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) {
+        const unsigned to = dma_tile();
+#pragma unroll
+        for (int k = 0; k < NXO; ++k) issue_piece(k, to, dstage);
+        dma_advance();
+    }
+
+    // ---- per-segment state ----
+    float rowacc[2] = {0.f, 0.f};
+    bf16x8 pf[2][DK];
+    int row0w = 0, rmod = 0;
+    unsigned st_soff[2] = {0u, 0u};               // stash byte offset of the CURRENT tile's records, per 32-row half
+    // ---- published column sums waiting for their flush ----
+    int pend = 0;                                 // 1: cs[pbuf] holds the sums of colpart row pend_soff
+    unsigned pbuf = 0, pend_soff = 0;
+    unsigned cstage = 0;                          // LDS byte offset of the current tile's stage
+    // first PF fragments of the CURRENT tile (read during the previous step / the prologue)
+    u32x4 nx0, nx1, nx2, nx3;
+
+    struct Bits8 { bf16_t v[8]; };
+    auto store_rows = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v = rowacc[s] + wave_xor_f32(rowacc[s], 32);
+            if (half == 0) part[(size_t)(vb - fwd_first_block(wk, rb)) * 2 * g.bpad + row0w + 32 * s + l31] = v;
+        }
+    };
+    // the flush of a pending publication OUTSIDE a step (segment end, kernel end): every wave adds, wave 0 stores
+    auto flush_now = [&]() {
+        if (pend && tid < QT) {
+            const float* c = cs + pbuf * (4 * QT);
+            buf_store4(rs_cp, (unsigned)(tid * 4), pend_soff, (c[tid] + c[QT + tid]) + (c[2 * QT + tid] + c[3 * QT + tid]));
+        }
+        pend = 0;
+    };
+    auto publish = [&](float colsum, unsigned soff) {
+        pbuf ^= 1u;
+        *reinterpret_cast<float*>(lds + CS0 + pub_addr + (pbuf ? pub_flip : 0u)) = colsum;
+        pend = 1;
+        pend_soff = soff;
+    };
+    auto stash_store = [&](const f32x16& e, int s, unsigned soff) {
+        if (!ST || (CROSSCLR_ZABL & 2)) return;
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            Bits8 pk;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pk.v[q] = f32_to_bf16_bits(e[8 * th + q]);
+            buf_store16(rs_st, st_voff + 1024u * th, soff, __builtin_bit_cast(u32x4, pk));
+        }
+    };
+    // plain (not overlapped) epilogue of the tile in `acc`: jt = its index in the row block's list, soff = its stash offsets
+    auto epilogue_plain = [&](f32x16 (&acc)[2], int jt) __attribute__((always_inline)) {
+        mfma_results_visible();
+        const int mt = TPR * rb + jt;
+        const float c2s = ((mt >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
+        const bool upper = jt >= TPR;
+        const float ninf = -__builtin_inff();
+        float es[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) es[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float xx[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xx[r] = acc[s][r] * c2s - g.m2;
+            if (jt == 2 * wave + s) {              // the tile that holds this half's self pairs
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (frag_row(r, half) == l31) xx[r] = ninf;
+            }
+            f32x16 e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = fast_exp2(xx[r]);
+            stash_store(e, s, st_soff[s] + 2048u * (unsigned)jt);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rowacc[s] += e[r]; es[r] += e[r]; }
+        }
+        if (upper) publish(halving_sum16(es, l31), (unsigned)((rb * NT + mt) * (QT * 4)));
+    };
+
+    // ---- one tile: 2 DK MFMAs into accC; MODE 1: the epilogue of the previous tile (accP, index jt - 1) in their shadow ----
+    auto step = [&](auto modec, f32x16 (&accC)[2], f32x16 (&accP)[2], int jt) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(modec)::value;
+        constexpr bool EPI = MODE == 1 && !(CROSSCLR_ZABL & 1);
+        const unsigned nstage = ring_next(cstage);
+        const auto xa = lds_addr(lds + cstage);
+        decltype(lds_addr(lds)) abase[8], anext[PF];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) abase[q] = xa + off8[q];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) anext[q] = lds_addr(lds + nstage) + off8[q];
+        u32x4 fr[DK];                                  // A fragments of k-steps PF .. DK-1 (indices < PF unused)
+        u32x4 nn[PF];                                  // first fragments of the next tile
+        fr[0] = nx0; fr[1] = nx1; fr[2] = nx2; fr[3] = nx3;
+        // the owed tile (MODE 1)
+        const int mtp = TPR * rb + jt - 1;
+        const float c2s = ((mtp >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
+        const unsigned so0 = st_soff[0] + 2048u * (unsigned)(jt - 1), so1 = st_soff[1] + 2048u * (unsigned)(jt - 1);
+        float es[16], k8[8], k4[4], k2[2];
+        // the pending publication (flushed behind this step's barrier)
+        const auto fa = lds_addr(lds + CS0 + (pbuf ? 4 * QT * 4 : 0) + l31 * 4);
+        const unsigned f_voff = (pend && wave == (jt & 3) && half == 0) ? (unsigned)(l31 * 4) : 0xFFFFFF00u;
+        const unsigned f_soff = pend_soff;
+        u32x2 f01, f23;
+        const unsigned d_to = dma_tile(), d_so = dstage;
+
+        auto issue_read = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if ((CROSSCLR_ZABL & 32)) {
+                if constexpr (q < DK - PF) fr[q + PF] = fr[(q + PF) & 3]; else nn[q - (DK - PF)] = fr[q - (DK - PF)];
+                return;
+            }
+            if constexpr (q < DK - PF) {
+                constexpr int kf = q + PF;
+                fr[kf] = lds_read_b128_async<(kf >> 3) * 256>(abase[kf & 7]);
+            } else {
+                constexpr int kn = q - (DK - PF);
+                nn[kn] = lds_read_b128_async<0>(anext[kn]);
+            }
+        };
+        auto chore = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            if constexpr (!EPI) return;
+            if constexpr (h < H1) {
+                // exp of element idx, then the row-sum add of element idx - 1 (a transcendental's result costs a wait state when it is used
+                // by the very next instruction; the adds keep their order r = 0 .. 15 per half: the same bits as the plain epilogue)
+#pragma unroll
+                for (int idx = (32 * h) / H1; idx < (32 * (h + 1)) / H1; ++idx) {
+                    const int s = idx >> 4, r = idx & 15;
+                    accP[s][r] = fast_exp2(accP[s][r] * c2s - g.m2);
+                    if (idx > 0) { rowacc[(idx - 1) >> 4] += accP[(idx - 1) >> 4][(idx - 1) & 15]; pin_v(rowacc[(idx - 1) >> 4]); }
+                }
+            } else if constexpr (h < H2) {
+                constexpr int n = H2 - H1, i = h - H1;
+                if constexpr (h == H1) { rowacc[1] += accP[1][15]; pin_v(rowacc[1]); }
+#pragma unroll
+                for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = accP[0][r] + accP[1][r];
+                if (ST && !(CROSSCLR_ZABL & 2)) {
+#pragma unroll
+                    for (int f = (4 * i) / n; f < (4 * (i + 1)) / n; ++f) {
+                        const int s = f >> 1, th = f & 1;
+                        Bits8 pk;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) pk.v[q] = f32_to_bf16_bits(accP[s][8 * th + q]);
+                        buf_store16(rs_st, st_voff + 1024u * th, s ? so1 : so0, __builtin_bit_cast(u32x4, pk));
+                    }
+                }
+            } else {
+                constexpr int n = H - H2, i = h - H2;
+                constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;     // units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: (publish: behind the loop)
+#pragma unroll
+                for (int u = lo; u < hi; ++u) {
+                    if (CROSSCLR_ZABL & 64) { if (u == 14) k2[0] = es[l31 & 15]; continue; }
+                    if (u < 8) {
+                        const bool up = (l31 >> 3) & 1;
+                        k8[u] = (up ? es[8 + u] : es[u]) + lane_xor<15>(up ? es[u] : es[8 + u]);
+                    } else if (u < 12) {
+                        const int q = u - 8;
+                        const bool up = (l31 >> 2) & 1;
+                        k4[q] = (up ? k8[4 + q] : k8[q]) + lane_xor<7>(up ? k8[q] : k8[4 + q]);
+                    } else if (u < 14) {
+                        const int q = u - 12;
+                        const bool up = (l31 >> 1) & 1;
+                        k2[q] = (up ? k4[2 + q] : k4[q]) + lane_xor<2>(up ? k4[q] : k4[2 + q]);
+                    } else if (u == 14) {
+                        const bool up = l31 & 1;
+                        const float k1 = (up ? k2[1] : k2[0]) + lane_xor<1>(up ? k2[0] : k2[1]);
+                        k2[0] = k1 + lane_xor<16>(k1);
+                    }
+                }
+            }
+        };
+
+        static_for<DK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // ---- head: the fragments of k-steps k and k + 1 are complete (one counted wait per two k-steps)
+            if constexpr (k >= PF && (k % 2 == 0)) {
+                constexpr int kl = k + 1 < DK ? k + 1 : k;
+                constexpr int keep_frag = FwdReadPlan::keep_for(DK, k, kl);
+                constexpr int keep_flush = FwdReadPlan::ops_before(DK, k) - FwdReadPlan::flush_seq(DK) - 1;    // (k = DK/2 + 2: the flush's reads too)
+                constexpr int keep = (k == KB + 2 && keep_flush < keep_frag) ? keep_flush : keep_frag;
+                static_assert(keep >= 0, "a wait cannot ask for an operation that has not been issued");
+                wait_lgkm_n<keep>();
+                after_wait(fr[k]);
+                if constexpr (k + 1 < DK) after_wait(fr[k + 1]);
+                if constexpr (k == KB + 2) { after_wait(f01); after_wait(f23); }
+            }
+            if constexpr (k == KB) {
+                // tile i + 1 has landed (only the NXO pieces of tile i + 2 may still be in flight) -- everywhere; everybody is done with tile i - 1
+                if (!(CROSSCLR_ZABL & 4)) wait_dma_keep<NXO>();
+                if (!(CROSSCLR_ZABL & 8)) barrier_only();
+                f01 = lds_read2_b32_async<0, QT>(fa);
+                f23 = lds_read2_b32_async<2 * QT, 3 * QT>(fa);
+            }
+            const bf16x8 a = __builtin_bit_cast(bf16x8, fr[k]);
+            if constexpr (k == 0) mfma_first_va(accC[0], a, pf[0][k]); else mfma_va(accC[0], a, pf[0][k]);
+            // ---- this k-step's fragment reads
+            static_for<DK>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if constexpr (FwdReadPlan::kstep_of(DK, q) == k) issue_read(qc);
+            });
+            if constexpr (k == KB + 2) {
+                // (whole-vector casts: clang mis-reads __builtin_bit_cast(float, v[1]) of an asm-written ext_vector element as v[0])
+                const f32x2 c01 = __builtin_bit_cast(f32x2, f01), c23 = __builtin_bit_cast(f32x2, f23);
+                buf_store4(rs_cp, f_voff, f_soff, (c01[0] + c01[1]) + (c23[0] + c23[1]));
+            }
+            chore(IdxC<2 * k>{});
+            sched_fence();
+            if constexpr (k == 0) mfma_first_va(accC[1], a, pf[1][k]); else mfma_va(accC[1], a, pf[1][k]);
+            if constexpr (k >= KB && k < KB + NXO) issue_piece(k - KB, d_to, d_so);
+            chore(IdxC<2 * k + 1>{});
+            sched_fence();
+        });
+        // every read of the step is complete (all were issued >= 4 k-steps ago): the next tile's first fragments may cross the back edge
+        wait_lgkm_n<0>();
+#pragma unroll
+        for (int q = 0; q < PF; ++q) after_wait(nn[q]);
+        nx0 = nn[0]; nx1 = nn[1]; nx2 = nn[2]; nx3 = nn[3];
+        pend = 0;
+        if constexpr (EPI) {
+            if (!(CROSSCLR_ZABL & 64)) publish(k2[0], (unsigned)((rb * NT + mtp) * (QT * 4)));
+        } else if constexpr (MODE == 1) {
+            rowacc[0] += accP[0][0] + accP[1][1];      // (ablation: keeps the previous tile's MFMAs alive)
+        }
+        dma_advance();
+        cstage = nstage;
+    };
+
+    f32x16 accA[2], accB[2];
+    timing_mark(1);
+    bool primed = false;
+    while (w < w_end) {
+        // ---- a segment: the tiles j .. j + n - 1 of row block rb ----
+        int n = NT - TPR * rb - j;
+        if (n > w_end - w) n = w_end - w;
+        w += n;
+        row0w = rb * RBLK + 64 * wave;
+        rmod = uniform(row0w / g.bpad);
+        rowacc[0] = rowacc[1] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (ST) st_soff[s] = (unsigned)(stash_tile_index(TPR, NT, TPR * rb + 2 * wave + s, TPR * rb) * 2048);
+            const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * 16) + 8 * half;
+#pragma unroll
+            for (int k = 0; k < DK; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
+        }
+        wait_loads_visible();
+        if (!primed) {
+            // the first tile of the range has landed everywhere; its first fragments
+            primed = true;
+            wait_dma();
+            barrier_only();
+            const auto xa = lds_addr(lds + cstage);
+            nx0 = lds_read_b128_async<0>(xa + off8[0]);
+            nx1 = lds_read_b128_async<0>(xa + off8[1]);
+            nx2 = lds_read_b128_async<0>(xa + off8[2]);
+            nx3 = lds_read_b128_async<0>(xa + off8[3]);
+            wait_lgkm_n<0>();
+            after_wait(nx0); after_wait(nx1); after_wait(nx2); after_wait(nx3);
+        }
+        // phase 1: masked tiles one by one, up to and including the first tile that can stay owed (set A)
+        bool owedA = false;
+        while (n > 0) {
+            step(IdxC<0>{}, accA, accB, j);
+            ++j; --n;
+            if (j - 1 < TPR) epilogue_plain(accA, j - 1);
+            else { owedA = true; break; }
+        }
+        // phase 2: pairs -- (B while A's epilogue runs), (A while B's epilogue runs)
+        bool owedB = false;
+        while (n > 0) {
+            step(IdxC<1>{}, accB, accA, j);
+            ++j; --n;
+            if (n == 0) { owedA = false; owedB = true; break; }
+            step(IdxC<1>{}, accA, accB, j);
+            ++j; --n;
+        }
+        // the segment's last tile: an earlier publication may still wait for its barrier -- flush it, then finish the tile in the open
+        if (owedA || owedB) {
+            wait_lgkm_n<0>();
+            barrier_only();
+            flush_now();
+            if (owedA) epilogue_plain(accA, j - 1); else epilogue_plain(accB, j - 1);
+        }
+        store_rows();
+        ++rb;
+        j = 0;
+    }
+    timing_mark(2);
+    wait_dma();      // (the clamped re-fetches past the end of the work list)
+    __syncthreads();
+    flush_now();
+    timing_mark(3);
+}
+
+}  // namespace crossclr

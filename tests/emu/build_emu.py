@@ -18,7 +18,7 @@ def sources():
            [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "emu_runtime.cpp")]
 
 
-UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_saved_wide.cpp", "tu_recomp.cpp"]
+UNITS = ["crossclr_api.cpp", "tu_fwd.cpp", "tu_fwdp.cpp", "tu_saved_lds.cpp", "tu_saved_xf1.cpp", "tu_saved_xfp.cpp", "tu_saved_wide.cpp", "tu_recomp.cpp"]
 
 
 def build(force=False):

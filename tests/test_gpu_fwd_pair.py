@@ -1,0 +1,60 @@
+"""GPU tests: fast_fwd_pair_kernel (csrc/crossclr_kernels_symp.h: the symmetric forward with one unbroken MFMA stream per wave) against
+fast_fwd_pipe_kernel, the kernel it replaces for whole batches -- same work list, same summation order: loss, saved exponentials and
+gradients BIT FOR BIT, launch after launch (hand-counted lgkmcnt / vmcnt waits, the mid-tile barrier, asm MFMAs with VGPR accumulators:
+everything the host emulation cannot see).  Reference goldens: tests/test_gpu_parity.py runs them through this kernel by default."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(crit, v, t, grad=True):
+    if not grad:
+        with torch.no_grad():
+            return crit(v, t).item(), None, None
+    vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    loss = crit(vv, tt)
+    loss.backward()
+    return loss.item(), vv.grad.clone(), tt.grad.clone()
+
+
+SHAPES = [(128, 128), (256, 100), (384, 256), (512, 384), (1024, 512), (1152, 200), (2048, 512), (4096, 384), (8192, 512), (3200, 512)]
+
+
+@pytest.mark.parametrize("B,D", SHAPES)
+def test_pair_forward_is_bit_identical_to_the_pipe_forward(B, D, monkeypatch):
+    import crossclr_amd
+    from crossclr_amd import _native as nat
+    assert nat.backend() == "hip-gfx950"
+    g = torch.Generator().manual_seed(B + D)
+    v = torch.randn(B, D, generator=g).cuda()
+    t = (0.6 * v.cpu() + torch.randn(B, D, generator=g)).cuda()       # correlated pairs: exponentials of mixed magnitude
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.8, compute_mode="bf16").cuda()
+    monkeypatch.setenv("CROSSCLR_FWD_PAIR", "0")
+    lo, gvo, gto = _step(crit, v, t)
+    lfo, _, _ = _step(crit, v, t, grad=False)
+    monkeypatch.delenv("CROSSCLR_FWD_PAIR")
+    for rep in range(4):
+        ln, gvn, gtn = _step(crit, v, t)
+        assert ln == lo, (rep, ln, lo)
+        assert torch.equal(gvn, gvo) and torch.equal(gtn, gto), rep
+        lfn, _, _ = _step(crit, v, t, grad=False)
+        assert lfn == lfo
+    torch.cuda.synchronize()
+
+
+def test_pair_forward_many_launches_headline_shape():
+    """BASELINE config 3's shape, 200 steps: every loss and every gradient identical to the first."""
+    import crossclr_amd
+    g = torch.Generator().manual_seed(1234)
+    v, t = torch.randn(8192, 512, generator=g).cuda(), torch.randn(8192, 512, generator=g).cuda()
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()
+    l0, gv0, gt0 = _step(crit, v, t)
+    bad = 0
+    for _ in range(200):
+        l, gv, gt = _step(crit, v, t)
+        bad += int(l != l0) + int(not torch.equal(gv, gv0)) + int(not torch.equal(gt, gt0))
+    assert bad == 0
+    assert abs(l0 - 10.627098744839678) <= 1e-3        # tests/golden/index.json: g7_b8192_d512_s1234
