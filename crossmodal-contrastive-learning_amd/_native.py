@@ -19,7 +19,7 @@ HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcro
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
-ABI_VERSION = 5
+ABI_VERSION = 6
 LAUNCH_GROUPS = 8      # CROSSCLR_LAUNCH_GROUPS of include/crossclr.h
 
 
@@ -37,6 +37,18 @@ class Plan(ctypes.Structure):
 class SampleWeights(ctypes.Structure):
     """crossclr_sample_weights: device pointers (0 = all ones)."""
     _fields_ = [("neg_scale_rows", ctypes.c_void_p), ("neg_scale_cols", ctypes.c_void_p), ("loss_weight", ctypes.c_void_p)]
+
+
+class StepLayout(ctypes.Structure):
+    """crossclr_step_layout: what crossclr_step_plan decided for one step and where the pieces live in its workspace."""
+    _fields_ = [("total_bytes", ctypes.c_size_t), ("backward_scratch_bytes", ctypes.c_size_t)] + \
+               [(n, ctypes.c_size_t) for n in ("xhat", "inv_norm", "diag", "logz", "rz", "wrz", "part", "shift", "xf", "stash", "ticket")] + \
+               [("stash_bytes", ctypes.c_size_t), ("xf_bytes", ctypes.c_size_t),
+                ("two_pass", ctypes.c_int), ("saved", ctypes.c_int), ("backward_kernel", ctypes.c_int)]
+
+
+STEP_NO_SAVE, STEP_FORWARD_ONLY, STEP_PRENORMALIZED, STEP_NO_XFP, STEP_NO_XF = 1, 2, 4, 8, 16
+STEP_NONE = ctypes.c_size_t(-1).value
 
 
 class CrossCLRNativeError(RuntimeError):
@@ -151,6 +163,14 @@ _SIGNATURES = {
     "crossclr_maxmargin_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P]),
     "crossclr_maxmargin_backward_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                                           _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P]),
+    # ABI version 6: the whole single-device step behind two calls (the kernel-selection policy lives in the library)
+    "crossclr_step_plan": (ctypes.c_int, [ctypes.POINTER(Plan), ctypes.c_float, ctypes.c_float, ctypes.c_uint, ctypes.c_size_t,
+                                          ctypes.POINTER(StepLayout)]),
+    "crossclr_step_forward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_float,
+                                             ctypes.c_float, ctypes.POINTER(SampleWeights), ctypes.c_uint, _P, ctypes.c_size_t, _P, _P]),
+    "crossclr_step_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_float,
+                                              ctypes.c_float, ctypes.POINTER(SampleWeights), ctypes.c_uint, _P, ctypes.c_size_t, _P, _P, _P, _P,
+                                              ctypes.c_long, ctypes.c_long, _P]),
     # measurement aid (bench.py: the matrix pipe's sustained rate on this device, in the run that quotes it)
     "crossclr_mfma_sustained": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, _P]),
 }

@@ -293,28 +293,28 @@ static int make_geo(const crossclr_plan* p, int col_ranks, int col_rank0, int sk
 // ------------------------------------------------------------------------------------------------
 template <typename TIN, bool NORM>
 static int normalize_t(const crossclr_plan* p, const void* v, const void* t, long ldv, long ldt, void* xhat,
-                       float* inv_norm, float* diag, void* stream) {
+                       float* inv_norm, float* diag, void* stream, int* zero_word) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     dim3 grid((p->bpad + 3) / 4), block(256);
     if (p->mode == CROSSCLR_MODE_FP32)
         LAUNCH((normalize_kernel<TIN, float, NORM>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
-               (float*)xhat, inv_norm, diag);
+               (float*)xhat, inv_norm, diag, zero_word);
     else
         LAUNCH((normalize_kernel<TIN, bf16_t, NORM>), grid, block, stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
-               (bf16_t*)xhat, inv_norm, diag);
+               (bf16_t*)xhat, inv_norm, diag, zero_word);
     return launch_status("normalize_kernel");
 }
 template <bool NORM>
 static int normalize_any(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
-                         void* xhat, float* inv_norm, float* diag_cos, void* stream) {
+                         void* xhat, float* inv_norm, float* diag_cos, void* stream, int* zero_word = nullptr) {
     if (!plan || !video || !text || !xhat || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
     if (ld_video < plan->D || ld_text < plan->D) return fail(CROSSCLR_E_ARG, "row stride smaller than D");
     switch (in_dtype) {
-        case CROSSCLR_IN_F32: return normalize_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F64: return normalize_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F16: return normalize_t<in_f16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_BF16: return normalize_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F32: return normalize_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream, zero_word);
+        case CROSSCLR_IN_F64: return normalize_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream, zero_word);
+        case CROSSCLR_IN_F16: return normalize_t<in_f16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream, zero_word);
+        case CROSSCLR_IN_BF16: return normalize_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, inv_norm, diag_cos, stream, zero_word);
     }
     return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
 }
@@ -322,21 +322,21 @@ static int normalize_any(const crossclr_plan* plan, const void* video, const voi
 #ifndef CROSSCLR_NO_FAST
 template <typename TIN, bool NORM>
 static int normalize_xf_t(const crossclr_plan* p, const void* v, const void* t, long ldv, long ldt, void* xhat, void* xf,
-                          float* inv_norm, float* diag, void* stream) {
+                          float* inv_norm, float* diag, void* stream, int* zero_word) {
     Geo g; memset(&g, 0, sizeof(g));
     g.b = p->b; g.bpad = p->bpad; g.D = p->D; g.Dpad = p->Dpad;
     if (p->Dpad <= 512)
         LAUNCH((normalize_xf_kernel<TIN, NORM, 2>), dim3(p->bpad / 16), dim3(512), stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
-               (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag);
+               (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag, zero_word);
     else
         LAUNCH((normalize_xf_kernel<TIN, NORM, 4>), dim3(p->bpad / 16), dim3(512), stream, (const TIN*)v, (const TIN*)t, ldv, ldt, g,
-               (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag);
+               (bf16_t*)xhat, (unsigned char*)xf, inv_norm, diag, zero_word);
     return launch_status("normalize_xf_kernel");
 }
 #endif
 template <bool NORM>
 static int normalize_xf_any(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
-                            void* xhat, void* xf, float* inv_norm, float* diag_cos, void* stream) {
+                            void* xhat, void* xf, float* inv_norm, float* diag_cos, void* stream, int* zero_word = nullptr) {
     if (!plan || !video || !text || !xhat || !xf || !inv_norm || !diag_cos) return fail(CROSSCLR_E_ARG, "NULL argument");
     if (ld_video < plan->D || ld_text < plan->D) return fail(CROSSCLR_E_ARG, "row stride smaller than D");
 #ifdef CROSSCLR_NO_FAST
@@ -344,14 +344,14 @@ static int normalize_xf_any(const crossclr_plan* plan, const void* video, const 
 #else
     if (!plan->xf_bytes) return fail(CROSSCLR_E_ARG, "this plan has no fragment-major operand (xf_bytes == 0): use crossclr_normalize / crossclr_pack");
     if (plan->Dpad > 1024) {   // wide plans: the row kernel, then the packed rows re-laid fragment-major (1024 columns of a 32-row tile per block)
-        if (int rc = normalize_any<NORM>(plan, video, text, ld_video, ld_text, in_dtype, xhat, inv_norm, diag_cos, stream)) return rc;
+        if (int rc = normalize_any<NORM>(plan, video, text, ld_video, ld_text, in_dtype, xhat, inv_norm, diag_cos, stream, zero_word)) return rc;
         return crossclr_pack_xf_from_packed(plan, xhat, 1, xf, stream);
     }
     switch (in_dtype) {
-        case CROSSCLR_IN_F32: return normalize_xf_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F64: return normalize_xf_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_F16: return normalize_xf_t<in_f16, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
-        case CROSSCLR_IN_BF16: return normalize_xf_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream);
+        case CROSSCLR_IN_F32: return normalize_xf_t<float, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream, zero_word);
+        case CROSSCLR_IN_F64: return normalize_xf_t<double, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream, zero_word);
+        case CROSSCLR_IN_F16: return normalize_xf_t<in_f16, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream, zero_word);
+        case CROSSCLR_IN_BF16: return normalize_xf_t<in_bf16, NORM>(plan, video, text, ld_video, ld_text, xhat, xf, inv_norm, diag_cos, stream, zero_word);
     }
     return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
 #endif
@@ -807,10 +807,21 @@ extern "C" int crossclr_forward_finish_w(const crossclr_plan* plan, const float*
                                      stream);
 }
 
+static int forward_finish_impl(const crossclr_plan* plan, const float* part, int nslots,
+                               const float* diag_cos, float temperature, float negative_weight,
+                               const crossclr_sample_weights* sw, const float* shift_rows, float* logz, float* rz,
+                               float* wrz, double* loss_sum, void* stream, int* ticket);
 extern "C" int crossclr_forward_finish_s(const crossclr_plan* plan, const float* part, int nslots,
                                          const float* diag_cos, float temperature, float negative_weight,
                                          const crossclr_sample_weights* sw, const float* shift_rows, float* logz, float* rz,
                                          float* wrz, double* loss_sum, void* stream) {
+    return forward_finish_impl(plan, part, nslots, diag_cos, temperature, negative_weight, sw, shift_rows, logz, rz, wrz, loss_sum, stream, nullptr);
+}
+// ticket != NULL (crossclr_step_forward; an int the step's first kernel has cleared): the finish kernel's last block forms the sum -- one launch
+static int forward_finish_impl(const crossclr_plan* plan, const float* part, int nslots,
+                               const float* diag_cos, float temperature, float negative_weight,
+                               const crossclr_sample_weights* sw, const float* shift_rows, float* logz, float* rz,
+                               float* wrz, double* loss_sum, void* stream, int* ticket) {
     if (!plan || !part || !diag_cos || !logz || !rz || !wrz || !loss_sum || plan->fwd_slots <= 0 || nslots <= 0 ||
         nslots % plan->fwd_slots != 0 || nslots / plan->fwd_slots > kLaunchGroups)
         return fail(CROSSCLR_E_ARG, "NULL argument / nslots must be fwd_slots times the number of launch groups (1..%d)", kLaunchGroups);
@@ -824,8 +835,8 @@ extern "C" int crossclr_forward_finish_s(const crossclr_plan* plan, const float*
     LAUNCH(fwd_finish_kernel, dim3(nb), dim3(256), stream, part, nlaunch, plan->fwd_slots, g, diag_cos, 1.0f / temperature,
            negative_weight, logz, rz, wrz, loss_sum, part + ws_colpart_off(plan),
            reinterpret_cast<const int*>(part + ws_flag_off(plan)), sw ? sw->neg_scale_rows : nullptr,
-           sw ? sw->loss_weight : nullptr, shift_rows);
-    LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb, 1.0 / (2.0 * (double)plan->b * (double)plan->world));
+           sw ? sw->loss_weight : nullptr, shift_rows, ticket, 1.0 / (2.0 * (double)plan->b * (double)plan->world));
+    if (!ticket) LAUNCH(fwd_finish_reduce_kernel, dim3(1), dim3(64), stream, loss_sum, nb, 1.0 / (2.0 * (double)plan->b * (double)plan->world));
     return launch_status("fwd_finish_kernel");
 }
 
@@ -1668,6 +1679,175 @@ __global__ void __launch_bounds__(256, 1) mfma_sustained_kernel(float* out, int 
 }
 #endif
 }  // namespace crossclr
+
+// ------------------------------------------------------------------------------------------------
+// The whole step behind two calls (include/crossclr.h, ABI 6): the kernel-selection policy that used to live in the Python module.
+// Composition of the entry points above; every decision is a pure function of (plan, temperature, negative_weight, flags, workspace_bytes).
+static size_t step_max_stash_bytes() {
+    const char* e = getenv("CROSSCLR_MAX_STASH_GB");
+    const double gb = e ? atof(e) : 8.0;
+    return (size_t)(gb * (double)((size_t)1 << 30));
+}
+// Padded widths at which the fragment-major saved backward beats the LDS-staged one (profiles/r03_xf_widths.txt: wins from 512 up, ties at
+// 384, loses at 256 / 128), with the row floor below which crossclr_normalize_xf's second copy is not paid back; CROSSCLR_XF_WIDTHS="128,256"
+// (or "") overrides the widths and drops the floor (tuning / tests)
+static bool step_use_xf(const crossclr_plan* p) {
+    const char* e = getenv("CROSSCLR_XF_WIDTHS");
+    if (!e) {
+        static const int widths[] = {512, 768, 1024, 1152, 1536, 2048, 2560, 3072, 4096};
+        bool in = false;
+        for (int w : widths) in = in || p->Dpad == w;
+        return in && p->bpad >= (p->Dpad <= 512 ? 2048 : 4096);
+    }
+    for (const char* c = e; *c;) {
+        char* end;
+        const long w = strtol(c, &end, 10);
+        if (end == c) { ++c; continue; }
+        if (w == p->Dpad) return true;
+        c = end;
+    }
+    return false;
+}
+static size_t step_align(size_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" int crossclr_step_plan(const crossclr_plan* plan, float temperature, float negative_weight, unsigned flags,
+                                  size_t workspace_bytes, crossclr_step_layout* L) {
+    if (!plan || !L) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (plan->world != 1) return fail(CROSSCLR_E_ARG, "crossclr_step_* is the single-device step (plan->world == 1); sharded runs compose the fine-grained entry points around their collectives");
+    if (!(temperature > 0.f) || !isfinite(temperature) || !isfinite(negative_weight)) return fail(CROSSCLR_E_ARG, "temperature must be > 0 and finite, negative_weight finite");
+    const bool two_pass = needs_row_shift(temperature, negative_weight);
+    const bool may_save = !(flags & (CROSSCLR_STEP_NO_SAVE | CROSSCLR_STEP_FORWARD_ONLY));
+    const size_t stash_full = two_pass ? crossclr_stash_bytes_s(plan) : plan->stash_bytes;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool saved = attempt == 0 && may_save && stash_full > 0 && stash_full <= step_max_stash_bytes();
+        if (attempt == 0 && !saved) continue;
+        const bool xf = saved && !two_pass && plan->xf_bytes > 0 && step_use_xf(plan);
+        memset(L, 0, sizeof(*L));
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += step_align(bytes); return o; };
+        const size_t n2 = (size_t)2 * plan->bpad;
+        L->xhat = take(plan->operand_bytes);
+        L->inv_norm = take(4 * n2);
+        L->diag = take(4 * (size_t)plan->bpad);
+        L->logz = take(4 * n2);
+        L->rz = take(4 * n2);
+        L->wrz = take(4 * n2);
+        L->part = take(4 * plan->fwd_ws_floats);
+        L->ticket = take(4);
+        L->shift = two_pass ? take(4 * n2) : CROSSCLR_STEP_NONE;
+        L->xf = xf ? take(plan->xf_bytes) : CROSSCLR_STEP_NONE;
+        L->stash = saved ? take(stash_full) : CROSSCLR_STEP_NONE;
+        L->xf_bytes = xf ? plan->xf_bytes : 0;
+        L->stash_bytes = saved ? stash_full : 0;
+        L->total_bytes = off;
+        L->backward_scratch_bytes = (flags & CROSSCLR_STEP_FORWARD_ONLY) ? 0 : plan->gbuf_bytes;
+        L->two_pass = two_pass ? 1 : 0;
+        L->saved = saved ? 1 : 0;
+        L->backward_kernel = 0;
+        if (saved) {
+            L->backward_kernel = 1;
+            if (xf) {
+                const char* e = getenv("CROSSCLR_XFP");
+                const bool xfp_ok = plan->stash_bytes < ((size_t)1 << 32) && !(e && e[0] == '0') && !(flags & CROSSCLR_STEP_NO_XFP);
+                const bool xf1_ok = plan->Dpad <= 1024 && !(flags & CROSSCLR_STEP_NO_XF);     // (wide plans: the pair kernel or the LDS-staged one)
+                L->backward_kernel = xfp_ok ? 3 : (xf1_ok ? 2 : 1);
+            }
+        }
+        if (workspace_bytes == 0 || off <= workspace_bytes) return CROSSCLR_OK;
+    }
+    return fail(CROSSCLR_E_WORKSPACE, "workspace of %zu bytes is below the recomputing layout's %zu", workspace_bytes, L->total_bytes);
+}
+
+namespace {
+struct StepBufs {
+    crossclr_step_layout L;
+    unsigned char* w;
+    void* xhat() const { return w + L.xhat; }
+    float* f(size_t off) const { return off == CROSSCLR_STEP_NONE ? nullptr : reinterpret_cast<float*>(w + off); }
+    void* v(size_t off) const { return off == CROSSCLR_STEP_NONE ? nullptr : static_cast<void*>(w + off); }
+};
+}  // namespace
+
+extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                                     float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
+                                     void* workspace, size_t workspace_bytes, double* loss_ws, void* stream) {
+    if (!workspace || !loss_ws || !video || !text) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (workspace_bytes == 0) return fail(CROSSCLR_E_WORKSPACE, "workspace_bytes must be the size of the buffer (crossclr_step_plan reports what is needed)");
+    StepBufs B;
+    if (int rc = crossclr_step_plan(plan, temperature, negative_weight, flags, workspace_bytes, &B.L)) return rc;
+    B.w = static_cast<unsigned char*>(workspace);
+    const crossclr_step_layout& L = B.L;
+    const float* k = sw ? sw->neg_scale_rows : nullptr;
+    const float* lw = sw ? sw->loss_weight : nullptr;
+    const crossclr_sample_weights sw_k = {k, k, nullptr}, sw_klw = {k, k, lw};
+    const crossclr_sample_weights* pk = k ? &sw_k : nullptr;
+    const crossclr_sample_weights* pklw = (k || lw) ? &sw_klw : nullptr;
+    const bool pre = (flags & CROSSCLR_STEP_PRENORMALIZED) != 0;
+    int rc;
+    // loss.py:79-80 (+ the packed operand, 1 / ||x||, the positive pairs' cosines; with a fragment-major saved backward to follow: its operand copy)
+    int* ticket = reinterpret_cast<int*>(B.w + L.ticket);      // cleared by this first kernel, taken by the finish kernel's blocks
+    if (L.xf != CROSSCLR_STEP_NONE)
+        rc = pre ? normalize_xf_any<false>(plan, video, text, ld_video, ld_text, in_dtype, B.xhat(), B.v(L.xf), B.f(L.inv_norm), B.f(L.diag), stream, ticket)
+                 : normalize_xf_any<true>(plan, video, text, ld_video, ld_text, in_dtype, B.xhat(), B.v(L.xf), B.f(L.inv_norm), B.f(L.diag), stream, ticket);
+    else
+        rc = pre ? normalize_any<false>(plan, video, text, ld_video, ld_text, in_dtype, B.xhat(), B.f(L.inv_norm), B.f(L.diag), stream, ticket)
+                 : normalize_any<true>(plan, video, text, ld_video, ld_text, in_dtype, B.xhat(), B.f(L.inv_norm), B.f(L.diag), stream, ticket);
+    if (rc) return rc;
+    if (L.two_pass) {      // loss.py:60's float64 soft-max takes the row maximum; so do these: row maxima, then sums relative to them
+        rc = crossclr_forward_rowmax(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, pk, B.f(L.part), B.f(L.shift), 0, stream);
+        if (rc) return rc;
+        rc = L.saved ? crossclr_forward_save_s(plan, B.xhat(), temperature, negative_weight, pk, B.f(L.shift), B.f(L.part), 0, B.v(L.stash), stream)
+                     : crossclr_forward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, pk, B.f(L.shift), B.f(L.part), 0, stream);
+        if (rc) return rc;
+        return forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, B.f(L.shift),
+                                   B.f(L.logz), B.f(L.rz), B.f(L.wrz), loss_ws, stream, ticket);
+    }
+    // loss.py:83-100, 59-60: soft-max denominators of the local block (and, saving, its exponentials)
+    rc = L.saved ? crossclr_forward_save(plan, B.xhat(), temperature, negative_weight, pk, B.f(L.part), 0, B.v(L.stash), stream)
+                 : crossclr_forward_w(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, pk, B.f(L.part), 0, stream);
+    if (rc) return rc;
+    // loss.py:60 (-log), :111-114
+    return forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, nullptr, B.f(L.logz), B.f(L.rz),
+                               B.f(L.wrz), loss_ws, stream, ticket);
+}
+
+extern "C" int crossclr_step_backward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                                      float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
+                                      void* workspace, size_t workspace_bytes, void* scratch, const double* grad_out,
+                                      void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext, void* stream) {
+    if (!workspace || !scratch || !video || !text || !grad_out || !grad_video || !grad_text) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (flags & CROSSCLR_STEP_FORWARD_ONLY) return fail(CROSSCLR_E_ARG, "the forward of this step was declared CROSSCLR_STEP_FORWARD_ONLY");
+    if (workspace_bytes == 0) return fail(CROSSCLR_E_WORKSPACE, "workspace_bytes must be the size given to crossclr_step_forward");
+    StepBufs B;
+    if (int rc = crossclr_step_plan(plan, temperature, negative_weight, flags, workspace_bytes, &B.L)) return rc;
+    B.w = static_cast<unsigned char*>(workspace);
+    const crossclr_step_layout& L = B.L;
+    const float* k = sw ? sw->neg_scale_rows : nullptr;
+    const float* lw = sw ? sw->loss_weight : nullptr;
+    const crossclr_sample_weights sw_k = {k, k, nullptr}, sw_lw = {nullptr, nullptr, lw};
+    const crossclr_sample_weights* pk = k ? &sw_k : nullptr;
+    float* gbuf = static_cast<float*>(scratch);
+    float *rz = B.f(L.rz), *wrz = B.f(L.wrz);
+    int rc;
+    // autograd of loss.py:83-112: gbuf = d(loss)/d(unit rows), unscaled, in column slices
+    if (L.two_pass) {
+        rc = L.saved ? crossclr_backward_saved_s(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream)
+                     : crossclr_backward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk,
+                                           B.f(L.shift), B.f(L.shift), gbuf, 0, stream);
+    } else if (L.saved) {
+        switch (L.backward_kernel) {
+            case 3: rc = crossclr_backward_saved_xfp(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream); break;
+            case 2: rc = crossclr_backward_saved_xf(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream); break;
+            default: rc = crossclr_backward_saved(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream); break;
+        }
+    } else {
+        rc = crossclr_backward_w(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk, gbuf, 0, stream);
+    }
+    if (rc) return rc;
+    // autograd of loss.py:79-80 + the positive-pair term, x grad_out, in the input dtype
+    return crossclr_backward_finish_p(plan, gbuf, video, text, ld_video, ld_text, in_dtype, B.f(L.inv_norm), temperature, lw ? &sw_lw : nullptr, grad_out,
+                                      grad_video, grad_text, ld_gvideo, ld_gtext, (flags & CROSSCLR_STEP_PRENORMALIZED) ? 1 : 0, stream);
+}
 
 extern "C" int crossclr_mfma_sustained(float* out, int blocks, int iters, unsigned seed, int zero_operands, void* stream) {
 #ifndef CROSSCLR_EMU

@@ -97,7 +97,9 @@ __device__ __forceinline__ void op_store4(bf16_t* row, int d, const float (&v)[4
 // cast / laid out into the packed operand, inv_norm = 1, and the positive-pair cosine is still formed in fp32 here.
 template <typename TIN, typename T, bool NORM = true>
 __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const TIN* text, long ldv, long ldt,
-                                                        Geo g, T* X, float* inv_norm, float* diag_cos) {
+                                                        Geo g, T* X, float* inv_norm, float* diag_cos, int* zero_word) {
+    // (crossclr_step_forward: the step's first kernel clears the ticket its finish kernel's last block is found with)
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= g.bpad) return;
@@ -172,8 +174,9 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* video, const 
 // +16 MiB written at B = 8192, D = 512.
 template <typename TIN, bool NORM, int KC>
 __global__ void __launch_bounds__(512) normalize_xf_kernel(const TIN* video, const TIN* text, long ldv, long ldt, Geo g, bf16_t* X,
-                                                           unsigned char* XF, float* inv_norm, float* diag_cos) {
+                                                           unsigned char* XF, float* inv_norm, float* diag_cos, int* zero_word) {
     CROSSCLR_SHARED __attribute__((aligned(16))) bf16_t sh[2][16][256 * KC];
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 16;
 #pragma unroll
@@ -642,8 +645,9 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
                                                          const float* diag_cos, float inv_tau, float neg_w, float* logz,
                                                          float* rz, float* wrz, double* loss_ws, const float* colpart,
                                                          const int* header, const float* krows, const float* lw,
-                                                         const float* row_shift) {
+                                                         const float* row_shift, int* ticket, double scale) {
     CROSSCLR_SHARED double red[4];
+    CROSSCLR_SHARED int last_block;
     const int n = 2 * g.bpad;
     double acc = 0.0;
     // FOUR lanes per row: lane q of a quad adds the terms k = q, q + 4, ... (independent loads, up to 16 rows of column sums and a
@@ -695,6 +699,22 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) loss_ws[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (ticket == nullptr) return;      // (crossclr_forward_finish*: fwd_finish_reduce_kernel adds the block partials up)
+    // crossclr_step_forward: the block that arrives LAST adds the partials up itself -- the same 64 lanes, strides and shuffle order as
+    // fwd_finish_reduce_kernel, hence the same bits -- and clears the ticket for whoever uses this workspace next.  Partials travel
+    // through agent-scope release (fence + atomic) / acquire (atomic + fence): the XCDs' L2s are not coherent with each other.
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last_block = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_block || threadIdx.x >= 64) return;
+    __threadfence();
+    const int nblocks = (int)gridDim.x;
+    double tot = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 64) tot += __builtin_nontemporal_load(&loss_ws[1 + k]);
+    tot = wave_sum_f64(tot);
+    if (threadIdx.x == 0) { loss_ws[0] = tot; if (nblocks >= 1) loss_ws[1] = tot * scale; *ticket = 0; }
 }
 // pairs exchange (sharded forward): out[c] = sum over row blocks of the column sums a kind-3 launch left in colpart
 __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* colpart, int nrb, int ncols, float* out) {

@@ -37,6 +37,20 @@ namespace crossclr {
                           // bit3 no barrier, bit4 no MFMA, bit5 no fragment reads after the first tile, bit6 no butterfly
 #endif
 
+#ifndef CROSSCLR_ZPF
+#define CROSSCLR_ZPF 4    // A fragments in flight ahead of their MFMA pair (k-steps); the first ZPF fragments of a tile are read during the previous tile
+#endif
+#ifndef CROSSCLR_ZW
+#define CROSSCLR_ZW 2     // k-steps per counted LDS wait (2: one wait covers the fragments of k-steps k and k + 1; 1: a wait per k-step)
+#endif
+#ifndef CROSSCLR_ZKB
+#define CROSSCLR_ZKB -1   // the k-step in front of which the tile's barrier sits (even; -1: DK / 2).  Measured (profiles/r05c_ab_fwdp.txt): the barrier
+                          // at k-step 2 with the DMA pieces spread over every second k-step behind it is not faster (0.130 vs 0.127 ms without save)
+#endif
+#ifndef CROSSCLR_ZLAG
+#define CROSSCLR_ZLAG 1   // column-sum butterfly: the DPP add of unit u - 1 behind the selects of unit u (no s_nop between a select and its DPP reader)
+#endif
+
 #ifndef CROSSCLR_EMU
 // accumulators in VGPRs (the epilogue reads them with plain VALU), B fragments in AGPRs (256 of them: the whole accumulation-register half)
 __device__ __forceinline__ void mfma_first_va(f32x16& acc, bf16x8 a, bf16x8 b) {
@@ -81,18 +95,19 @@ template <int OFF0, int OFF1> __device__ __forceinline__ u32x2 lds_read2_b32_asy
 // Read q = 0 .. DK-1 of a step: q < DK - PF fetches the A fragment of k-step q + PF of THIS tile, the last PF ones the fragments of k-steps
 // 0 .. PF-1 of the NEXT tile.  One read per k-step up to k-step DK - 9, two per k-step in k-steps DK - 8 .. DK - 5, none in the last four.
 struct FwdReadPlan {
-    static constexpr int PF = 4;
+    static constexpr int PF = CROSSCLR_ZPF;
+    static constexpr int kb(int DK) { return CROSSCLR_ZKB < 0 ? DK / 2 : CROSSCLR_ZKB; }
     static constexpr int kstep_of(int DK, int q) { return q < DK - 8 ? q : (DK - 8) + (q - (DK - 8)) / 2; }
     static constexpr int reads_before(int DK, int k) {        // reads issued in k-steps < k
         return k <= DK - 8 ? k : ((DK - 8) + 2 * (k - (DK - 8)) < DK ? (DK - 8) + 2 * (k - (DK - 8)) : DK);
     }
-    // LDS operations issued before the wait at the head of k-step k (the flush's two reads go out at the head of k-step DK / 2)
-    static constexpr int ops_before(int DK, int k) { return reads_before(DK, k) + (k > DK / 2 ? 2 : 0); }
-    static constexpr int seq_of(int DK, int q) { return q + (kstep_of(DK, q) >= DK / 2 ? 2 : 0); }
+    // LDS operations issued before the wait at the head of k-step k (the flush's two reads go out at the head of k-step KB, behind its wait)
+    static constexpr int ops_before(int DK, int k) { return reads_before(DK, k) + (k > kb(DK) ? 2 : 0); }
+    static constexpr int seq_of(int DK, int q) { return q + (kstep_of(DK, q) >= kb(DK) ? 2 : 0); }
     // younger operations that may stay in flight when fragment k' (k' >= PF) of this tile is needed at the head of k-step k <= k'
     static constexpr int keep_for(int DK, int k, int kfrag) { return ops_before(DK, k) - seq_of(DK, kfrag - PF) - 1; }
-    // the flush's second read is consumed in k-step DK / 2 + 2, behind that k-step's wait
-    static constexpr int flush_seq(int DK) { return reads_before(DK, DK / 2) + 1; }
+    // the flush's second read is consumed in k-step KB + 2, behind that k-step's wait
+    static constexpr int flush_seq(int DK) { return reads_before(DK, kb(DK)) + 1; }
 };
 
 template <int DK, bool ST>
@@ -107,7 +122,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     constexpr int NXO = DK / 4;            // DMA pieces per wave and tile
     constexpr int PF = FwdReadPlan::PF;
     constexpr int H = 2 * DK, H1 = H / 2, H2 = 3 * H / 4;     // MFMA slots of a tile: exp + row sums | sums of halves, pack, stash | butterfly
-    constexpr int KB = DK / 2;             // the k-step the barrier sits in front of
+    constexpr int KB = FwdReadPlan::kb(DK);      // the k-step the barrier sits in front of
+    // DMA pieces behind the barrier: every second k-step from KB + 1 on where that fits, else one per k-step from KB on
+    constexpr int DSTRIDE = (KB + 1 + 2 * (NXO - 1) < DK) ? 2 : 1, DK0 = DSTRIDE == 2 ? KB + 1 : KB;
+    static_assert(KB % 2 == 0 && KB + 2 < DK && DK0 + DSTRIDE * (NXO - 1) < DK && PF % 2 == 0 && PF >= 4 && PF <= DK - 2, "schedule constants");
     constexpr int CS0 = NST * TILE;        // two column-sum slots [4 waves][32] floats, then a dump slot for the lanes that publish nothing
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512}");
     static_assert(NST * TILE + 2 * 4 * QT * 4 + 256 <= 160 * 1024, "LDS budget");
@@ -195,7 +213,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     unsigned pbuf = 0, pend_soff = 0;
     unsigned cstage = 0;                          // LDS byte offset of the current tile's stage
     // first PF fragments of the CURRENT tile (read during the previous step / the prologue)
-    u32x4 nx0, nx1, nx2, nx3;
+    u32x4 nx[PF];
 
     struct Bits8 { bf16_t v[8]; };
     auto store_rows = [&]() {
@@ -272,12 +290,13 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         for (int q = 0; q < PF; ++q) anext[q] = lds_addr(lds + nstage) + off8[q];
         u32x4 fr[DK];                                  // A fragments of k-steps PF .. DK-1 (indices < PF unused)
         u32x4 nn[PF];                                  // first fragments of the next tile
-        fr[0] = nx0; fr[1] = nx1; fr[2] = nx2; fr[3] = nx3;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) fr[q] = nx[q];
         // the owed tile (MODE 1)
         const int mtp = TPR * rb + jt - 1;
         const float c2s = ((mtp >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
         const unsigned so0 = st_soff[0] + 2048u * (unsigned)(jt - 1), so1 = st_soff[1] + 2048u * (unsigned)(jt - 1);
-        float es[16], k8[8], k4[4], k2[2];
+        float es[16], k8[8], k4[4], k2[2], sa[15], sb[15];
         // the pending publication (flushed behind this step's barrier)
         const auto fa = lds_addr(lds + CS0 + (pbuf ? 4 * QT * 4 : 0) + l31 * 4);
         const unsigned f_voff = (pend && wave == (jt & 3) && half == 0) ? (unsigned)(l31 * 4) : 0xFFFFFF00u;
@@ -288,7 +307,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         auto issue_read = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if ((CROSSCLR_ZABL & 32)) {
-                if constexpr (q < DK - PF) fr[q + PF] = fr[(q + PF) & 3]; else nn[q - (DK - PF)] = fr[q - (DK - PF)];
+                if constexpr (q < DK - PF) fr[q + PF] = fr[(q + PF) % PF]; else nn[q - (DK - PF)] = fr[q - (DK - PF)];
                 return;
             }
             if constexpr (q < DK - PF) {
@@ -326,7 +345,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                         buf_store16(rs_st, st_voff + 1024u * th, s ? so1 : so0, __builtin_bit_cast(u32x4, pk));
                     }
                 }
-            } else {
+            } else if constexpr (CROSSCLR_ZLAG == 0) {
                 constexpr int n = H - H2, i = h - H2;
                 constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;     // units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: (publish: behind the loop)
 #pragma unroll
@@ -349,21 +368,55 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                         k2[0] = k1 + lane_xor<16>(k1);
                     }
                 }
+            } else {
+                // the same 15 exchanges (halving_sum16), each cut in two: unit u SELECTS its two operands, the DPP add that consumes them
+                // runs with unit u + 1 -- one MFMA slot later, so no wait states between a v_cndmask and the DPP instruction reading it
+                constexpr int n = H - H2, i = h - H2;
+                constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;
+#pragma unroll
+                for (int u = lo; u < hi; ++u) {
+                    if (CROSSCLR_ZABL & 64) { if (u == 15) k2[0] = es[l31 & 15]; continue; }
+                    // combine(u - 1)
+                    if (u >= 1 && u <= 8) k8[u - 1] = sa[u - 1] + lane_xor<15>(sb[u - 1]);
+                    else if (u >= 9 && u <= 12) k4[u - 9] = sa[u - 1] + lane_xor<7>(sb[u - 1]);
+                    else if (u >= 13 && u <= 14) k2[u - 13] = sa[u - 1] + lane_xor<2>(sb[u - 1]);
+                    else if (u == 15) { const float k1 = sa[14] + lane_xor<1>(sb[14]); k2[0] = k1 + lane_xor<16>(k1); }
+                    // select(u)
+                    if (u < 8) {
+                        const bool up = (l31 >> 3) & 1;
+                        sa[u] = up ? es[8 + u] : es[u]; sb[u] = up ? es[u] : es[8 + u];
+                    } else if (u < 12) {
+                        const int q = u - 8;
+                        const bool up = (l31 >> 2) & 1;
+                        sa[u] = up ? k8[4 + q] : k8[q]; sb[u] = up ? k8[q] : k8[4 + q];
+                    } else if (u < 14) {
+                        const int q = u - 12;
+                        const bool up = (l31 >> 1) & 1;
+                        sa[u] = up ? k4[2 + q] : k4[q]; sb[u] = up ? k4[q] : k4[2 + q];
+                    } else if (u == 14) {
+                        const bool up = l31 & 1;
+                        sa[u] = up ? k2[1] : k2[0]; sb[u] = up ? k2[0] : k2[1];
+                    }
+                    if (u < 15) { pin_v(sa[u]); pin_v(sb[u]); }
+                }
             }
         };
 
         static_for<DK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            // ---- head: the fragments of k-steps k and k + 1 are complete (one counted wait per two k-steps)
-            if constexpr (k >= PF && (k % 2 == 0)) {
-                constexpr int kl = k + 1 < DK ? k + 1 : k;
-                constexpr int keep_frag = FwdReadPlan::keep_for(DK, k, kl);
-                constexpr int keep_flush = FwdReadPlan::ops_before(DK, k) - FwdReadPlan::flush_seq(DK) - 1;    // (k = DK/2 + 2: the flush's reads too)
-                constexpr int keep = (k == KB + 2 && keep_flush < keep_frag) ? keep_flush : keep_frag;
-                static_assert(keep >= 0, "a wait cannot ask for an operation that has not been issued");
+            // ---- head: the fragments of k-steps k and k + 1 are complete (one counted wait per two k-steps); at k-step KB + 2 the flush's reads too
+            if constexpr ((k >= PF && (k % CROSSCLR_ZW == 0)) || k == KB + 2) {
+                constexpr bool frag = k >= PF && (k % CROSSCLR_ZW == 0);
+                constexpr int kl = (CROSSCLR_ZW == 2 && k + 1 < DK) ? k + 1 : k;
+                constexpr int keep_frag = frag ? FwdReadPlan::keep_for(DK, k, kl) : 63;
+                constexpr int keep_flush = k == KB + 2 ? FwdReadPlan::ops_before(DK, k) - FwdReadPlan::flush_seq(DK) - 1 : 63;
+                constexpr int keep = keep_flush < keep_frag ? keep_flush : keep_frag;
+                static_assert(keep >= 0 && keep < 16, "a wait cannot ask for an operation that has not been issued (lgkmcnt is 4 bits wide)");
                 wait_lgkm_n<keep>();
-                after_wait(fr[k]);
-                if constexpr (k + 1 < DK) after_wait(fr[k + 1]);
+                if constexpr (frag) {
+                    after_wait(fr[k]);
+                    if constexpr (CROSSCLR_ZW == 2 && k + 1 < DK) after_wait(fr[k + 1]);
+                }
                 if constexpr (k == KB + 2) { after_wait(f01); after_wait(f23); }
             }
             if constexpr (k == KB) {
@@ -388,7 +441,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             chore(IdxC<2 * k>{});
             sched_fence();
             if constexpr (k == 0) mfma_first_va(accC[1], a, pf[1][k]); else mfma_va(accC[1], a, pf[1][k]);
-            if constexpr (k >= KB && k < KB + NXO) issue_piece(k - KB, d_to, d_so);
+            if constexpr (k >= DK0 && (k - DK0) % DSTRIDE == 0 && (k - DK0) / DSTRIDE < NXO) issue_piece((k - DK0) / DSTRIDE, d_to, d_so);
             chore(IdxC<2 * k + 1>{});
             sched_fence();
         });
@@ -396,7 +449,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         wait_lgkm_n<0>();
 #pragma unroll
         for (int q = 0; q < PF; ++q) after_wait(nn[q]);
-        nx0 = nn[0]; nx1 = nn[1]; nx2 = nn[2]; nx3 = nn[3];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) nx[q] = nn[q];
         pend = 0;
         if constexpr (EPI) {
             if (!(CROSSCLR_ZABL & 64)) publish(k2[0], (unsigned)((rb * NT + mtp) * (QT * 4)));
@@ -432,12 +486,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             wait_dma();
             barrier_only();
             const auto xa = lds_addr(lds + cstage);
-            nx0 = lds_read_b128_async<0>(xa + off8[0]);
-            nx1 = lds_read_b128_async<0>(xa + off8[1]);
-            nx2 = lds_read_b128_async<0>(xa + off8[2]);
-            nx3 = lds_read_b128_async<0>(xa + off8[3]);
+            static_for<PF>([&](auto qc) { constexpr int q = decltype(qc)::value; nx[q] = lds_read_b128_async<(q >> 3) * 256>(xa + off8[q & 7]); });
             wait_lgkm_n<0>();
-            after_wait(nx0); after_wait(nx1); after_wait(nx2); after_wait(nx3);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) after_wait(nx[q]);
         }
         // phase 1: masked tiles one by one, up to and including the first tile that can stay owed (set A)
         bool owedA = false;

@@ -91,7 +91,7 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf", "xf_all")
+                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf", "xf_all", "step")
 
 
 _plan_cache: dict = {}
@@ -406,7 +406,7 @@ def _xf_selftest(dev, D: int, weighted: bool, entry_name: str, launches: int = 3
     for b in _XF_SELFTEST_ROWS:
         plan = nat.make_plan(b, D, 1, 0, nat.MODE_BF16)
         if not (plan.stash_bytes > 0 and plan.xf_bytes > 0):
-            return False
+            return None        # nothing to compare on this build / under these knobs: not a mismatch (the caller keeps the LDS-staged kernel, silently)
         pp = ctypes.byref(plan)
         g = torch.Generator().manual_seed(1000 + b)
         # aligned pairs (t = v + noise): a soft-max that is neither flat nor one-hot, so every tile carries weights of mixed magnitude
@@ -465,11 +465,11 @@ def _saved_backward_entry(ws, plan, dev) -> str:
                 return "crossclr_backward_saved"          # nothing can be verified inside a capture
             else:
                 ok = _xf_selftest(dev, plan.D, weighted, name)
-                if not ok:
+                if ok is False:
                     import warnings
                     warnings.warn(f"CrossCLR: {name} disagrees with the LDS-staged saved backward on this device / build at Dpad = {plan.Dpad}; "
                                   "it is disabled for this process (tools/soak_xf.py reproduces the comparison)")
-            _xf_verified[key] = ok
+            _xf_verified[key] = ok = bool(ok)
         if ok:
             return name
     return "crossclr_backward_saved"
@@ -499,6 +499,112 @@ def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
     return ctypes.pointer(s)
 
 
+_last_step_backward_kernel = None     # crossclr_step_layout.backward_kernel of the most recent single-device forward (tests, bench.py)
+_last_step_saved = None               # ... and whether that step saved its exponentials
+
+
+def _step_flags(plan, flags: int, temperature: float, negative_w: float, weighted: bool, dev) -> "tuple[int, nat.StepLayout]":
+    """The single-device step's flags after this module's one reservation about the library's choice: a hand-scheduled fragment-major
+    backward (crossclr_backward_saved_xfp / _xf) is only taken once it has reproduced the LDS-staged kernel bit for bit on this device
+    (`_xf_selftest`, once per instantiation); a rejected -- or, inside a HIP-graph capture, unverifiable -- one is taken out with
+    CROSSCLR_STEP_NO_XFP / _NO_XF and the library plans again.  Everything else (two-pass regime, save or recompute, layouts) is
+    crossclr_step_plan's decision."""
+    lib = nat.library()
+    lay = nat.StepLayout()
+    names = {3: ("crossclr_backward_saved_xfp", nat.STEP_NO_XFP), 2: ("crossclr_backward_saved_xf", nat.STEP_NO_XF)}
+    while True:
+        nat.check(lib.crossclr_step_plan(ctypes.byref(plan), temperature, negative_w, flags, 0, ctypes.byref(lay)))
+        cand = names.get(lay.backward_kernel)
+        if cand is None or nat.injected_for_testing():
+            return flags, lay
+        name, off_flag = cand
+        key = (str(dev), plan.Dpad, weighted, name, nat.library_path())
+        ok = _xf_verified.get(key)
+        if ok and _XF_RECHECK > 0:
+            n = _xf_launches[key] = _xf_launches.get(key, 0) + 1
+            if n % _XF_RECHECK == 0 and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                ok = None
+        if ok is None:
+            if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                flags |= nat.STEP_NO_XFP | nat.STEP_NO_XF       # nothing can be verified inside a capture: the LDS-staged kernel
+                continue
+            verdict = _xf_selftest(dev, plan.D, weighted, name)
+            if verdict is False:
+                warnings.warn(f"CrossCLR: {name} disagrees with the LDS-staged saved backward on this device / build at Dpad = {plan.Dpad}; "
+                              "it is disabled for this process (tools/soak_xf.py reproduces the comparison)")
+            ok = _xf_verified[key] = bool(verdict)
+        if ok:
+            return flags, lay
+        flags |= off_flag
+
+
+def _forward_step(video, text, temperature, negative_w, plan, mode, negative_scale, loss_weight, save_for_backward, prenormalized):
+    """The single-device step through the library's two calls (include/crossclr.h, ABI 6): crossclr_step_forward here,
+    crossclr_step_backward in `_backward_step`.  One caller-owned workspace whose layout the library reports; the module carves views of
+    it for the tools and tests that look at intermediate results."""
+    lib = nat.library()
+    dev = video.device
+    b = video.shape[0]
+    ws = _Workspace()
+    ws.plan, ws.world, ws.rank, ws.sharded = plan, 1, 0, False
+    ws.temperature, ws.negative_w = float(temperature), float(negative_w)
+    ws.in_dtype = _IN_DTYPE[video.dtype]
+    ws.group = ws.partner_peers = ws.exchange = ws.k_work = ws.stats_work = None
+    ws.saved_blocks = ws.recompute_ranges = ws.xf_all = None
+    ws.k_rows = _pack_pair(negative_scale, b, plan.bpad, dev, "negative_scale")
+    ws.lw = _pack_pair(loss_weight, b, plan.bpad, dev, "loss_weight")
+    ws.k_cols = ws.k_rows
+    ws.prenormalized = bool(prenormalized)
+    flags = (nat.STEP_PRENORMALIZED if prenormalized else 0) | (0 if save_for_backward else nat.STEP_FORWARD_ONLY)
+    flags, lay = _step_flags(plan, flags, ws.temperature, ws.negative_w, ws.k_rows is not None, dev)
+    try:
+        slab = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+    except torch.OutOfMemoryError:
+        if not lay.saved:
+            raise
+        flags |= nat.STEP_NO_SAVE          # the saved exponentials do not fit: the recomputing pair
+        nat.check(lib.crossclr_step_plan(ctypes.byref(plan), ws.temperature, ws.negative_w, flags, 0, ctypes.byref(lay)))
+        slab = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+    # (the loss the caller gets back is a 0-dim view of this buffer: its own small allocation, so it never pins the workspace)
+    ws.loss_sum = torch.empty(max(2, plan.loss_ws_doubles), dtype=torch.float64, device=dev)
+    with _Range("crossclr.step_forward"):
+        nat.check(lib.crossclr_step_forward(ctypes.byref(plan), _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                            ws.temperature, ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), flags, _ptr(slab), lay.total_bytes,
+                                            _ptr(ws.loss_sum), _stream_for(video)))
+    n2 = 2 * plan.bpad
+    view = lambda off, nbytes, dt: None if off == nat.STEP_NONE else _carve(slab, off, nbytes, dt)
+    ws.xhat = view(lay.xhat, plan.operand_bytes, torch.uint8)
+    ws.inv_norm, ws.diag = view(lay.inv_norm, 4 * n2, torch.float32), view(lay.diag, 4 * plan.bpad, torch.float32)
+    ws.logz, ws.rz, ws.wrz = (view(o, 4 * n2, torch.float32) for o in (lay.logz, lay.rz, lay.wrz))
+    ws.shift = view(lay.shift, 4 * n2, torch.float32)
+    ws.xf = view(lay.xf, lay.xf_bytes, torch.uint8)
+    ws.stash = view(lay.stash, lay.stash_bytes, torch.uint8)
+    ws.xcols, ws.rz_cols, ws.wrz_cols, ws.shift_cols = ws.xhat, ws.rz, ws.wrz, ws.shift
+    ws.step = (flags, slab, lay.total_bytes, lay.backward_scratch_bytes)
+    global _last_step_backward_kernel, _last_step_saved
+    _last_step_backward_kernel, _last_step_saved = lay.backward_kernel, bool(lay.saved)
+    return ws.loss_sum[1], ws      # = sum / (2 B), written by the finish kernel
+
+
+def _backward_step(ws, video, text, grad_out):
+    lib = nat.library()
+    plan = ws.plan
+    dev = video.device
+    flags, slab, nbytes, scratch_bytes = ws.step
+    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+    if grad_out.dtype == torch.float64 and grad_out.device == dev and grad_out.numel() == 1:
+        go = grad_out.detach().reshape(1)
+    else:
+        go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
+    gv = torch.empty(video.shape, dtype=video.dtype, device=dev)
+    gt = torch.empty(text.shape, dtype=text.dtype, device=dev)
+    with _Range("crossclr.step_backward"):
+        nat.check(lib.crossclr_step_backward(ctypes.byref(plan), _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
+                                             ws.temperature, ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), flags, _ptr(slab), nbytes,
+                                             _ptr(scratch), _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0), _stream_for(video)))
+    return gv, gt
+
+
 def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, negative_w: float,
                   compute_mode: str, group, negative_scale=None, loss_weight=None,
                   save_for_backward: bool = False, prenormalized: bool = False, project=None) -> "tuple[torch.Tensor, _Workspace]":
@@ -520,6 +626,8 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     small_tau = bool(lib.crossclr_needs_row_shift(float(temperature), float(negative_w)))
     mode = _resolve_mode(compute_mode, b * world, video.dtype, small_tau)
     plan = _plan_for(b, D, world, rank, mode)
+    if not sharded and project is None:
+        return _forward_step(video, text, temperature, negative_w, plan, mode, negative_scale, loss_weight, save_for_backward, prenormalized)
     stash_everywhere = True
     if world > 1:
         # (what a rank of the pair scheme keeps alive between forward and backward: the local stash and one rectangular stash per block
@@ -533,6 +641,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
     f32 = dict(dtype=torch.float32, device=dev)
 
     ws = _Workspace()
+    ws.step = None
     ws.plan, ws.world, ws.rank, ws.sharded = plan, world, rank, sharded
     ws.temperature, ws.negative_w = float(temperature), float(negative_w)
     ws.in_dtype = _IN_DTYPE[video.dtype]
@@ -864,6 +973,8 @@ def _remote_xfp(ws, plan, lib, pp, dev) -> bool:
 
 
 def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad_out: torch.Tensor):
+    if ws.step is not None and ws.prenormalized != 2:
+        return _backward_step(ws, video, text, grad_out)
     lib = nat.library()
     plan = ws.plan
     pp = ctypes.byref(plan)
@@ -968,6 +1079,14 @@ def _backward_impl(ws: _Workspace, video: torch.Tensor, text: torch.Tensor, grad
         ws.saved_blocks = None
         ws.xf = ws.xf_all = None
     elif ws.sharded and ws.shift is None:
+        if ws.partner_peers is not None:
+            # Partner-gradient scheme (the default from 3 ranks): the first backward consumed the saved blocks, and the operand slices of
+            # the ranks whose blocks the PARTNER evaluated were never requested (deferred exchange) -- a recomputing launch over every
+            # rank's slice would read memory nobody wrote.  Every rank takes this branch together.
+            raise RuntimeError("CrossCLR (sharded, partner gradients): backward was called a second time through the same graph "
+                               "(retain_graph=True); the saved exponentials are released after the first backward and the late operand "
+                               "slices are never exchanged in this scheme -- run the forward again, or set CROSSCLR_PARTNER_GRADS=0 on "
+                               "every rank (the recomputing scheme supports repeated backwards)")
         if ws.wrz_cols is None:
             _traced_wait("statistics", [ws.stats_work])
             ws.wrz_cols = ws.rz_cols * ws.negative_w

@@ -10,7 +10,7 @@ with the projection, the L2-normalisation of `trainer/loss.py:79-80` and the pac
 Backward: the loss' finish kernel reads the packed bf16 unit rows and 1 / ||y|| and writes g_y = d(loss)/d(projected features) in bf16
 (normalise-backward and positive-pair term fused: `crossclr_backward_finish_p(prenormalized = 2)`); the projection's own gradients
 (dW = g_y^T x, dx = g_y W, db = column sums) are plain library GEMMs with bf16 operands and fp32 accumulation (hipBLASLt), against the
-bf16 weights the forward multiplied with (cast once per parameter version).
+bf16 weights the forward multiplied with (cast every step: no cache to go stale; dx leaves the GEMM in fp32 for fp32 inputs).
 bf16 operands with fp32 accumulation (the BASELINE headline mode), embed_dim <= 1024 (64 rows per block up to 512, 32 rows above).
 """
 from __future__ import annotations
@@ -22,39 +22,42 @@ from . import _native as nat
 from . import loss as L
 
 
-_weight_cache: dict = {}      # (id(weight), form) -> (data_ptr, _version, device, Dpad, copy, ldw): re-cast only when the parameter changed
-
-
-def _weights_bf16(w: torch.Tensor, Dpad: int = 0) -> "tuple[torch.Tensor, int]":
+def _weights_bf16(w: torch.Tensor, Dpad: int = 0, row_major: "torch.Tensor | None" = None) -> "tuple[torch.Tensor, int]":
     """nn.Linear weight [D, Din] as the kernels want it, columns zero-padded to ldw = a multiple of 64 (the kernel's K chunk).
     Dpad = 0: bf16 [D, ldw] row-major (the backward's dx = g_y W GEMM; `crossclr_project_pack`).
     Dpad > 0: FRAGMENT-MAJOR for `crossclr_project_pack_wf` -- [Dpad / 32][ldw / 16][64][8], lane (l31, half) of record (d32, ks) holding
-    W[32 d32 + l31][16 ks + 8 half .. + 7], rows beyond D zero: a wave's MFMA B fragment is one coalesced 1-KiB load.
-    Cached per parameter VERSION (gradient accumulation, evaluation and the backward of the same step reuse the copy; an optimiser step
-    bumps `_version` and the next forward casts again)."""
-    key = (id(w), Dpad > 0)
-    hit = _weight_cache.get(key)
-    if hit is not None and hit[0] == w.data_ptr() and hit[1] == w._version and hit[2] == w.device and hit[3] == Dpad and hit[4].numel() >= w.numel():
-        return hit[4], hit[5]
+    W[32 d32 + l31][16 ks + 8 half .. + 7], rows beyond D zero: a wave's MFMA B fragment is one coalesced 1-KiB load
+    (`row_major`: the Dpad = 0 form of the same weight, if the caller already has it -- saves the second cast).
+    Cast on EVERY call (two small launches per weight and step): a cache keyed on the parameter's identity / `_version` cannot see updates
+    through `.data` (fused optimisers, EMA, clipping) nor tell a new parameter from a freed one whose id and address were reused, and a
+    stale copy would train silently on old weights (round-4 review)."""
     D, Din = w.shape
     ldw = (Din + 63) // 64 * 64
     if Dpad > 0:
-        pad = torch.zeros(Dpad, ldw, dtype=torch.bfloat16, device=w.device) if (Dpad != D or ldw != Din) else None
-        if pad is None:
-            pad = w.detach().to(torch.bfloat16)
-        else:
+        if row_major is not None and Dpad == D:
+            pad = row_major
+        elif Dpad != D or ldw != Din:
+            pad = torch.zeros(Dpad, ldw, dtype=torch.bfloat16, device=w.device)
             pad[:D, :Din].copy_(w.detach())
+        else:
+            pad = w.detach().to(torch.bfloat16)
         out = pad.view(Dpad // 32, 32, ldw // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
     elif ldw == Din:
         out = w.detach().to(torch.bfloat16).contiguous()
     else:
-        out = torch.empty(D, ldw, dtype=torch.bfloat16, device=w.device)
+        out = torch.zeros(D, ldw, dtype=torch.bfloat16, device=w.device)
         out[:, :Din].copy_(w.detach())
-        out[:, Din:].zero_()
-    if len(_weight_cache) > 32:
-        _weight_cache.clear()
-    _weight_cache[key] = (w.data_ptr(), w._version, w.device, Dpad, out, ldw)
     return out, ldw
+
+
+def _mm_f32_out(a_bf16: torch.Tensor, b_bf16: torch.Tensor, out_dtype) -> torch.Tensor:
+    """a @ b with bf16 operands and fp32 accumulation, result in `out_dtype` WITHOUT passing through bf16 when it is wider (the library's
+    bf16 GEMM with an fp32 output on the device; on the host emulation's CPU tensors: an fp32 product of the same bf16 values)."""
+    if out_dtype == torch.bfloat16:
+        return torch.mm(a_bf16, b_bf16)
+    if a_bf16.is_cuda:
+        return torch.mm(a_bf16, b_bf16, out_dtype=torch.float32).to(out_dtype)
+    return torch.mm(a_bf16.float(), b_bf16.float()).to(out_dtype)
 
 
 class _ProjectedFunction(torch.autograd.Function):
@@ -63,22 +66,28 @@ class _ProjectedFunction(torch.autograd.Function):
         xv_c, xt_c = L._row_major(xv.detach()), L._row_major(xt.detach())
         needs = any(ctx.needs_input_grad[:6])
         Dpad = L._plan_for(xv.shape[0], wv.shape[0], 1, 0, nat.MODE_BF16).Dpad
-        wvb, ldw = _weights_bf16(wv, Dpad)          # fragment-major (crossclr_project_pack_wf)
-        wtb, ldw_t = _weights_bf16(wt, Dpad)
+        # row-major bf16 copies (the backward's dx GEMM multiplies with the values the forward multiplied with: handed over through ctx,
+        # not looked up again), and the fragment-major form of the same values for crossclr_project_pack_wf
+        wv_rm, ldw = _weights_bf16(wv)
+        wt_rm, ldw_t = _weights_bf16(wt)
+        wvb, _ = _weights_bf16(wv, Dpad, wv_rm)
+        wtb, _ = _weights_bf16(wt, Dpad, wt_rm)
         bvf = None if bv is None else bv.detach().float().contiguous()
         btf = None if bt is None else bt.detach().float().contiguous()
         with L._device_of(xv_c):
             loss, ws = L._forward_impl(xv_c, xt_c, temperature, negative_w, "bf16", group, None, None, save_for_backward=needs,
                                        project=(wvb, wtb, (ldw, ldw_t), bvf, btf, wv.shape[0]))
         ctx.ws = ws
-        ctx.save_for_backward(xv_c, xt_c, wv.detach(), wt.detach())
+        ctx.save_for_backward(xv_c, xt_c, wv_rm, wt_rm)
+        ctx.w_meta = (tuple(wv.shape), wv.dtype, tuple(wt.shape), wt.dtype)
         ctx.bias_dtype = (None if bv is None else bv.dtype, None if bt is None else bt.dtype)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         L._refuse_double_backward("ProjectedCrossCLR")
-        xv, xt, wv, wt = ctx.saved_tensors
+        xv, xt, wv_rm, wt_rm = ctx.saved_tensors
+        (wv_shape, wv_dtype, wt_shape, wt_dtype) = ctx.w_meta
         ws = ctx.ws
         plan = ws.plan
         b, D, bpad, Dpad = plan.b, plan.D, plan.bpad, plan.Dpad
@@ -92,14 +101,14 @@ class _ProjectedFunction(torch.autograd.Function):
             gyv, gyt = L._backward_impl(ws, packed[0, :b, :D], packed[1, :b, :D], grad_out)
             # the projection's own gradients: bf16 operands, fp32 accumulation (plain library GEMMs -- hipBLASLt)
             need = ctx.needs_input_grad
-            dxv = torch.mm(gyv, _weights_bf16(wv)[0][:, :wv.shape[1]]).to(xv.dtype) if need[0] else None     # (the bf16 values the forward multiplied with)
-            dxt = torch.mm(gyt, _weights_bf16(wt)[0][:, :wt.shape[1]]).to(xt.dtype) if need[1] else None
+            dxv = _mm_f32_out(gyv, wv_rm[:, :wv_shape[1]], xv.dtype) if need[0] else None     # (the bf16 values the forward multiplied with)
+            dxt = _mm_f32_out(gyt, wt_rm[:, :wt_shape[1]], xt.dtype) if need[1] else None
             dwv = dwt = dbv = dbt = None
             if need[2] or need[4] or need[3] or need[5]:
                 # dW = g_y^T x and db = column sums of g_y, both modalities: ONE split-K MFMA launch + a reduce (crossclr_project_dw) --
                 # hipBLASLt's pick for this shape (K = batch = 8192, 128 output tiles, no split-K) takes 59 us per modality, this ~1/4
                 lib = nat.library()
-                dinv, dint = wv.shape[1], wt.shape[1]
+                dinv, dint = wv_shape[1], wt_shape[1]
                 wsf = torch.empty(lib.crossclr_project_dw_ws_floats(b, D, dinv, dint), dtype=torch.float32, device=xv.device)
                 dwv32 = torch.empty(D, dinv, dtype=torch.float32, device=xv.device)
                 dwt32 = torch.empty(D, dint, dtype=torch.float32, device=xv.device)
@@ -108,8 +117,8 @@ class _ProjectedFunction(torch.autograd.Function):
                 nat.check(lib.crossclr_project_dw(b, D, L._ptr(gyv), L._ptr(gyt), gyv.stride(0), L._ptr(xv), L._ptr(xt), xv.stride(0), xt.stride(0),
                                                   dinv, dint, L._IN_DTYPE[xv.dtype], L._ptr(wsf), L._ptr(dwv32), L._ptr(dwt32), dinv, dint,
                                                   L._ptr(dbv32), L._ptr(dbt32), L._stream_for(xv)))
-                dwv = dwv32.to(wv.dtype) if need[2] else None
-                dwt = dwt32.to(wt.dtype) if need[4] else None
+                dwv = dwv32.to(wv_dtype) if need[2] else None
+                dwt = dwt32.to(wt_dtype) if need[4] else None
                 dbv = dbv32.to(ctx.bias_dtype[0]) if (need[3] and dbv32 is not None) else None
                 dbt = dbt32.to(ctx.bias_dtype[1]) if (need[5] and dbt32 is not None) else None
         return dxv, dxt, dwv, dbv, dwt, dbt, None, None, None

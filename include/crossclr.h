@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define CROSSCLR_LAUNCH_GROUPS 8   /* launch groups the forward workspace has room for */
-#define CROSSCLR_ABI_VERSION 5
+#define CROSSCLR_ABI_VERSION 6
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
 #define CROSSCLR_IN_F32 0
@@ -450,6 +450,55 @@ int crossclr_maxmargin_backward(const crossclr_plan* plan, const void* xhat, con
 int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* gbuf, const void* im, const void* s, long ld_im,
                                        long ld_s, int in_dtype, const float* ones, const float* active, const double* grad_out,
                                        void* grad_im, void* grad_s, long ld_gim, long ld_gs, void* stream);
+
+/* ---- THE WHOLE STEP BEHIND TWO CALLS (ABI 6; single device: plan->world == 1) -----------------------------------------------
+ * What the reference's one class is to its caller (trainer/loss.py:68-114 `forward`, and autograd's backward through it): a binding needs
+ * nothing but crossclr_make_plan, crossclr_step_plan, crossclr_step_forward and crossclr_step_backward.  The library chooses the kernels:
+ *   two-pass soft-max when max(1, |negative_weight|) / temperature > 128 (crossclr_needs_row_shift), the fixed-shift kernels otherwise;
+ *   save-for-backward (the forward leaves its exponentials in the workspace, the backward is the gradient product alone) whenever the plan
+ *     offers it, the caller did not forbid it (CROSSCLR_STEP_NO_SAVE / _FORWARD_ONLY), the stash is at most CROSSCLR_MAX_STASH_GB (default 8)
+ *     and the workspace the caller brought is large enough -- otherwise the recomputing pair;
+ *   the fragment-major operand copy + the pair kernel (crossclr_backward_saved_xfp), the one-tile fragment-major kernel (_xf) or the
+ *     LDS-staged saved backward, by padded width and batch (measured break-even: Dpad in {512, 768, 1024, wide plans} from 2048 / 4096 padded
+ *     rows; CROSSCLR_XF_WIDTHS overrides) -- CROSSCLR_STEP_NO_XFP / _NO_XF take a hand-scheduled kernel out (a caller that verifies
+ *     them on its device first, as this repository's Python module does, passes the verdict here).
+ * All of it is a pure function of (plan, temperature, negative_weight, flags, workspace_bytes): crossclr_step_plan reports the decision and
+ * the workspace layout, and forward and backward of one step must be given the same five values.
+ * Buffers (caller-owned, device): `workspace` (layout.total_bytes; must reach the backward unmodified), `loss_ws` (max(2,
+ * plan->loss_ws_doubles) doubles: loss_ws[1] = the mean loss of loss.py:114 after the forward), `scratch` (layout.backward_scratch_bytes, backward
+ * only), the inputs and the gradients.  sw (optional): neg_scale_rows = k[2][bpad], loss_weight = omega[2][bpad] (neg_scale_cols is ignored:
+ * the local block's columns are its rows).  Nothing is allocated, nothing synchronises; errors as everywhere (CROSSCLR_E_WORKSPACE:
+ * workspace_bytes below even the recomputing layout).                                                                               */
+#define CROSSCLR_STEP_NO_SAVE 1u        /* the backward recomputes the similarity product (smallest workspace)            */
+#define CROSSCLR_STEP_FORWARD_ONLY 2u   /* no backward will follow (evaluation / no_grad): implies NO_SAVE                 */
+#define CROSSCLR_STEP_PRENORMALIZED 4u  /* the rows are unit vectors already (loss.py:79-80 skipped; gradients w.r.t. the unit rows) */
+#define CROSSCLR_STEP_NO_XFP 8u         /* do not take crossclr_backward_saved_xfp                                         */
+#define CROSSCLR_STEP_NO_XF 16u         /* do not take crossclr_backward_saved_xf either (LDS-staged saved backward)       */
+#define CROSSCLR_STEP_NONE ((size_t)-1) /* a layout offset that this step does not have                                    */
+
+typedef struct crossclr_step_layout {
+    size_t total_bytes;             /* bytes of `workspace` this layout needs                                          */
+    size_t backward_scratch_bytes;  /* bytes of crossclr_step_backward's `scratch` (the gradient slices, plan->gbuf_bytes) */
+    /* byte offsets into `workspace` (256-byte aligned; CROSSCLR_STEP_NONE: not part of this step) */
+    size_t xhat, inv_norm, diag, logz, rz, wrz, part, shift, xf, stash;
+    size_t ticket;                  /* one int: cleared by the step's first kernel, counts the finish kernel's blocks (its last block forms the loss) */
+    size_t stash_bytes, xf_bytes;   /* sizes of xf and stash                                                           */
+    int two_pass;                   /* 1: per-row soft-max shifts (small temperature)                                  */
+    int saved;                      /* 1: the forward saves its exponentials                                           */
+    int backward_kernel;            /* 0 recomputing, 1 saved (LDS-staged / generic), 2 saved fragment-major, 3 saved fragment-major pair kernel */
+} crossclr_step_layout;
+
+/* workspace_bytes = 0: the best layout for these arguments (ask, allocate layout.total_bytes, pass that number on);
+ * otherwise the best layout that fits into workspace_bytes.                                                            */
+int crossclr_step_plan(const crossclr_plan* plan, float temperature, float negative_weight, unsigned flags,
+                       size_t workspace_bytes, crossclr_step_layout* layout);
+int crossclr_step_forward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                          float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
+                          void* workspace, size_t workspace_bytes, double* loss_ws, void* stream);
+int crossclr_step_backward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                           float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
+                           void* workspace, size_t workspace_bytes, void* scratch, const double* grad_out,
+                           void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext, void* stream);
 
 /* Hardware assumption checks (MFMA fragment layouts, ds_read_b64_tr_b16 gather).  `out` is a
  * device buffer of at least 64 KiB; the caller compares it with the documented layouts.        */

@@ -119,6 +119,8 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 #define gridDim (emu::g_gridDim)
 
 inline void __syncthreads() { emu::t_block->bar.wait(); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
 namespace crossclr {
 

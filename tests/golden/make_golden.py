@@ -188,6 +188,10 @@ def main():
     for tau, tag in ((0.01, "tau001"), (0.015, "tau0015")):
         metas.append(case(f"g9_{tag}_b2048_d512", "randn", 2048, 512, 21, tau=tau, full=False))
         metas.append(case(f"g9_{tag}_cluster_b2048_d512", "cluster", 2048, 512, 23, tau=tau, full=False))
+    # G10: wide embeddings -- the XP = 2 (D = 1024) and XP = 3 (D = 1536, beyond the register-resident forward) instantiations of the saved
+    # backward's pair kernel meet reference-generated numbers directly (round-4 review: they were checked against the streaming oracle only)
+    metas.append(case("g10_b2048_d1024", "randn", 2048, 1024, 31, full=False))
+    metas.append(case("g10_b2048_d1536", "randn", 2048, 1536, 32, full=False))
     # G7: large
     if args.large:
         metas.append(case("g7_b4096_d512_s1234", "randn", 4096, 512, 1234, full=False))

@@ -326,3 +326,61 @@ def test_fused_projection_in_a_sharded_run_over_gloo(world):
         assert loss != "error", ref
         assert abs(loss - ref) <= 2e-3 * max(1.0, abs(ref)), (rank, loss, ref)      # bf16 products in the projection AND the similarities
         assert err <= 3e-2, (rank, err)
+
+
+def _second_backward_worker(rank, world, port, q, partner):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        if not partner:
+            os.environ["CROSSCLR_PARTNER_GRADS"] = "0"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import crossclr_amd
+        from crossclr_amd import _native as nat
+        from emu import build_emu
+        from oracle import crossclr_oracle as orc
+        nat.use_library_for_testing(build_emu.OUT)
+        B, D = 24 * world, 24
+        v, t = orc.make_inputs("randn", B, D, 77)
+        b = B // world
+        vl = v[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        tl = t[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        crit = crossclr_amd.CrossCLR_onlyIntraModality(0.05, 0.7, compute_mode="bf16", process_group=dist.group.WORLD)
+        loss = crit(vl, tl)
+        loss.backward(retain_graph=True)
+        g1 = vl.grad.clone()
+        vl.grad = None
+        try:
+            loss.backward()
+            q.put((rank, "ok", float((vl.grad - g1).abs().max() / g1.abs().max())))
+        except RuntimeError as e:
+            q.put((rank, "error", str(e)))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "crash", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("partner", [True, False])
+def test_second_backward_in_a_three_rank_run(partner):
+    """Round-4 review: with partner gradients the first backward consumes the saved blocks and the late operand slices are never
+    exchanged -- a second backward through the same graph used to read unwritten memory.  It now raises on every rank; the
+    recomputing scheme (CROSSCLR_PARTNER_GRADS=0) repeats the backward with the same gradients (bf16 saved vs recomputed: 1e-2)."""
+    from emu import build_emu
+    build_emu.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 31 + int(partner)
+    procs = [ctx.Process(target=_second_backward_worker, args=(r, 3, port, q, partner)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, kind, info in results:
+        if partner:
+            assert kind == "error" and "second time" in info, (rank, kind, info)
+        else:
+            assert kind == "ok" and info <= 2e-2, (rank, kind, info)

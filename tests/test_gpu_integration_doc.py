@@ -1,29 +1,57 @@
-"""INTEGRATION.md shows the ctypes binding a maintainer of the reference would add inside its own `forward`.  This test runs
-that very code block (extracted from the document) on the MI355X and compares it with the module."""
+"""INTEGRATION.md shows the ctypes binding a maintainer of the reference would add inside its own module: forward AND backward through the
+two step calls of the C-ABI (crossclr_step_forward / crossclr_step_backward).  This test runs that very code block (extracted from the
+document) on the MI355X against the reference's golden loss and gradients, and against the module."""
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
 import crossclr_amd
+from conftest import golden_arrays, golden_index, golden_inputs
 from crossclr_amd import _native as nat
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_the_documented_ctypes_stub_runs_and_matches_the_module():
+def _stub():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     m = re.search(r"```python\nimport ctypes, torch\n(.*?)```", text, re.S)
     assert m, "the binding example is missing from INTEGRATION.md"
-    code = "import ctypes, torch\n" + m.group(1).replace('ctypes.CDLL("libcrossclr_hip.so")', f'ctypes.CDLL("{nat.library_path()}")')
+    body = m.group(1)
+    assert len([l for l in body.splitlines() if l.strip()]) <= 40, "the documented binding is meant to stay within 40 lines"
+    code = "import ctypes, torch\n" + body.replace('ctypes.CDLL("libcrossclr_hip.so")', f'ctypes.CDLL("{nat.library_path()}")')
     ns = {}
     exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    return ns["CrossCLRStep"]
+
+
+def test_the_documented_binding_matches_the_reference_golden_forward_and_backward():
+    step = _stub()
+    m = golden_index()["g1_b64_d256_s0"]
+    v, t = golden_inputs(m)
+    vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    loss = step.apply(vd, td, m["temperature"], m["negative_weight"], 0)         # exact-fp32 products
+    assert loss.dtype == torch.float64 and loss.dim() == 0
+    loss.backward()
+    assert abs(loss.item() - m["loss"]) <= 2e-5
+    arr = golden_arrays("g1_b64_d256_s0")
+    scale = max(m["grad_v_absmax"], m["grad_t_absmax"])
+    assert np.abs(vd.grad.cpu().numpy() - arr["grad_v"]).max() <= 2e-4 * scale
+    assert np.abs(td.grad.cpu().numpy() - arr["grad_t"]).max() <= 2e-4 * scale
+
+
+def test_the_documented_binding_is_the_module_bit_for_bit():
+    step = _stub()
     g = torch.Generator().manual_seed(0)
     v, t = torch.randn(1000, 300, generator=g).cuda(), torch.randn(1000, 300, generator=g).cuda()
-    got = ns["crossclr_forward_only"](v, t)
-    with torch.no_grad():
-        want = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()(v, t)
-    assert got.dtype == torch.float64 and got.dim() == 0
-    assert abs(got.item() - want.item()) <= 1e-9
+    va, ta = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    got = step.apply(va, ta, 0.03, 0.8, 1)
+    (2.0 * got).backward()
+    vb, tb = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    want = crossclr_amd.CrossCLR_onlyIntraModality(0.03, 0.8, compute_mode="bf16").cuda()(vb, tb)
+    (2.0 * want).backward()
+    assert got.item() == want.item()
+    assert torch.equal(va.grad, vb.grad) and torch.equal(ta.grad, tb.grad)

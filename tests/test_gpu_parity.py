@@ -93,8 +93,6 @@ def test_bf16_mode_meets_the_stated_bars_on_baseline_config1(name):
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "auto"])
 def test_large_cases_sampled_rows(name, mode):
     m = IDX[name]
-    if mode == "fp32" and m["B"] > 4096:
-        pytest.skip("fp32 at B=8192 is covered by the forward-only test; keep the GPU suite short")
     v, t = golden_inputs(m)
     loss, gv, gt = run_module(v, t, m, mode)
     if name == "g7_b8192_d512_s1234" and mode == "bf16":

@@ -118,3 +118,23 @@ def test_weight_gradient_kernel_equals_the_matrix_product(b, D, din_v, din_t, dt
         want = gy.double().t() @ x.bfloat16().double()
         assert (dw.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
         assert (db.double() - gy.double().sum(0)).abs().max().item() <= 1e-4
+
+
+def test_weight_casts_track_data_updates_and_fresh_modules():
+    """Round-4 review: a cache keyed on id(weight) / _version returned stale bf16 weights after `.data` updates (fused optimisers, EMA)
+    and for a new module whose parameter reused a freed one's id and address.  The casts are now redone on every call."""
+    from crossclr_amd.projection import _weights_bf16
+    for it in range(20):
+        lin = torch.nn.Linear(128, 128)
+        want = lin.weight.detach().to(torch.bfloat16)
+        got, ldw = _weights_bf16(lin.weight)
+        assert ldw == 128 and torch.equal(got, want), it
+        frag, _ = _weights_bf16(lin.weight, 128)
+        back = frag.view(4, 8, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(128, 128)
+        assert torch.equal(back, want), it
+        del lin
+    w = torch.nn.Parameter(torch.randn(64, 96))
+    a, _ = _weights_bf16(w)
+    w.data.mul_(2.0)                       # no _version bump
+    b, _ = _weights_bf16(w)
+    assert torch.equal(b[:, :96], (w.detach()).to(torch.bfloat16)) and not torch.equal(a, b)

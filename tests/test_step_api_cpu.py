@@ -1,0 +1,89 @@
+"""CPU tests (host emulation): the two step calls of the C-ABI (crossclr_step_plan / _forward / _backward, include/crossclr.h ABI 6) against
+the stage entry points they are composed of -- same bits -- and the library's kernel-selection policy as crossclr_step_plan reports it."""
+import ctypes
+
+import pytest
+import torch
+
+import crossclr_amd
+from crossclr_amd import _native as nat
+from crossclr_amd import loss as L
+from oracle import crossclr_oracle as orc
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulated_library():
+    from emu import build_emu
+    nat.use_library_for_testing(build_emu.build())
+    yield
+    nat.use_library_for_testing(None)
+
+
+def _stages(v, t, tau, w, mode):
+    """normalize -> forward -> forward_finish through the fine-grained entry points (separate loss-reduce launch)."""
+    lib = nat.library()
+    b, D = v.shape
+    plan = nat.make_plan(b, D, 1, 0, mode)
+    pp, p = ctypes.byref(plan), L._ptr
+    f32 = dict(dtype=torch.float32)
+    xhat = torch.empty(plan.operand_bytes, dtype=torch.uint8)
+    inv_norm, diag = torch.empty(2 * plan.bpad, **f32), torch.empty(plan.bpad, **f32)
+    part = torch.empty(plan.fwd_ws_floats, **f32)
+    logz, rz, wrz = (torch.empty(2 * plan.bpad, **f32) for _ in range(3))
+    loss_sum = torch.empty(max(2, plan.loss_ws_doubles), dtype=torch.float64)
+    nat.check(lib.crossclr_normalize(pp, p(v), p(t), v.stride(0), t.stride(0), nat.IN_F32, p(xhat), p(inv_norm), p(diag), 0))
+    nat.check(lib.crossclr_forward(pp, p(xhat), p(xhat), 1, 0, -1, tau, w, p(part), 0, 0))
+    nat.check(lib.crossclr_forward_finish(pp, p(part), plan.fwd_slots, p(diag), tau, w, p(logz), p(rz), p(wrz), p(loss_sum), 0))
+    return loss_sum[1].item(), logz
+
+
+@pytest.mark.parametrize("B,D,mode", [(40, 24, "fp32"), (150, 32, "bf16"), (256, 16, "bf16"), (300, 40, "fp32")])
+def test_step_forward_equals_the_stage_entry_points_bit_for_bit(B, D, mode):
+    v, t = orc.make_inputs("randn", B, D, 3)
+    want, logz = _stages(v, t, 0.05, 0.8, nat.MODE_FP32 if mode == "fp32" else nat.MODE_BF16)
+    with torch.no_grad():
+        got = crossclr_amd.crossclr_loss(v, t, 0.05, 0.8, compute_mode=mode)
+    assert got.item() == want      # (the finish kernel's last block sums the block partials exactly like fwd_finish_reduce_kernel)
+    _, ws = L._forward_impl(v, t, 0.05, 0.8, mode, None, save_for_backward=True)
+    assert torch.equal(ws.logz, logz) and ws.step is not None
+
+
+def test_step_plan_reports_the_policy(monkeypatch):
+    lib = nat.library()
+    lay = nat.StepLayout()
+
+    def plan_of(b, D, mode, tau=0.05, flags=0, nbytes=0):
+        plan = nat.make_plan(b, D, 1, 0, mode)
+        nat.check(lib.crossclr_step_plan(ctypes.byref(plan), tau, 0.8, flags, nbytes, ctypes.byref(lay)))
+        return plan
+    plan_of(2048, 512, nat.MODE_BF16)                       # the headline path at its smallest batch: pair kernel on the fragment-major copy
+    assert (lay.saved, lay.two_pass, lay.backward_kernel) == (1, 0, 3) and lay.xf != nat.STEP_NONE and lay.stash != nat.STEP_NONE
+    full = lay.total_bytes
+    plan_of(2048, 512, nat.MODE_BF16, flags=nat.STEP_NO_XFP)
+    assert lay.backward_kernel == 2
+    plan_of(2048, 512, nat.MODE_BF16, flags=nat.STEP_NO_XFP | nat.STEP_NO_XF)
+    assert lay.backward_kernel == 1 and lay.saved == 1
+    plan_of(1024, 512, nat.MODE_BF16)                       # below the row floor: the plain pair (LDS-staged saved backward)
+    assert (lay.saved, lay.backward_kernel) == (1, 1) and lay.xf == nat.STEP_NONE
+    plan_of(2048, 256, nat.MODE_BF16)
+    assert lay.backward_kernel == 1
+    plan_of(2048, 512, nat.MODE_BF16, flags=nat.STEP_NO_SAVE)
+    assert (lay.saved, lay.backward_kernel) == (0, 0) and lay.stash == nat.STEP_NONE and lay.total_bytes < full
+    small = lay.total_bytes
+    plan_of(2048, 512, nat.MODE_BF16, nbytes=full - 1)      # a workspace one byte short of the saving layout: the recomputing one
+    assert lay.saved == 0 and lay.total_bytes == small
+    plan = nat.make_plan(2048, 512, 1, 0, nat.MODE_BF16)
+    assert lib.crossclr_step_plan(ctypes.byref(plan), 0.05, 0.8, 0, small - 1, ctypes.byref(lay)) == -4      # CROSSCLR_E_WORKSPACE
+    plan_of(2048, 512, nat.MODE_BF16, flags=nat.STEP_FORWARD_ONLY)
+    assert lay.saved == 0 and lay.backward_scratch_bytes == 0
+    plan_of(2048, 512, nat.MODE_FP32, tau=0.004)            # two-pass regime, exact fp32: saves U and Ut
+    assert (lay.two_pass, lay.saved) == (1, 1) and lay.shift != nat.STEP_NONE
+    monkeypatch.setenv("CROSSCLR_MAX_STASH_GB", "0.001")
+    plan_of(2048, 512, nat.MODE_BF16)
+    assert lay.saved == 0
+    monkeypatch.delenv("CROSSCLR_MAX_STASH_GB")
+    monkeypatch.setenv("CROSSCLR_XF_WIDTHS", "256")
+    plan_of(256, 200, nat.MODE_BF16)
+    assert lay.backward_kernel == 3
+    plan = nat.make_plan(64, 32, 2, 0, nat.MODE_BF16)
+    assert lib.crossclr_step_plan(ctypes.byref(plan), 0.05, 0.8, 0, 0, ctypes.byref(lay)) == -1              # single device only
