@@ -819,7 +819,7 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
     return fwd_make_work(symmetric ? 1 : (pairs ? 3 : 2), p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
 }
 
-// the symmetric forward of whole batches (crossclr_kernels_symp.h: one unbroken MFMA stream per wave): Dpad <= 512, b a multiple of 128,
+// the symmetric forward of whole batches (crossclr_kernels_symp.h: one unbroken MFMA stream per wave): Dpad <= 1024, b a multiple of 128,
 // no sample weights, a stash below 4 GiB
 #ifndef CROSSCLR_DEF_FWDP
 int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, float* part, float* colpart, int* header,
@@ -837,13 +837,21 @@ CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const 
         if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm); \
         else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm);  \
     } while (0)
+#define CROSSCLR_LZW(DK)                                                                                                                         \
+    do {                                                                                                                                         \
+        if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true, 1, 2>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false, 1, 2>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm);  \
+    } while (0)
     switch (p->Dpad) {
         case 128: CROSSCLR_LZ(8); break;
         case 256: CROSSCLR_LZ(16); break;
         case 384: CROSSCLR_LZ(24); break;
         case 512: CROSSCLR_LZ(32); break;
+        case 768: CROSSCLR_LZW(24); break;      // wide operands: one 32-row half per wave, the tile in two ring stages
+        case 1024: CROSSCLR_LZW(32); break;
         default: return CROSSCLR_E_ARG;
     }
+#undef CROSSCLR_LZW
 #undef CROSSCLR_LZ
     return CROSSCLR_OK;
 }
@@ -885,8 +893,8 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
     // the same bits as the kernel below, CROSSCLR_FWD_PAIR=0 keeps that one: A/B)
     const char* pair_env = getenv("CROSSCLR_FWD_PAIR");      // (read per launch: the bit-identity tests flip it inside one process)
     const bool pair_kernel = !(pair_env && pair_env[0] == '0');
-    if (pair_kernel && kind == 1 && !sw && g.b == g.bpad && p->Dpad <= 512 && wk.tpr == 8) {
-        const size_t sbytes = st ? stash_tiles_total(8, 2 * p->bpad / 32) * 2048 : 0;
+    if (pair_kernel && kind == 1 && !sw && g.b == g.bpad && p->Dpad <= 1024 && wk.tpr == (p->Dpad <= 512 ? 8 : 4)) {
+        const size_t sbytes = st ? stash_tiles_total(wk.tpr, 2 * p->bpad / 32) * 2048 : 0;
         if (sbytes < ((size_t)1 << 32) && (size_t)wk.NB * wk.NT * 128 < ((size_t)1 << 32))
             return fast_forward_pair(p, g, wk, rows, part, colpart, header, stash, sbytes, perm, stream);
     }

@@ -1,4 +1,4 @@
-// crossclr_kernels_symp.h -- the symmetric forward of the local block (Dpad <= 512, whole 128-row batches, no sample weights), rebuilt
+// crossclr_kernels_symp.h -- the symmetric forward of the local block (Dpad <= 1024, whole 128-row batches, no sample weights), rebuilt
 // around ONE unbroken MFMA stream per wave.
 //
 // Same math, same work list, same workspace / stash layout and the same summation order as fast_fwd_pipe_kernel<DK, 1, false, ST>
@@ -27,7 +27,7 @@
 //
 // Tiles that need a mask (the TPR tiles of a row block's own diagonal block) run the bare MFMA stream and a plain epilogue behind it; the last
 // tile of a segment (a maximal run of one row block's tiles inside the thread block's range) is finished the same way.  Everything else --
-// ragged batches, padding rows, sample weights, rectangular / pair launches, Dpad > 512 -- stays with fast_fwd_pipe_kernel.
+// ragged batches, padding rows, sample weights, rectangular / pair launches -- stays with fast_fwd_pipe_kernel.
 #pragma once
 
 namespace crossclr {
@@ -110,24 +110,35 @@ struct FwdReadPlan {
     static constexpr int flush_seq(int DK) { return reads_before(DK, kb(DK)) + 1; }
 };
 
-template <int DK, bool ST>
+// DK = k-steps of 16 embedding columns per ring STAGE, KS = stages per column tile (Dpad = 16 DK KS), NH = 32-row halves per wave:
+//   Dpad <= 512:        <DK = Dpad / 16, ST, 2, 1>   256-row blocks, one MFMA pair per LDS read, a tile = one stage
+//   512 < Dpad <= 1024: <DK = Dpad / 32, ST, 1, 2>   128-row blocks (the fragments of 64 rows x 1024 columns would not fit the register file); a
+//                       64-KiB tile would leave room for two ring stages only, so the tile travels as TWO stages of half its embedding columns:
+//                       the ring, the barrier, the DMA and the fragment reads run per stage exactly as below, the accumulators run through
+//                       both stages and the epilogue of the previous tile is dealt over the 2 DK MFMA slots of both.
+template <int DK, bool ST, int NH = 2, int KS = 1>
 __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, Geo g, FwdWork wk, float* part, float* colpart, int* header,
                                                                unsigned char* stash, unsigned stash_bytes, FwdPerm perm) {
-    constexpr int RB = DK * 32;            // bytes per operand row
+    constexpr int RB = DK * 32;            // bytes per row of a ring stage
+    constexpr int RBG = KS * RB;           // bytes per operand row in memory
     constexpr int QT = 32;
-    constexpr int TILE = QT * RB;
-    constexpr int TPR = 8;                 // 32-row groups per row block
-    constexpr int RBLK = 256;
+    constexpr int TILE = QT * RB;          // bytes of a ring stage
+    constexpr int TILEG = QT * RBG;        // bytes of a column tile in memory
+    constexpr int TPR = 4 * NH;            // 32-row groups per row block
+    constexpr int RW = 32 * NH;            // rows per wave
+    constexpr int RBLK = 4 * RW;
     constexpr int NST = 4;
-    constexpr int NXO = DK / 4;            // DMA pieces per wave and tile
+    constexpr int NXO = DK / 4;            // DMA pieces per wave and stage
     constexpr int PF = FwdReadPlan::PF;
-    constexpr int H = 2 * DK, H1 = H / 2, H2 = 3 * H / 4;     // MFMA slots of a tile: exp + row sums | sums of halves, pack, stash | butterfly
+    constexpr int SPS = DK * NH;           // MFMA slots of a step (= a stage)
+    constexpr int H = SPS * KS, H1 = H / 2, H2 = 3 * H / 4;     // MFMA slots of a tile: exp + row sums | sums of halves, pack, stash | butterfly
+    static_assert((NH == 2 && KS == 1) || (NH == 1 && KS == 2), "256-row blocks with whole tiles, or 128-row blocks with the tile in two stages");
     constexpr int KB = FwdReadPlan::kb(DK);      // the k-step the barrier sits in front of
     // DMA pieces behind the barrier: every second k-step from KB + 1 on where that fits, else one per k-step from KB on
     constexpr int DSTRIDE = (KB + 1 + 2 * (NXO - 1) < DK) ? 2 : 1, DK0 = DSTRIDE == 2 ? KB + 1 : KB;
     static_assert(KB % 2 == 0 && KB + 2 < DK && DK0 + DSTRIDE * (NXO - 1) < DK && PF % 2 == 0 && PF >= 4 && PF <= DK - 2, "schedule constants");
     constexpr int CS0 = NST * TILE;        // two column-sum slots [4 waves][32] floats, then a dump slot for the lanes that publish nothing
-    static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512}");
+    static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512} (KS = 1) / {768, 1024} (KS = 2)");
     static_assert(NST * TILE + 2 * 4 * QT * 4 + 256 <= 160 * 1024, "LDS budget");
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[CS0 + 2 * 4 * QT * 4 + 256];
 
@@ -144,7 +155,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     if (w >= w_end) return;
 
     // ---- descriptors and per-lane offsets ----
-    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * RB));
+    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * RBG));
     const BufRsrc rs_st = make_rsrc(stash, stash_bytes);
     const BufRsrc rs_cp = make_rsrc(colpart, (unsigned)((size_t)wk.NB * NT * QT * 4));
     unsigned voffx[NXO];
@@ -152,7 +163,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     for (int k = 0; k < NXO; ++k) {
         const int L = (wave + 4 * k) * 1024 + lane * 16;
         const int row = L / RB, slot = (L - row * RB) >> 4;
-        voffx[k] = (unsigned)(row * RB + (swz_slot(slot, row) << 4));
+        voffx[k] = (unsigned)(row * RBG + (swz_slot(slot, row) << 4));
     }
     int off8[8];  // byte offset of logical chunk (2j + half) of this lane's tile row
 #pragma unroll
@@ -164,7 +175,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     const unsigned st_voff = (unsigned)(lane * 16);
 
     // ---- DMA cursor: item w + 3 ahead of the compute cursor after the prologue ----
-    int d_rb, d_mt, d_left;
+    int d_rb, d_mt, d_left, d_kh = 0;             // (d_kh: which stage of the tile goes out next, KS = 2)
     {
         int rb = 0;
         while (fwd_prefix(wk, rb + 1) <= w) ++rb;
@@ -175,12 +186,14 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     }
     int rb = d_rb, j = d_mt - TPR * d_rb;        // compute cursor: row block, tile inside its list (column tile = TPR rb + j)
     unsigned dstage = 0;                          // LDS byte offset of the stage the next DMA fills
-    auto dma_tile = [&]() { return (unsigned)(d_mt < NT - 1 ? d_mt : NT - 1) * (unsigned)TILE; };
+    auto dma_tile = [&]() { return (unsigned)(d_mt < NT - 1 ? d_mt : NT - 1) * (unsigned)TILEG + (unsigned)(d_kh * RB); };
     auto ring_next = [&](unsigned o) {            // next stage of the ring (a power of two of bytes except at DK = 24)
         if constexpr ((NST * TILE & (NST * TILE - 1)) == 0) return (o + (unsigned)TILE) & (unsigned)(NST * TILE - 1);
         else { const unsigned nx = o + (unsigned)TILE; return nx == (unsigned)(NST * TILE) ? 0u : nx; }
     };
     auto dma_advance = [&]() {
+        dstage = ring_next(dstage);
+        if (KS == 2) { d_kh ^= 1; if (d_kh) return; }      // (the tile's second stage follows)
         ++d_mt;
         if (--d_left == 0) {
             ++d_rb;
@@ -188,13 +201,12 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             d_left = NT - d_mt;
             if (d_left <= 0) d_left = 1 << 30;   // past the last row block: clamped re-fetches of the last tile, never consumed
         }
-        dstage = ring_next(dstage);
     };
     auto issue_piece = [&](int k, unsigned tile_off, unsigned stage_off) {
         if (CROSSCLR_ZABL & 4) return;
         lds_dma16_buf(rs_x, voffx[k], tile_off, lds + stage_off + (wave + 4 * k) * 1024);
     };
-    // prologue: tiles of items w, w + 1, w + 2 into stages 0, 1, 2
+    // prologue: the first three stages of the range (KS = 1: the tiles of items w, w + 1, w + 2)
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) {
         const unsigned to = dma_tile();
@@ -204,10 +216,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     }
 
     // ---- per-segment state ----
-    float rowacc[2] = {0.f, 0.f};
-    bf16x8 pf[2][DK];
+    float rowacc[NH];
+    bf16x8 pf[NH][DK * KS];
     int row0w = 0, rmod = 0;
-    unsigned st_soff[2] = {0u, 0u};               // stash byte offset of the CURRENT tile's records, per 32-row half
+    unsigned st_soff[NH];                         // stash byte offset of the CURRENT tile's records, per 32-row half
     // ---- published column sums waiting for their flush ----
     int pend = 0;                                 // 1: cs[pbuf] holds the sums of colpart row pend_soff
     unsigned pbuf = 0, pend_soff = 0;
@@ -218,7 +230,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     struct Bits8 { bf16_t v[8]; };
     auto store_rows = [&]() {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NH; ++s) {
             const float v = rowacc[s] + wave_xor_f32(rowacc[s], 32);
             if (half == 0) part[(size_t)(vb - fwd_first_block(wk, rb)) * 2 * g.bpad + row0w + 32 * s + l31] = v;
         }
@@ -248,7 +260,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         }
     };
     // plain (not overlapped) epilogue of the tile in `acc`: jt = its index in the row block's list, soff = its stash offsets
-    auto epilogue_plain = [&](f32x16 (&acc)[2], int jt) __attribute__((always_inline)) {
+    auto epilogue_plain = [&](f32x16 (&acc)[NH], int jt) __attribute__((always_inline)) {
         mfma_results_visible();
         const int mt = TPR * rb + jt;
         const float c2s = ((mt >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
@@ -258,11 +270,11 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) es[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NH; ++s) {
             float xx[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) xx[r] = acc[s][r] * c2s - g.m2;
-            if (jt == 2 * wave + s) {              // the tile that holds this half's self pairs
+            if (jt == NH * wave + s) {             // the tile that holds this half's self pairs
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (frag_row(r, half) == l31) xx[r] = ninf;
@@ -277,9 +289,9 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         if (upper) publish(halving_sum16(es, l31), (unsigned)((rb * NT + mt) * (QT * 4)));
     };
 
-    // ---- one tile: 2 DK MFMAs into accC; MODE 1: the epilogue of the previous tile (accP, index jt - 1) in their shadow ----
-    auto step = [&](auto modec, f32x16 (&accC)[2], f32x16 (&accP)[2], int jt) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(modec)::value;
+    // ---- one stage: NH DK MFMAs into accC (stage KH of tile jt); MODE 1: the epilogue of the previous tile (accP, index jt - 1) in their shadow ----
+    auto step = [&](auto modec, auto khc, f32x16 (&accC)[NH], f32x16 (&accP)[NH], int jt) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(modec)::value, KH = decltype(khc)::value;
         constexpr bool EPI = MODE == 1 && !(CROSSCLR_ZABL & 1);
         const unsigned nstage = ring_next(cstage);
         const auto xa = lds_addr(lds + cstage);
@@ -295,7 +307,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         // the owed tile (MODE 1)
         const int mtp = TPR * rb + jt - 1;
         const float c2s = ((mtp >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
-        const unsigned so0 = st_soff[0] + 2048u * (unsigned)(jt - 1), so1 = st_soff[1] + 2048u * (unsigned)(jt - 1);
+        const unsigned so0 = st_soff[0] + 2048u * (unsigned)(jt - 1), so1 = st_soff[NH - 1] + 2048u * (unsigned)(jt - 1);
         float es[16], k8[8], k4[4], k2[2], sa[15], sb[15];
         // the pending publication (flushed behind this step's barrier)
         const auto fa = lds_addr(lds + CS0 + (pbuf ? 4 * QT * 4 : 0) + l31 * 4);
@@ -325,19 +337,19 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                 // exp of element idx, then the row-sum add of element idx - 1 (a transcendental's result costs a wait state when it is used
                 // by the very next instruction; the adds keep their order r = 0 .. 15 per half: the same bits as the plain epilogue)
 #pragma unroll
-                for (int idx = (32 * h) / H1; idx < (32 * (h + 1)) / H1; ++idx) {
+                for (int idx = (16 * NH * h) / H1; idx < (16 * NH * (h + 1)) / H1; ++idx) {
                     const int s = idx >> 4, r = idx & 15;
                     accP[s][r] = fast_exp2(accP[s][r] * c2s - g.m2);
                     if (idx > 0) { rowacc[(idx - 1) >> 4] += accP[(idx - 1) >> 4][(idx - 1) & 15]; pin_v(rowacc[(idx - 1) >> 4]); }
                 }
             } else if constexpr (h < H2) {
                 constexpr int n = H2 - H1, i = h - H1;
-                if constexpr (h == H1) { rowacc[1] += accP[1][15]; pin_v(rowacc[1]); }
+                if constexpr (h == H1) { rowacc[NH - 1] += accP[NH - 1][15]; pin_v(rowacc[NH - 1]); }
 #pragma unroll
-                for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = accP[0][r] + accP[1][r];
+                for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = NH == 2 ? accP[0][r] + accP[NH - 1][r] : accP[0][r];
                 if (ST && !(CROSSCLR_ZABL & 2)) {
 #pragma unroll
-                    for (int f = (4 * i) / n; f < (4 * (i + 1)) / n; ++f) {
+                    for (int f = (2 * NH * i) / n; f < (2 * NH * (i + 1)) / n; ++f) {
                         const int s = f >> 1, th = f & 1;
                         Bits8 pk;
 #pragma unroll
@@ -427,7 +439,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                 f23 = lds_read2_b32_async<2 * QT, 3 * QT>(fa);
             }
             const bf16x8 a = __builtin_bit_cast(bf16x8, fr[k]);
-            if constexpr (k == 0) mfma_first_va(accC[0], a, pf[0][k]); else mfma_va(accC[0], a, pf[0][k]);
+            constexpr int kp = KH * DK + k;          // the k-step inside the row fragments
+            if constexpr (kp == 0) mfma_first_va(accC[0], a, pf[0][kp]); else mfma_va(accC[0], a, pf[0][kp]);
             // ---- this k-step's fragment reads
             static_for<DK>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -438,11 +451,11 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                 const f32x2 c01 = __builtin_bit_cast(f32x2, f01), c23 = __builtin_bit_cast(f32x2, f23);
                 buf_store4(rs_cp, f_voff, f_soff, (c01[0] + c01[1]) + (c23[0] + c23[1]));
             }
-            chore(IdxC<2 * k>{});
+            chore(IdxC<KH * SPS + NH * k>{});
             sched_fence();
-            if constexpr (k == 0) mfma_first_va(accC[1], a, pf[1][k]); else mfma_va(accC[1], a, pf[1][k]);
+            if constexpr (NH == 2) { if constexpr (kp == 0) mfma_first_va(accC[NH - 1], a, pf[NH - 1][kp]); else mfma_va(accC[NH - 1], a, pf[NH - 1][kp]); }
             if constexpr (k >= DK0 && (k - DK0) % DSTRIDE == 0 && (k - DK0) / DSTRIDE < NXO) issue_piece((k - DK0) / DSTRIDE, d_to, d_so);
-            chore(IdxC<2 * k + 1>{});
+            if constexpr (NH == 2) chore(IdxC<KH * SPS + NH * k + 1>{});
             sched_fence();
         });
         // every read of the step is complete (all were issued >= 4 k-steps ago): the next tile's first fragments may cross the back edge
@@ -452,16 +465,21 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
 #pragma unroll
         for (int q = 0; q < PF; ++q) nx[q] = nn[q];
         pend = 0;
-        if constexpr (EPI) {
+        if constexpr (EPI && KH == KS - 1) {
             if (!(CROSSCLR_ZABL & 64)) publish(k2[0], (unsigned)((rb * NT + mtp) * (QT * 4)));
-        } else if constexpr (MODE == 1) {
-            rowacc[0] += accP[0][0] + accP[1][1];      // (ablation: keeps the previous tile's MFMAs alive)
+        } else if constexpr (MODE == 1 && KH == KS - 1) {
+            rowacc[0] += accP[0][0] + accP[NH - 1][1];      // (ablation: keeps the previous tile's MFMAs alive)
         }
         dma_advance();
         cstage = nstage;
     };
 
-    f32x16 accA[2], accB[2];
+    // a tile = KS stages
+    auto tile = [&](auto modec, f32x16 (&accC)[NH], f32x16 (&accP)[NH], int jt) __attribute__((always_inline)) {
+        step(modec, IdxC<0>{}, accC, accP, jt);
+        if constexpr (KS == 2) step(modec, IdxC<1>{}, accC, accP, jt);
+    };
+    f32x16 accA[NH], accB[NH];
     timing_mark(1);
     bool primed = false;
     while (w < w_end) {
@@ -469,15 +487,15 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         int n = NT - TPR * rb - j;
         if (n > w_end - w) n = w_end - w;
         w += n;
-        row0w = rb * RBLK + 64 * wave;
+        row0w = rb * RBLK + RW * wave;
         rmod = uniform(row0w / g.bpad);
-        rowacc[0] = rowacc[1] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (ST) st_soff[s] = (unsigned)(stash_tile_index(TPR, NT, TPR * rb + 2 * wave + s, TPR * rb) * 2048);
-            const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * 16) + 8 * half;
+        for (int s = 0; s < NH; ++s) {
+            rowacc[s] = 0.f;
+            st_soff[s] = ST ? (unsigned)(stash_tile_index(TPR, NT, TPR * rb + NH * wave + s, TPR * rb) * 2048) : 0u;
+            const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * KS * 16) + 8 * half;
 #pragma unroll
-            for (int k = 0; k < DK; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
+            for (int k = 0; k < DK * KS; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
         }
         wait_loads_visible();
         if (!primed) {
@@ -494,7 +512,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         // phase 1: masked tiles one by one, up to and including the first tile that can stay owed (set A)
         bool owedA = false;
         while (n > 0) {
-            step(IdxC<0>{}, accA, accB, j);
+            tile(IdxC<0>{}, accA, accB, j);
             ++j; --n;
             if (j - 1 < TPR) epilogue_plain(accA, j - 1);
             else { owedA = true; break; }
@@ -502,10 +520,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         // phase 2: pairs -- (B while A's epilogue runs), (A while B's epilogue runs)
         bool owedB = false;
         while (n > 0) {
-            step(IdxC<1>{}, accB, accA, j);
+            tile(IdxC<1>{}, accB, accA, j);
             ++j; --n;
             if (n == 0) { owedA = false; owedB = true; break; }
-            step(IdxC<1>{}, accA, accB, j);
+            tile(IdxC<1>{}, accA, accB, j);
             ++j; --n;
         }
         // the segment's last tile: an earlier publication may still wait for its barrier -- flush it, then finish the tile in the open

@@ -20,7 +20,8 @@ def _step(crit, v, t, grad=True):
     return loss.item(), vv.grad.clone(), tt.grad.clone()
 
 
-SHAPES = [(128, 128), (256, 100), (384, 256), (512, 384), (1024, 512), (1152, 200), (2048, 512), (4096, 384), (8192, 512), (3200, 512)]
+SHAPES = [(128, 128), (256, 100), (384, 256), (512, 384), (1024, 512), (1152, 200), (2048, 512), (4096, 384), (8192, 512), (3200, 512),
+          (128, 1024), (384, 600), (1024, 768), (2048, 1024), (8192, 1024), (4224, 900)]      # wide operands: the tile in two ring stages
 
 
 @pytest.mark.parametrize("B,D", SHAPES)
