@@ -42,12 +42,12 @@ class SampleWeights(ctypes.Structure):
 class StepLayout(ctypes.Structure):
     """crossclr_step_layout: what crossclr_step_plan decided for one step and where the pieces live in its workspace."""
     _fields_ = [("total_bytes", ctypes.c_size_t), ("backward_scratch_bytes", ctypes.c_size_t)] + \
-               [(n, ctypes.c_size_t) for n in ("xhat", "inv_norm", "diag", "logz", "rz", "wrz", "part", "shift", "xf", "stash", "ticket")] + \
+               [(n, ctypes.c_size_t) for n in ("xhat", "inv_norm", "diag", "logz", "rz", "wrz", "part", "shift", "xf", "stash", "gbuf", "ticket")] + \
                [("stash_bytes", ctypes.c_size_t), ("xf_bytes", ctypes.c_size_t),
                 ("two_pass", ctypes.c_int), ("saved", ctypes.c_int), ("backward_kernel", ctypes.c_int)]
 
 
-STEP_NO_SAVE, STEP_FORWARD_ONLY, STEP_PRENORMALIZED, STEP_NO_XFP, STEP_NO_XF = 1, 2, 4, 8, 16
+STEP_NO_SAVE, STEP_FORWARD_ONLY, STEP_PRENORMALIZED, STEP_NO_XFP, STEP_NO_XF, STEP_EAGER = 1, 2, 4, 8, 16, 32
 STEP_NONE = ctypes.c_size_t(-1).value
 
 

@@ -230,7 +230,11 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
         plan->bwd_slices = sl;
     }
     {
-        int nb = (2 * plan->bpad + 63) / 64;      // finish kernels: 64 rows per block (four lanes per row), grid-stride beyond
+#ifndef CROSSCLR_FINISH_LPR
+#define CROSSCLR_FINISH_LPR 4
+#endif
+        const int rows_per_block = 256 / CROSSCLR_FINISH_LPR;
+        int nb = (2 * plan->bpad + rows_per_block - 1) / rows_per_block;      // finish kernels: 256 / LPR rows per block, grid-stride beyond
         if (nb > 1024) nb = 1024;
         plan->loss_ws_doubles = 1 + nb;
     }
@@ -1737,10 +1741,12 @@ extern "C" int crossclr_step_plan(const crossclr_plan* plan, float temperature, 
         L->shift = two_pass ? take(4 * n2) : CROSSCLR_STEP_NONE;
         L->xf = xf ? take(plan->xf_bytes) : CROSSCLR_STEP_NONE;
         L->stash = saved ? take(stash_full) : CROSSCLR_STEP_NONE;
+        const bool eager = (flags & CROSSCLR_STEP_EAGER) && !(flags & CROSSCLR_STEP_FORWARD_ONLY);
+        L->gbuf = eager ? take(plan->gbuf_bytes) : CROSSCLR_STEP_NONE;
         L->xf_bytes = xf ? plan->xf_bytes : 0;
         L->stash_bytes = saved ? stash_full : 0;
         L->total_bytes = off;
-        L->backward_scratch_bytes = (flags & CROSSCLR_STEP_FORWARD_ONLY) ? 0 : plan->gbuf_bytes;
+        L->backward_scratch_bytes = ((flags & CROSSCLR_STEP_FORWARD_ONLY) || eager) ? 0 : plan->gbuf_bytes;
         L->two_pass = two_pass ? 1 : 0;
         L->saved = saved ? 1 : 0;
         L->backward_kernel = 0;
@@ -1767,6 +1773,8 @@ struct StepBufs {
     void* v(size_t off) const { return off == CROSSCLR_STEP_NONE ? nullptr : static_cast<void*>(w + off); }
 };
 }  // namespace
+static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, float temperature, float negative_weight, const float* k,
+                                 float* gbuf, void* stream);
 
 extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
                                      float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
@@ -1799,23 +1807,48 @@ extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* vide
         rc = L.saved ? crossclr_forward_save_s(plan, B.xhat(), temperature, negative_weight, pk, B.f(L.shift), B.f(L.part), 0, B.v(L.stash), stream)
                      : crossclr_forward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, pk, B.f(L.shift), B.f(L.part), 0, stream);
         if (rc) return rc;
-        return forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, B.f(L.shift),
-                                   B.f(L.logz), B.f(L.rz), B.f(L.wrz), loss_ws, stream, ticket);
+        rc = forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, B.f(L.shift),
+                                 B.f(L.logz), B.f(L.rz), B.f(L.wrz), loss_ws, stream, ticket);
+        if (rc || L.gbuf == CROSSCLR_STEP_NONE) return rc;
+        return step_gradient_product(plan, B, temperature, negative_weight, k, B.f(L.gbuf), stream);
     }
     // loss.py:83-100, 59-60: soft-max denominators of the local block (and, saving, its exponentials)
     rc = L.saved ? crossclr_forward_save(plan, B.xhat(), temperature, negative_weight, pk, B.f(L.part), 0, B.v(L.stash), stream)
                  : crossclr_forward_w(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, pk, B.f(L.part), 0, stream);
     if (rc) return rc;
     // loss.py:60 (-log), :111-114
-    return forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, nullptr, B.f(L.logz), B.f(L.rz),
-                               B.f(L.wrz), loss_ws, stream, ticket);
+    rc = forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, nullptr, B.f(L.logz), B.f(L.rz),
+                             B.f(L.wrz), loss_ws, stream, ticket);
+    if (rc || L.gbuf == CROSSCLR_STEP_NONE) return rc;
+    return step_gradient_product(plan, B, temperature, negative_weight, k, B.f(L.gbuf), stream);      // CROSSCLR_STEP_EAGER
+}
+
+// autograd of loss.py:83-112: gbuf = d(loss)/d(unit rows), unscaled, in column slices (independent of grad_out)
+static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, float temperature, float negative_weight, const float* k,
+                                 float* gbuf, void* stream) {
+    const crossclr_step_layout& L = B.L;
+    const crossclr_sample_weights sw_k = {k, k, nullptr};
+    const crossclr_sample_weights* pk = k ? &sw_k : nullptr;
+    float *rz = B.f(L.rz), *wrz = B.f(L.wrz);
+    if (L.two_pass)
+        return L.saved ? crossclr_backward_saved_s(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream)
+                       : crossclr_backward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk,
+                                             B.f(L.shift), B.f(L.shift), gbuf, 0, stream);
+    if (L.saved) {
+        switch (L.backward_kernel) {
+            case 3: return crossclr_backward_saved_xfp(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream);
+            case 2: return crossclr_backward_saved_xf(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream);
+            default: return crossclr_backward_saved(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream);
+        }
+    }
+    return crossclr_backward_w(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk, gbuf, 0, stream);
 }
 
 extern "C" int crossclr_step_backward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
                                       float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
                                       void* workspace, size_t workspace_bytes, void* scratch, const double* grad_out,
                                       void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext, void* stream) {
-    if (!workspace || !scratch || !video || !text || !grad_out || !grad_video || !grad_text) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (!workspace || !video || !text || !grad_out || !grad_video || !grad_text) return fail(CROSSCLR_E_ARG, "NULL argument");
     if (flags & CROSSCLR_STEP_FORWARD_ONLY) return fail(CROSSCLR_E_ARG, "the forward of this step was declared CROSSCLR_STEP_FORWARD_ONLY");
     if (workspace_bytes == 0) return fail(CROSSCLR_E_WORKSPACE, "workspace_bytes must be the size given to crossclr_step_forward");
     StepBufs B;
@@ -1824,26 +1857,15 @@ extern "C" int crossclr_step_backward(const crossclr_plan* plan, const void* vid
     const crossclr_step_layout& L = B.L;
     const float* k = sw ? sw->neg_scale_rows : nullptr;
     const float* lw = sw ? sw->loss_weight : nullptr;
-    const crossclr_sample_weights sw_k = {k, k, nullptr}, sw_lw = {nullptr, nullptr, lw};
-    const crossclr_sample_weights* pk = k ? &sw_k : nullptr;
-    float* gbuf = static_cast<float*>(scratch);
-    float *rz = B.f(L.rz), *wrz = B.f(L.wrz);
-    int rc;
-    // autograd of loss.py:83-112: gbuf = d(loss)/d(unit rows), unscaled, in column slices
-    if (L.two_pass) {
-        rc = L.saved ? crossclr_backward_saved_s(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream)
-                     : crossclr_backward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk,
-                                           B.f(L.shift), B.f(L.shift), gbuf, 0, stream);
-    } else if (L.saved) {
-        switch (L.backward_kernel) {
-            case 3: rc = crossclr_backward_saved_xfp(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream); break;
-            case 2: rc = crossclr_backward_saved_xf(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream); break;
-            default: rc = crossclr_backward_saved(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream); break;
-        }
+    const crossclr_sample_weights sw_lw = {nullptr, nullptr, lw};
+    float* gbuf;
+    if (L.gbuf != CROSSCLR_STEP_NONE) {
+        gbuf = B.f(L.gbuf);                 // CROSSCLR_STEP_EAGER: the forward call enqueued the gradient product already
     } else {
-        rc = crossclr_backward_w(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk, gbuf, 0, stream);
+        if (!scratch) return fail(CROSSCLR_E_ARG, "scratch is NULL (layout.backward_scratch_bytes bytes)");
+        gbuf = static_cast<float*>(scratch);
+        if (int rc = step_gradient_product(plan, B, temperature, negative_weight, k, gbuf, stream)) return rc;
     }
-    if (rc) return rc;
     // autograd of loss.py:79-80 + the positive-pair term, x grad_out, in the input dtype
     return crossclr_backward_finish_p(plan, gbuf, video, text, ld_video, ld_text, in_dtype, B.f(L.inv_norm), temperature, lw ? &sw_lw : nullptr, grad_out,
                                       grad_video, grad_text, ld_gvideo, ld_gtext, (flags & CROSSCLR_STEP_PRENORMALIZED) ? 1 : 0, stream);

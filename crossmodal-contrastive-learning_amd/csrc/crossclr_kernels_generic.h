@@ -650,10 +650,16 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     CROSSCLR_SHARED int last_block;
     const int n = 2 * g.bpad;
     double acc = 0.0;
-    // FOUR lanes per row: lane q of a quad adds the terms k = q, q + 4, ... (independent loads, up to 16 rows of column sums and a
-    // few slots each instead of one chain of ~70), the quad combines in a fixed order -- (s0 + s1) + (s2 + s3) in every lane
-    const int q = threadIdx.x & 3;
-    for (int p = (blockIdx.x * 256 + threadIdx.x) >> 2; p < n; p += gridDim.x * 64) {
+    // LPR lanes per row: lane q of the group adds the terms k = q, q + LPR, ... (independent loads, fixed order), the group combines by a
+    // butterfly.  4 lanes: 10 us at B = 8192; 16 lanes (a quarter of the loads per lane, four times the blocks and the fp64 logs): 13-15 us
+    // (profiles/r05i_ab_finish_lpr.txt) -- the kernel is bound by its chain of dependent round trips (header -> sums -> log -> block sum),
+    // not by the loads per lane.
+#ifndef CROSSCLR_FINISH_LPR
+#define CROSSCLR_FINISH_LPR 4
+#endif
+    constexpr int LPR = CROSSCLR_FINISH_LPR;
+    const int q = threadIdx.x & (LPR - 1);
+    for (int p = (blockIdx.x * 256 + threadIdx.x) / LPR; p < n; p += gridDim.x * (256 / LPR)) {
         const int mod = p / g.bpad, i = p - mod * g.bpad;
         // shift of this row's sums (natural log): one value for the whole launch, or the row's own maximum (two-pass mode)
         const double shift = (row_shift ? (double)row_shift[p] : (double)g.m2) * (double)kLn2;
@@ -667,19 +673,20 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
             if (kind == 4) {          // generic symmetric launch: every slot is valid; column sums of the row blocks above
                 const int rb = p / (32 * tpr);
 #pragma unroll 4
-                for (int k = q; k < rb; k += 4) s += (double)colpart[(size_t)k * n + p];
+                for (int k = q; k < rb; k += LPR) s += (double)colpart[(size_t)k * n + p];
             } else if (kind != 0) {
                 const int rb = p / (32 * tpr);
                 count = fwdw_last_block(kind, tpr, NT, per, rb) - fwdw_first_block(kind, tpr, NT, per, rb) + 1;
                 if (kind == 1) {
 #pragma unroll 4
-                    for (int k = q; k < rb; k += 4) s += (double)colpart[(size_t)k * n + p];   // independent loads, fixed order
+                    for (int k = q; k < rb; k += LPR) s += (double)colpart[(size_t)k * n + p];   // independent loads, fixed order
                 }
             }
-            for (int k = q; k < count; k += 4) s += (double)base[(size_t)k * n + p];
+            for (int k = q; k < count; k += LPR) s += (double)base[(size_t)k * n + p];
         }
         s += wave_xor_f64(s, 1);
         s += wave_xor_f64(s, 2);
+        if (LPR > 4) { s += wave_xor_f64(s, 4); s += wave_xor_f64(s, 8); }
         s += krows ? self_term * (double)krows[p] : self_term;   // the masked self pair travels with its column
         const bool valid = i < g.b;
         const double lz = shift + log(s);

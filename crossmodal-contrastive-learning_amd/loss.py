@@ -556,6 +556,11 @@ def _forward_step(video, text, temperature, negative_w, plan, mode, negative_sca
     ws.k_cols = ws.k_rows
     ws.prenormalized = bool(prenormalized)
     flags = (nat.STEP_PRENORMALIZED if prenormalized else 0) | (0 if save_for_backward else nat.STEP_FORWARD_ONLY)
+    # With a backward to follow the forward call also enqueues the gradient product (it does not depend on grad_out): the GPU keeps working
+    # while the host walks from forward() to backward() -- autograd's thread hand-over -- and backward() is the finish kernel alone.
+    # CROSSCLR_EAGER_BACKWARD=0: the product is launched from backward(), as in rounds 1-4.
+    if save_for_backward and os.environ.get("CROSSCLR_EAGER_BACKWARD", "1") != "0":
+        flags |= nat.STEP_EAGER
     flags, lay = _step_flags(plan, flags, ws.temperature, ws.negative_w, ws.k_rows is not None, dev)
     try:
         slab = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
@@ -591,7 +596,7 @@ def _backward_step(ws, video, text, grad_out):
     plan = ws.plan
     dev = video.device
     flags, slab, nbytes, scratch_bytes = ws.step
-    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev) if scratch_bytes else None
     if grad_out.dtype == torch.float64 and grad_out.device == dev and grad_out.numel() == 1:
         go = grad_out.detach().reshape(1)
     else:

@@ -474,6 +474,10 @@ int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* g
 #define CROSSCLR_STEP_PRENORMALIZED 4u  /* the rows are unit vectors already (loss.py:79-80 skipped; gradients w.r.t. the unit rows) */
 #define CROSSCLR_STEP_NO_XFP 8u         /* do not take crossclr_backward_saved_xfp                                         */
 #define CROSSCLR_STEP_NO_XF 16u         /* do not take crossclr_backward_saved_xf either (LDS-staged saved backward)       */
+#define CROSSCLR_STEP_EAGER 32u         /* crossclr_step_forward ALSO enqueues the gradient product of the backward (it does not depend on grad_out: only the
+                                           finish kernel scales by it) into a gbuf region of the workspace; crossclr_step_backward is then the finish kernel
+                                           alone.  Same kernels, same results; the GPU does not idle while the host walks from forward() to backward()
+                                           (autograd's thread hand-over), and a second backward through the same step re-runs the finish only. */
 #define CROSSCLR_STEP_NONE ((size_t)-1) /* a layout offset that this step does not have                                    */
 
 typedef struct crossclr_step_layout {
@@ -481,6 +485,7 @@ typedef struct crossclr_step_layout {
     size_t backward_scratch_bytes;  /* bytes of crossclr_step_backward's `scratch` (the gradient slices, plan->gbuf_bytes) */
     /* byte offsets into `workspace` (256-byte aligned; CROSSCLR_STEP_NONE: not part of this step) */
     size_t xhat, inv_norm, diag, logz, rz, wrz, part, shift, xf, stash;
+    size_t gbuf;                    /* CROSSCLR_STEP_EAGER: the gradient slices live in the workspace (backward_scratch_bytes == 0)             */
     size_t ticket;                  /* one int: cleared by the step's first kernel, counts the finish kernel's blocks (its last block forms the loss) */
     size_t stash_bytes, xf_bytes;   /* sizes of xf and stash                                                           */
     int two_pass;                   /* 1: per-row soft-max shifts (small temperature)                                  */

@@ -87,3 +87,32 @@ def test_step_plan_reports_the_policy(monkeypatch):
     assert lay.backward_kernel == 3
     plan = nat.make_plan(64, 32, 2, 0, nat.MODE_BF16)
     assert lib.crossclr_step_plan(ctypes.byref(plan), 0.05, 0.8, 0, 0, ctypes.byref(lay)) == -1              # single device only
+
+
+@pytest.mark.parametrize("B,D,mode,tau", [(150, 32, "bf16", 0.05), (40, 24, "fp32", 0.05), (64, 32, "fp32", 0.004)])
+def test_eager_gradient_product_is_the_same_step(B, D, mode, tau, monkeypatch):
+    """CROSSCLR_STEP_EAGER (the module's default with a backward to follow): the forward call also enqueues the gradient product, backward()
+    runs the finish kernel alone -- same kernels, same bits; a second backward through the same graph re-runs the finish only."""
+    v, t = orc.make_inputs("randn", B, D, 5)
+
+    def step(twice=False):
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, tau, 0.8, compute_mode=mode)
+        loss.backward(retain_graph=twice)
+        if twice:
+            g1 = vv.grad.clone()
+            vv.grad = None
+            (3.0 * loss).backward()
+            assert torch.allclose(vv.grad, 3.0 * g1, rtol=1e-6, atol=0)
+            vv.grad = g1
+        return loss.item(), vv.grad, tt.grad
+    le, gve, gte = step()
+    lay = nat.StepLayout()
+    _, ws = L._forward_impl(v, t, tau, 0.8, mode, None, save_for_backward=True)
+    assert ws.step[0] & nat.STEP_EAGER and ws.step[3] == 0
+    step(twice=True)
+    monkeypatch.setenv("CROSSCLR_EAGER_BACKWARD", "0")
+    _, ws = L._forward_impl(v, t, tau, 0.8, mode, None, save_for_backward=True)
+    assert not (ws.step[0] & nat.STEP_EAGER) and ws.step[3] == ws.plan.gbuf_bytes
+    ll, gvl, gtl = step()
+    assert le == ll and torch.equal(gve, gvl) and torch.equal(gte, gtl)
