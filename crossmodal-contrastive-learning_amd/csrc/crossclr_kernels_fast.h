@@ -822,37 +822,39 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
 // the symmetric forward of whole batches (crossclr_kernels_symp.h: one unbroken MFMA stream per wave): Dpad <= 1024, b a multiple of 128,
 // no sample weights, a stash below 4 GiB
 #ifndef CROSSCLR_DEF_FWDP
-int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, float* part, float* colpart, int* header,
-                      void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream);
+int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols, float* part, float* colpart,
+                      int* header, int kind, void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream);
 #else
-CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, float* part, float* colpart,
-                                    int* header, void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream) {
+CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols, float* part,
+                                    float* colpart, int* header, int kind, void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream) {
     const bf16_t* r = (const bf16_t*)rows;
+    const bf16_t* c = (const bf16_t*)cols;
     unsigned char* st = (unsigned char*)stash;
     const unsigned sb = (unsigned)stash_bytes;
     dim3 grid(wk.nblk), block(256);
-    (void)r; (void)st; (void)sb; (void)grid; (void)block;
-#define CROSSCLR_LZ(DK)                                                                                                                    \
-    do {                                                                                                                                   \
-        if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm);  \
+    (void)r; (void)c; (void)st; (void)sb; (void)grid; (void)block;
+#define CROSSCLR_LZ3(DK, NH, KS, KIND)                                                                                                                   \
+    do {                                                                                                                                                 \
+        if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true, NH, KS, KIND>), grid, block, stream, r, c, g, wk, part, colpart, header, st, sb, perm); \
+        else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false, NH, KS, KIND>), grid, block, stream, r, c, g, wk, part, colpart, header, st, sb, perm);  \
     } while (0)
-#define CROSSCLR_LZW(DK)                                                                                                                         \
-    do {                                                                                                                                         \
-        if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true, 1, 2>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false, 1, 2>), grid, block, stream, r, g, wk, part, colpart, header, st, sb, perm);  \
+#define CROSSCLR_LZ(DK, NH, KS)                          \
+    do {                                                 \
+        if (kind == 1) CROSSCLR_LZ3(DK, NH, KS, 1);      \
+        else if (kind == 2) CROSSCLR_LZ3(DK, NH, KS, 2); \
+        else CROSSCLR_LZ3(DK, NH, KS, 3);                \
     } while (0)
     switch (p->Dpad) {
-        case 128: CROSSCLR_LZ(8); break;
-        case 256: CROSSCLR_LZ(16); break;
-        case 384: CROSSCLR_LZ(24); break;
-        case 512: CROSSCLR_LZ(32); break;
-        case 768: CROSSCLR_LZW(24); break;      // wide operands: one 32-row half per wave, the tile in two ring stages
-        case 1024: CROSSCLR_LZW(32); break;
+        case 128: CROSSCLR_LZ(8, 2, 1); break;
+        case 256: CROSSCLR_LZ(16, 2, 1); break;
+        case 384: CROSSCLR_LZ(24, 2, 1); break;
+        case 512: CROSSCLR_LZ(32, 2, 1); break;
+        case 768: CROSSCLR_LZ(24, 1, 2); break;      // wide operands: one 32-row half per wave, the tile in two ring stages
+        case 1024: CROSSCLR_LZ(32, 1, 2); break;
         default: return CROSSCLR_E_ARG;
     }
-#undef CROSSCLR_LZW
 #undef CROSSCLR_LZ
+#undef CROSSCLR_LZ3
     return CROSSCLR_OK;
 }
 #endif   // CROSSCLR_DEF_FWDP
@@ -893,10 +895,24 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
     // the same bits as the kernel below, CROSSCLR_FWD_PAIR=0 keeps that one: A/B)
     const char* pair_env = getenv("CROSSCLR_FWD_PAIR");      // (read per launch: the bit-identity tests flip it inside one process)
     const bool pair_kernel = !(pair_env && pair_env[0] == '0');
-    if (pair_kernel && kind == 1 && !sw && g.b == g.bpad && p->Dpad <= 1024 && wk.tpr == (p->Dpad <= 512 ? 8 : 4)) {
-        const size_t sbytes = st ? stash_tiles_total(wk.tpr, 2 * p->bpad / 32) * 2048 : 0;
-        if (sbytes < ((size_t)1 << 32) && (size_t)wk.NB * wk.NT * 128 < ((size_t)1 << 32))
-            return fast_forward_pair(p, g, wk, rows, part, colpart, header, stash, sbytes, perm, stream);
+    if (pair_kernel && !sw && g.b == g.bpad && p->Dpad <= 1024 && wk.tpr == (p->Dpad <= 512 ? 8 : 4)) {
+        // rectangular / pair launches: only over OTHER ranks' columns (a launch that contains the rows' own rank needs the self-pair masks)
+        bool own = false;
+        if (kind != 1) {
+            const int W = g.col_wrap;
+            for (int i = 0; i < g.col_ranks; ++i) {
+                if (kind == 2 && g.col_rank0 + i == g.skip_rank) continue;
+                int rk = g.col_rank0 + i;
+                if (W > 0 && rk >= W) rk -= W;
+                own = own || rk == g.row_rank;
+            }
+        }
+        const size_t per_rank = (size_t)(2 * p->bpad / 32);
+        const size_t sbytes = !st ? 0 : (kind == 1 ? stash_tiles_total(wk.tpr, 2 * p->bpad / 32) * 2048 : per_rank * (size_t)wk.NT * 2048);
+        const size_t col_segs = kind == 1 ? 1 : (size_t)(g.col_wrap > 0 ? g.col_wrap : g.col_ranks);
+        if (!own && sbytes < ((size_t)1 << 32) && (size_t)wk.NB * wk.NT * 128 < ((size_t)1 << 32) &&
+            col_segs * 2 * p->bpad * p->Dpad * 2 < ((size_t)1 << 32))
+            return fast_forward_pair(p, g, wk, rows, cols, part, colpart, header, kind, stash, sbytes, perm, stream);
     }
 #define CROSSCLR_LP3(DK, KIND, SW, ST) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st, perm)

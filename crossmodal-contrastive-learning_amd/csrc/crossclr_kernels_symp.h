@@ -116,9 +116,16 @@ struct FwdReadPlan {
 //                       64-KiB tile would leave room for two ring stages only, so the tile travels as TWO stages of half its embedding columns:
 //                       the ring, the barrier, the DMA and the fragment reads run per stage exactly as below, the accumulators run through
 //                       both stages and the epilogue of the previous tile is dealt over the 2 DK MFMA slots of both.
-template <int DK, bool ST, int NH = 2, int KS = 1>
-__global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, Geo g, FwdWork wk, float* part, float* colpart, int* header,
-                                                               unsigned char* stash, unsigned stash_bytes, FwdPerm perm) {
+// KIND (the work lists of crossclr_device.h / crossclr_kernels_sym.h):
+//   1  symmetric local block (rows = columns = x): upper triangle, the row block's own TPR diagonal tiles masked, column sums for the rest
+//   2  rectangular: this rank's rows against OTHER ranks' columns (xc = their segments; the host keeps launches that would contain the
+//      rows' own rank with fast_fwd_pipe_kernel) -- no masks at all, no column sums; ST: the rectangular stash of crossclr_forward_rect_save
+//   3  pairs: rectangular, and every tile also yields its column sums over this rank's rows (what the partner rank is owed)
+template <int DK, bool ST, int NH = 2, int KS = 1, int KIND = 1>
+__global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, const bf16_t* xc, Geo g, FwdWork wk, float* part, float* colpart,
+                                                               int* header, unsigned char* stash, unsigned stash_bytes, FwdPerm perm) {
+    static_assert(KIND >= 1 && KIND <= 3, "1 symmetric, 2 rectangular, 3 pairs");
+    constexpr bool CSUM = KIND != 2;       // column sums are formed (KIND 1: right of the diagonal block)
     constexpr int RB = DK * 32;            // bytes per row of a ring stage
     constexpr int RBG = KS * RB;           // bytes per operand row in memory
     constexpr int QT = 32;
@@ -147,7 +154,16 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     timing_mark(0);
     if (blockIdx.x == 0 && tid == 0) { header[0] = wk.kind; header[1] = TPR; header[2] = wk.NT; header[3] = wk.per; }
     const int NT = wk.NT;
-    const int per_mod = g.bpad / QT;
+    const int per_mod = g.bpad / QT, per_rank = 2 * per_mod;
+    // rectangular launches: usable segment u of the column operand -> the rank segment it lives in (crossclr_kernels_sym.h: skipped rank,
+    // col_wrap = W: the operand is the whole gathered array and segment i is rank (col_rank0 + i) mod W)
+    const int skip_seg = (KIND == 2 && g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks) ? g.skip_rank - g.col_rank0 : -1;
+    const int col_segs = KIND == 1 ? 1 : (g.col_wrap > 0 ? g.col_wrap : g.col_ranks);
+    auto seg_mem = [&](int u) {            // memory segment of usable segment u
+        int r = u + ((skip_seg >= 0 && u >= skip_seg) ? 1 : 0);
+        if (g.col_wrap > 0) { r += g.col_rank0; if (r >= g.col_wrap) r -= g.col_wrap; }
+        return r;
+    };
 
     const int vb = uniform(blockIdx.x < 256 ? (int)perm.v[blockIdx.x < 256 ? blockIdx.x : 0] : (int)blockIdx.x);
     int w = fwd_block_begin(wk, vb);
@@ -155,7 +171,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     if (w >= w_end) return;
 
     // ---- descriptors and per-lane offsets ----
-    const BufRsrc rs_x = make_rsrc(x, (unsigned)((size_t)2 * g.bpad * RBG));
+    const BufRsrc rs_x = make_rsrc(KIND == 1 ? x : xc, (unsigned)((size_t)col_segs * 2 * g.bpad * RBG));
     const BufRsrc rs_st = make_rsrc(stash, stash_bytes);
     const BufRsrc rs_cp = make_rsrc(colpart, (unsigned)((size_t)wk.NB * NT * QT * 4));
     unsigned voffx[NXO];
@@ -175,18 +191,24 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     const unsigned st_voff = (unsigned)(lane * 16);
 
     // ---- DMA cursor: item w + 3 ahead of the compute cursor after the prologue ----
-    int d_rb, d_mt, d_left, d_kh = 0;             // (d_kh: which stage of the tile goes out next, KS = 2)
+    // KIND 1: d_mt = the column tile itself (row block d_rb owns tiles TPR d_rb .. NT - 1).  Rectangular: d_u = usable segment, d_mt = tile
+    // inside the segment (every row block owns all NT usable tiles); d_left = tiles left in the DMA cursor's row block.
+    int d_rb, d_mt, d_left, d_u = 0, d_kh = 0;    // (d_kh: which stage of the tile goes out next, KS = 2)
+    int rb, j;                                    // compute cursor: row block, tile inside its list
     {
-        int rb = 0;
-        while (fwd_prefix(wk, rb + 1) <= w) ++rb;
-        const int j0 = w - fwd_prefix(wk, rb);
-        d_rb = rb;
-        d_mt = TPR * rb + j0;
-        d_left = NT - d_mt;
+        int r0 = 0;
+        if (KIND == 1) { while (fwd_prefix(wk, r0 + 1) <= w) ++r0; } else r0 = w / NT;
+        const int j0 = w - fwd_prefix(wk, r0);
+        d_rb = rb = r0;
+        j = j0;
+        if (KIND == 1) { d_mt = TPR * r0 + j0; d_left = NT - d_mt; }
+        else { d_u = j0 / per_rank; d_mt = j0 - d_u * per_rank; d_left = NT - j0; }
     }
-    int rb = d_rb, j = d_mt - TPR * d_rb;        // compute cursor: row block, tile inside its list (column tile = TPR rb + j)
     unsigned dstage = 0;                          // LDS byte offset of the stage the next DMA fills
-    auto dma_tile = [&]() { return (unsigned)(d_mt < NT - 1 ? d_mt : NT - 1) * (unsigned)TILEG + (unsigned)(d_kh * RB); };
+    auto dma_tile = [&]() {
+        const int mt = KIND == 1 ? (d_mt < NT - 1 ? d_mt : NT - 1) : seg_mem(d_u) * per_rank + d_mt;
+        return (unsigned)mt * (unsigned)TILEG + (unsigned)(d_kh * RB);
+    };
     auto ring_next = [&](unsigned o) {            // next stage of the ring (a power of two of bytes except at DK = 24)
         if constexpr ((NST * TILE & (NST * TILE - 1)) == 0) return (o + (unsigned)TILE) & (unsigned)(NST * TILE - 1);
         else { const unsigned nx = o + (unsigned)TILE; return nx == (unsigned)(NST * TILE) ? 0u : nx; }
@@ -195,11 +217,16 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         dstage = ring_next(dstage);
         if (KS == 2) { d_kh ^= 1; if (d_kh) return; }      // (the tile's second stage follows)
         ++d_mt;
+        if (KIND != 1 && d_mt == per_rank) { d_mt = 0; ++d_u; }
         if (--d_left == 0) {
             ++d_rb;
-            d_mt = TPR * d_rb;
-            d_left = NT - d_mt;
-            if (d_left <= 0) d_left = 1 << 30;   // past the last row block: clamped re-fetches of the last tile, never consumed
+            if (KIND == 1) {
+                d_mt = TPR * d_rb;
+                d_left = NT - d_mt;
+                if (d_left <= 0) d_left = 1 << 30;   // past the last row block: clamped re-fetches of the last tile, never consumed
+            } else {
+                d_u = 0; d_mt = 0; d_left = NT;      // (past the last row block: re-fetches of valid tiles, never consumed)
+            }
         }
     };
     auto issue_piece = [&](int k, unsigned tile_off, unsigned stage_off) {
@@ -259,12 +286,29 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             buf_store16(rs_st, st_voff + 1024u * th, soff, __builtin_bit_cast(u32x4, pk));
         }
     };
-    // plain (not overlapped) epilogue of the tile in `acc`: jt = its index in the row block's list, soff = its stash offsets
+    // The tile BEHIND the compute cursor (index j - 1 of the row block's list -- the one whose epilogue is owed): modality of its columns and
+    // the byte offset of its 32 column sums in `colpart`.  c_in = position of tile j inside its rank segment (rectangular launches).
+    int c_in = 0;
+    struct TileInfo { int cmod; unsigned cs_off; };
+    auto owed_tile = [&]() {
+        TileInfo t;
+        if (KIND == 1) {
+            const int mt = TPR * rb + j - 1;
+            t.cmod = mt >= per_mod ? 1 : 0;
+            t.cs_off = (unsigned)((rb * NT + mt) * (QT * 4));
+        } else {
+            const int in = c_in == 0 ? per_rank - 1 : c_in - 1;
+            t.cmod = in >= per_mod ? 1 : 0;
+            t.cs_off = (unsigned)((rb * NT + j - 1) * (QT * 4));
+        }
+        return t;
+    };
+    // plain (not overlapped) epilogue of the tile in `acc`: jt = j - 1 = its index in the row block's list
     auto epilogue_plain = [&](f32x16 (&acc)[NH], int jt) __attribute__((always_inline)) {
         mfma_results_visible();
-        const int mt = TPR * rb + jt;
-        const float c2s = ((mt >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
-        const bool upper = jt >= TPR;
+        const TileInfo ti = owed_tile();
+        const float c2s = (ti.cmod == rmod) ? g.c_intra : g.c_inter;
+        const bool upper = KIND == 1 ? jt >= TPR : KIND == 3;
         const float ninf = -__builtin_inff();
         float es[16];
 #pragma unroll
@@ -274,7 +318,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             float xx[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) xx[r] = acc[s][r] * c2s - g.m2;
-            if (jt == NH * wave + s) {             // the tile that holds this half's self pairs
+            if (KIND == 1 && jt == NH * wave + s) {             // the tile that holds this half's self pairs
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (frag_row(r, half) == l31) xx[r] = ninf;
@@ -286,7 +330,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { rowacc[s] += e[r]; es[r] += e[r]; }
         }
-        if (upper) publish(halving_sum16(es, l31), (unsigned)((rb * NT + mt) * (QT * 4)));
+        if (upper) publish(halving_sum16(es, l31), ti.cs_off);
     };
 
     // ---- one stage: NH DK MFMAs into accC (stage KH of tile jt); MODE 1: the epilogue of the previous tile (accP, index jt - 1) in their shadow ----
@@ -305,8 +349,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
 #pragma unroll
         for (int q = 0; q < PF; ++q) fr[q] = nx[q];
         // the owed tile (MODE 1)
-        const int mtp = TPR * rb + jt - 1;
-        const float c2s = ((mtp >= per_mod ? 1 : 0) == rmod) ? g.c_intra : g.c_inter;
+        const TileInfo ti = owed_tile();             // (jt == j here: the tile behind the cursor is the owed one)
+        const float c2s = (ti.cmod == rmod) ? g.c_intra : g.c_inter;
         const unsigned so0 = st_soff[0] + 2048u * (unsigned)(jt - 1), so1 = st_soff[NH - 1] + 2048u * (unsigned)(jt - 1);
         float es[16], k8[8], k4[4], k2[2], sa[15], sb[15];
         // the pending publication (flushed behind this step's barrier)
@@ -345,8 +389,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             } else if constexpr (h < H2) {
                 constexpr int n = H2 - H1, i = h - H1;
                 if constexpr (h == H1) { rowacc[NH - 1] += accP[NH - 1][15]; pin_v(rowacc[NH - 1]); }
+                if (CSUM) {
 #pragma unroll
-                for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = NH == 2 ? accP[0][r] + accP[NH - 1][r] : accP[0][r];
+                    for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = NH == 2 ? accP[0][r] + accP[NH - 1][r] : accP[0][r];
+                }
                 if (ST && !(CROSSCLR_ZABL & 2)) {
 #pragma unroll
                     for (int f = (2 * NH * i) / n; f < (2 * NH * (i + 1)) / n; ++f) {
@@ -357,6 +403,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                         buf_store16(rs_st, st_voff + 1024u * th, s ? so1 : so0, __builtin_bit_cast(u32x4, pk));
                     }
                 }
+            } else if constexpr (!CSUM) {
+                // (rectangular launch without column sums: the last quarter of the tile carries no chores)
             } else if constexpr (CROSSCLR_ZLAG == 0) {
                 constexpr int n = H - H2, i = h - H2;
                 constexpr int lo = (16 * i) / n, hi = (16 * (i + 1)) / n;     // units 0..7: k8, 8..11: k4, 12..13: k2, 14: k1, 15: (publish: behind the loop)
@@ -465,9 +513,9 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
 #pragma unroll
         for (int q = 0; q < PF; ++q) nx[q] = nn[q];
         pend = 0;
-        if constexpr (EPI && KH == KS - 1) {
-            if (!(CROSSCLR_ZABL & 64)) publish(k2[0], (unsigned)((rb * NT + mtp) * (QT * 4)));
-        } else if constexpr (MODE == 1 && KH == KS - 1) {
+        if constexpr (EPI && CSUM && KH == KS - 1) {
+            if (!(CROSSCLR_ZABL & 64)) publish(k2[0], ti.cs_off);
+        } else if constexpr (!EPI && MODE == 1 && KH == KS - 1) {
             rowacc[0] += accP[0][0] + accP[NH - 1][1];      // (ablation: keeps the previous tile's MFMAs alive)
         }
         dma_advance();
@@ -484,16 +532,18 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     bool primed = false;
     while (w < w_end) {
         // ---- a segment: the tiles j .. j + n - 1 of row block rb ----
-        int n = NT - TPR * rb - j;
+        int n = (KIND == 1 ? NT - TPR * rb : NT) - j;
         if (n > w_end - w) n = w_end - w;
         w += n;
         row0w = rb * RBLK + RW * wave;
         rmod = uniform(row0w / g.bpad);
+        c_in = KIND == 1 ? 0 : j % per_rank;       // (j > 0 only in a range's first segment: one division per thread block)
 #pragma unroll
         for (int s = 0; s < NH; ++s) {
             rowacc[s] = 0.f;
-            st_soff[s] = ST ? (unsigned)(stash_tile_index(TPR, NT, TPR * rb + NH * wave + s, TPR * rb) * 2048) : 0u;
-            const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * KS * 16) + 8 * half;
+            st_soff[s] = !ST ? 0u : (KIND == 1 ? (unsigned)(stash_tile_index(TPR, NT, TPR * rb + NH * wave + s, TPR * rb) * 2048)
+                                               : (unsigned)(TPR * rb + NH * wave + s) * (unsigned)NT * 2048u);
+            const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * KS * 16) + 8 * half;      // (the ROW operand)
 #pragma unroll
             for (int k = 0; k < DK * KS; ++k) pf[s][k] = *reinterpret_cast<const bf16x8*>(src + 16 * k);
         }
@@ -511,20 +561,21 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         }
         // phase 1: masked tiles one by one, up to and including the first tile that can stay owed (set A)
         bool owedA = false;
+        auto next_tile = [&]() { ++j; --n; if (KIND != 1 && ++c_in == per_rank) c_in = 0; };
         while (n > 0) {
             tile(IdxC<0>{}, accA, accB, j);
-            ++j; --n;
-            if (j - 1 < TPR) epilogue_plain(accA, j - 1);
+            next_tile();
+            if (KIND == 1 && j - 1 < TPR) epilogue_plain(accA, j - 1);
             else { owedA = true; break; }
         }
         // phase 2: pairs -- (B while A's epilogue runs), (A while B's epilogue runs)
         bool owedB = false;
         while (n > 0) {
             tile(IdxC<1>{}, accB, accA, j);
-            ++j; --n;
+            next_tile();
             if (n == 0) { owedA = false; owedB = true; break; }
             tile(IdxC<1>{}, accA, accB, j);
-            ++j; --n;
+            next_tile();
         }
         // the segment's last tile: an earlier publication may still wait for its barrier -- flush it, then finish the tile in the open
         if (owedA || owedB) {

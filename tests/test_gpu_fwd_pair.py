@@ -59,3 +59,21 @@ def test_pair_forward_many_launches_headline_shape():
         bad += int(l != l0) + int(not torch.equal(gv, gv0)) + int(not torch.equal(gt, gt0))
     assert bad == 0
     assert abs(l0 - 10.627098744839678) <= 1e-3        # tests/golden/index.json: g7_b8192_d512_s1234
+
+
+@pytest.mark.parametrize("world,rank,b,D", [(3, 1, 128, 128), (4, 3, 256, 200), (2, 0, 1024, 512), (8, 4, 1024, 512), (5, 2, 384, 1024), (8, 7, 2048, 256)])
+def test_rectangular_and_pair_launches_are_bit_identical(world, rank, b, D, monkeypatch):
+    """The blocks a rank of a sharded run evaluates against OTHER ranks (crossclr_forward_pairs, crossclr_forward_rect_save, crossclr_forward_w
+    with the own rank skipped) on fast_fwd_pair_kernel<..., KIND 2 / 3> against fast_fwd_pipe_kernel: partial row sums, the partner's column
+    sums and the rectangular stash bit for bit, twice."""
+    from test_fwd_pair_rect_emulated import rect_outputs
+    stream = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("CROSSCLR_FWD_PAIR", "0")
+    old = rect_outputs(world, rank, b, D, dev="cuda", stream=stream)
+    monkeypatch.delenv("CROSSCLR_FWD_PAIR")
+    for _ in range(2):
+        new = rect_outputs(world, rank, b, D, dev="cuda", stream=stream)
+        assert set(new) == set(old) and len(new) >= 2
+        for k in new:
+            assert torch.equal(new[k], old[k]), k
+    torch.cuda.synchronize()
