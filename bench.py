@@ -596,7 +596,9 @@ def main():
                 kernels[k].update(executed_tflops=round(ex, 2), frac_executed=round(ex / peak, 4))
     saved = bool(st.get("saved_path"))
     if args.fwd_only:
-        dom, dom_kernel = "forward", ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel<float, false, 0, false>")
+        # (whole 128-row batches without sample weights take round 5's forward: csrc/crossclr_kernels_symp.h)
+        fwd_name = "fast_fwd_pair_kernel" if (b % 128 == 0 and not args.influential and os.environ.get("CROSSCLR_FWD_PAIR", "1") != "0") else "fast_fwd_pipe_kernel"
+        dom, dom_kernel = "forward", (fwd_name if st["fast_path"] else "fwd_sums_kernel<float, false, 0, false>")
     else:
         dom = "backward_saved" if saved else "backward"
         dom_kernel = (("fast_bwd_dsl_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
@@ -652,7 +654,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": f"{dom_kernel_label} (crossclr_{dom}{entry_suffix if dom == 'backward_saved' else ''}; dominant kernel)",
                      "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
                      "source": "HIP events in this process (torch's current stream = the launch stream): median over 50 passes of the step's own "
-                               "kernel sequence (normalize, forward + save, finish, saved backward, finish) right after the timed region, events "
+                               "kernel sequence (normalize, forward + save, finish [through the stage entry point: with the separate loss-reduce launch "
+                               "that crossclr_step_forward folds into the finish kernel], saved backward, finish) right after the timed region, events "
                                "between the launches -- the kernel in its place in the step, which is what the rocprofv3 trace of the same command "
                                "(profiles/) shows; `back_to_back_launch_ms` = the median of 20 launches of the kernel alone (package power limit: slower)",
                      "back_to_back_launch_ms": round(st[dom], 4),

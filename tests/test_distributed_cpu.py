@@ -144,7 +144,12 @@ def _worker(rank, world, port, B, D, mode, q, tau=0.05):
                                                        # 13 ranks: six pair partners + local + received > the workspace's 8 launch groups, so
                                                        # the per-peer exchange falls back to ONE launch over the pair range -- behind a wait
                                                        # for EVERY peer's slice (round-3 advisor finding)
-                                                       (13, 26, 16, "bf16+each", 5e-3, 2e-2)])
+                                                       (13, 26, 16, "bf16+each", 5e-3, 2e-2),
+                                                       # whole 128-row batches per rank: the local block AND the blocks against other ranks take
+                                                       # fast_fwd_pair_kernel (KIND 1 / 3 / 2: csrc/crossclr_kernels_symp.h) -- pairs + partner
+                                                       # gradients at 3 ranks, the antipodal rectangular block at 2
+                                                       (3, 384, 16, "bf16", 5e-3, 2e-2),
+                                                       (2, 256, 24, "bf16", 5e-3, 2e-2)])
 def test_sharded_loss_over_gloo(world, B, D, mode, ltol, gtol):
     from emu import build_emu
     build_emu.build()
