@@ -819,24 +819,33 @@ static inline FwdWork fast_forward_work(const crossclr_plan* p, int col_ranks, i
     return fwd_make_work(symmetric ? 1 : (pairs ? 3 : 2), p->bpad, usable, p->fwd_blocks, fast_fwd_tpr(p->Dpad));
 }
 
-// the symmetric forward of whole batches (crossclr_kernels_symp.h: one unbroken MFMA stream per wave): Dpad <= 1024, b a multiple of 128,
-// no sample weights, a stash below 4 GiB
+// the forward of whole batches (crossclr_kernels_symp.h: one unbroken MFMA stream per wave): Dpad <= 1024, b a multiple of 128, a stash below 4 GiB
 #ifndef CROSSCLR_DEF_FWDP
 int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols, float* part, float* colpart,
-                      int* header, int kind, void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream);
+                      int* header, int kind, const float* krows, const float* kcols, void* stash, size_t stash_bytes, const FwdPerm& perm,
+                      void* stream);
 #else
 CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols, float* part,
-                                    float* colpart, int* header, int kind, void* stash, size_t stash_bytes, const FwdPerm& perm, void* stream) {
+                                    float* colpart, int* header, int kind, const float* krows, const float* kcols, void* stash,
+                                    size_t stash_bytes, const FwdPerm& perm, void* stream) {
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
     unsigned char* st = (unsigned char*)stash;
     const unsigned sb = (unsigned)stash_bytes;
+    const bool sw = krows != nullptr && kcols != nullptr;
     dim3 grid(wk.nblk), block(256);
-    (void)r; (void)c; (void)st; (void)sb; (void)grid; (void)block;
-#define CROSSCLR_LZ3(DK, NH, KS, KIND)                                                                                                                   \
-    do {                                                                                                                                                 \
-        if (st) CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, true, NH, KS, KIND>), grid, block, stream, r, c, g, wk, part, colpart, header, st, sb, perm); \
-        else CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, false, NH, KS, KIND>), grid, block, stream, r, c, g, wk, part, colpart, header, st, sb, perm);  \
+    (void)r; (void)c; (void)st; (void)sb; (void)grid; (void)block; (void)sw;
+#define CROSSCLR_LZ4(DK, NH, KS, KIND, SW, ST) \
+    CROSSCLR_FAST_LAUNCH((fast_fwd_pair_kernel<DK, ST, NH, KS, KIND, SW>), grid, block, stream, r, c, g, wk, part, colpart, header, st, sb, perm, krows, kcols)
+    // (sample weights: the wide instantiations only -- NH = 1 leaves room for the 16 column scales of a tile; with both 32-row halves' accumulators
+    //  resident they spill, and the caller keeps those launches with fast_fwd_pipe_kernel)
+#define CROSSCLR_LZ3(DK, NH, KS, KIND)                                            \
+    do {                                                                          \
+        if (sw && NH == 2) return CROSSCLR_E_ARG;                                 \
+        if (sw && st) CROSSCLR_LZ4(DK, NH, KS, KIND, (NH == 1), true);            \
+        else if (sw) CROSSCLR_LZ4(DK, NH, KS, KIND, (NH == 1), false);            \
+        else if (st) CROSSCLR_LZ4(DK, NH, KS, KIND, false, true);                 \
+        else CROSSCLR_LZ4(DK, NH, KS, KIND, false, false);                        \
     } while (0)
 #define CROSSCLR_LZ(DK, NH, KS)                          \
     do {                                                 \
@@ -855,6 +864,7 @@ CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const 
     }
 #undef CROSSCLR_LZ
 #undef CROSSCLR_LZ3
+#undef CROSSCLR_LZ4
     return CROSSCLR_OK;
 }
 #endif   // CROSSCLR_DEF_FWDP
@@ -895,7 +905,7 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
     // the same bits as the kernel below, CROSSCLR_FWD_PAIR=0 keeps that one: A/B)
     const char* pair_env = getenv("CROSSCLR_FWD_PAIR");      // (read per launch: the bit-identity tests flip it inside one process)
     const bool pair_kernel = !(pair_env && pair_env[0] == '0');
-    if (pair_kernel && !sw && g.b == g.bpad && p->Dpad <= 1024 && wk.tpr == (p->Dpad <= 512 ? 8 : 4)) {
+    if (pair_kernel && (!sw || p->Dpad > 512) && g.b == g.bpad && p->Dpad <= 1024 && wk.tpr == (p->Dpad <= 512 ? 8 : 4)) {
         // rectangular / pair launches: only over OTHER ranks' columns (a launch that contains the rows' own rank needs the self-pair masks)
         bool own = false;
         if (kind != 1) {
@@ -912,7 +922,7 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
         const size_t col_segs = kind == 1 ? 1 : (size_t)(g.col_wrap > 0 ? g.col_wrap : g.col_ranks);
         if (!own && sbytes < ((size_t)1 << 32) && (size_t)wk.NB * wk.NT * 128 < ((size_t)1 << 32) &&
             col_segs * 2 * p->bpad * p->Dpad * 2 < ((size_t)1 << 32))
-            return fast_forward_pair(p, g, wk, rows, cols, part, colpart, header, kind, stash, sbytes, perm, stream);
+            return fast_forward_pair(p, g, wk, rows, cols, part, colpart, header, kind, krows, kcols, stash, sbytes, perm, stream);
     }
 #define CROSSCLR_LP3(DK, KIND, SW, ST) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st, perm)

@@ -121,9 +121,15 @@ struct FwdReadPlan {
 //   2  rectangular: this rank's rows against OTHER ranks' columns (xc = their segments; the host keeps launches that would contain the
 //      rows' own rank with fast_fwd_pipe_kernel) -- no masks at all, no column sums; ST: the rectangular stash of crossclr_forward_rect_save
 //   3  pairs: rectangular, and every tile also yields its column sums over this rank's rows (what the partner rank is owed)
-template <int DK, bool ST, int NH = 2, int KS = 1, int KIND = 1>
+// SW (per-sample weights): k >= 0 multiplies a sample's exponential wherever it is an INTRA-modal negative column -- the row sums
+//   take e k_q, the column sums (the mirrored tile's row sums) e k_p.  The tile's 32 k_q are fetched by four asm buffer loads per lane behind the
+//   tile's barrier (in front of the step's DMA pieces, waited for at the end of the step: s_waitcnt vmcnt(NXO)) and travel to the tile's epilogue
+//   in registers; inter-modal tiles multiply by 1.0 (exact), so both kinds of tile run the same branch-free chores.  Instantiated for NH = 1 (wide
+//   operands: BASELINE config 5's D = 1024) -- beside the accumulators of both 32-row halves the 16 scales spill; those launches keep fast_fwd_pipe_kernel.
+template <int DK, bool ST, int NH = 2, int KS = 1, int KIND = 1, bool SW = false>
 __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, const bf16_t* xc, Geo g, FwdWork wk, float* part, float* colpart,
-                                                               int* header, unsigned char* stash, unsigned stash_bytes, FwdPerm perm) {
+                                                               int* header, unsigned char* stash, unsigned stash_bytes, FwdPerm perm,
+                                                               const float* ks, const float* kc) {
     static_assert(KIND >= 1 && KIND <= 3, "1 symmetric, 2 rectangular, 3 pairs");
     constexpr bool CSUM = KIND != 2;       // column sums are formed (KIND 1: right of the diagonal block)
     constexpr int RB = DK * 32;            // bytes per row of a ring stage
@@ -143,6 +149,9 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     constexpr int KB = FwdReadPlan::kb(DK);      // the k-step the barrier sits in front of
     // DMA pieces behind the barrier: every second k-step from KB + 1 on where that fits, else one per k-step from KB on
     constexpr int DSTRIDE = (KB + 1 + 2 * (NXO - 1) < DK) ? 2 : 1, DK0 = DSTRIDE == 2 ? KB + 1 : KB;
+    // SW: the k-step at whose head the tile's column scales are waited for -- behind the last DMA piece, as late as the blend's VALU still hides
+    // (DK: behind the k-step chain, where the short tiles of Dpad = 128 issue their last piece in the last k-step)
+    constexpr int KLAST = DK0 + DSTRIDE * (NXO - 1), KWAIT = KLAST + 1 > DK - 3 ? KLAST + 1 : DK - 3;
     static_assert(KB % 2 == 0 && KB + 2 < DK && DK0 + DSTRIDE * (NXO - 1) < DK && PF % 2 == 0 && PF >= 4 && PF <= DK - 2, "schedule constants");
     constexpr int CS0 = NST * TILE;        // two column-sum slots [4 waves][32] floats, then a dump slot for the lanes that publish nothing
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad in {128, 256, 384, 512} (KS = 1) / {768, 1024} (KS = 2)");
@@ -174,6 +183,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     const BufRsrc rs_x = make_rsrc(KIND == 1 ? x : xc, (unsigned)((size_t)col_segs * 2 * g.bpad * RBG));
     const BufRsrc rs_st = make_rsrc(stash, stash_bytes);
     const BufRsrc rs_cp = make_rsrc(colpart, (unsigned)((size_t)wk.NB * NT * QT * 4));
+    const RawRsrc rs_k = make_raw_rsrc(SW ? (const void*)kc : (const void*)x, (unsigned)((size_t)col_segs * 2 * g.bpad * 4));
+    const unsigned kq_voff = (unsigned)(16 * half);      // register quad r4 of a lane = columns 8 r4 + 4 half .. + 3 of the tile
     unsigned voffx[NXO];
 #pragma unroll
     for (int k = 0; k < NXO; ++k) {
@@ -181,9 +192,11 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         const int row = L / RB, slot = (L - row * RB) >> 4;
         voffx[k] = (unsigned)(row * RBG + (swz_slot(slot, row) << 4));
     }
-    int off8[8];  // byte offset of logical chunk (2j + half) of this lane's tile row
+    // LDS address of logical chunk (2j + half) of this lane's tile row IN THE CURRENT STAGE: carried from step to step (bumped by the ring
+    // distance: 8 VALU per step, the same as rebuilding them from per-lane offsets, and 8 registers fewer)
+    decltype(lds_addr(lds)) abase[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) off8[j] = l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4);
+    for (int j = 0; j < 8; ++j) abase[j] = lds_addr(lds) + (unsigned)(l31 * RB + ((((2 * j + half) ^ sigma16(l31)) & 15) << 4));
     float* cs = reinterpret_cast<float*>(lds + CS0);
     // publish: lanes l31 < 16 write their column sum to cs[buf][wave][frag_row(elem, half)], the others into the dump slot
     const unsigned pub_addr = (unsigned)(l31 < 16 ? (wave * QT + frag_row(halving_elem16(l31), half)) * 4 : 2 * 4 * QT * 4 + lane * 4);
@@ -243,7 +256,9 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
     }
 
     // ---- per-segment state ----
-    float rowacc[NH];
+    float rowacc[NH], kp[NH];
+    u32x4 kq[4], kq_next[4];                      // SW: the 16 column scales of this lane for the tile behind the cursor (set by that tile's
+                                                  // last step; KS = 2: loaded in its first step, parked in kq_next while the owed tile still needs kq)
     bf16x8 pf[NH][DK * KS];
     int row0w = 0, rmod = 0;
     unsigned st_soff[NH];                         // stash byte offset of the CURRENT tile's records, per 32-row half
@@ -303,6 +318,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         }
         return t;
     };
+    int c_u = 0;                                  // rectangular launches: usable segment of tile j
+    auto cur_tile_mt = [&]() { return KIND == 1 ? TPR * rb + j : seg_mem(c_u) * per_rank + c_in; };     // memory tile (statistics index / 32) of tile j
     // plain (not overlapped) epilogue of the tile in `acc`: jt = j - 1 = its index in the row block's list
     auto epilogue_plain = [&](f32x16 (&acc)[NH], int jt) __attribute__((always_inline)) {
         mfma_results_visible();
@@ -327,8 +344,18 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = fast_exp2(xx[r]);
             stash_store(e, s, st_soff[s] + 2048u * (unsigned)jt);
+            if (SW) {      // (kq holds 1.0 for an inter-modal tile: exact)
+                const float kpe = ti.cmod == rmod ? kp[s] : 1.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { rowacc[s] += e[r]; es[r] += e[r]; }
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 k4 = __builtin_bit_cast(f32x4, kq[r4]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { rowacc[s] += e[4 * r4 + q] * k4[q]; es[4 * r4 + q] += e[4 * r4 + q] * kpe; }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { rowacc[s] += e[r]; es[r] += e[r]; }
+            }
         }
         if (upper) publish(halving_sum16(es, l31), ti.cs_off);
     };
@@ -338,12 +365,10 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         constexpr int MODE = decltype(modec)::value, KH = decltype(khc)::value;
         constexpr bool EPI = MODE == 1 && !(CROSSCLR_ZABL & 1);
         const unsigned nstage = ring_next(cstage);
-        const auto xa = lds_addr(lds + cstage);
-        decltype(lds_addr(lds)) abase[8], anext[PF];
+        const int ring_step = (int)nstage - (int)cstage;      // + TILE, or back to the first stage
+        decltype(lds_addr(lds)) anext[PF];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) abase[q] = xa + off8[q];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) anext[q] = lds_addr(lds + nstage) + off8[q];
+        for (int q = 0; q < PF; ++q) anext[q] = abase[q] + ring_step;
         u32x4 fr[DK];                                  // A fragments of k-steps PF .. DK-1 (indices < PF unused)
         u32x4 nn[PF];                                  // first fragments of the next tile
 #pragma unroll
@@ -353,6 +378,16 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         const float c2s = (ti.cmod == rmod) ? g.c_intra : g.c_inter;
         const unsigned so0 = st_soff[0] + 2048u * (unsigned)(jt - 1), so1 = st_soff[NH - 1] + 2048u * (unsigned)(jt - 1);
         float es[16], k8[8], k4[4], k2[2], sa[15], sb[15];
+        // SW: the owed tile's scales -- its columns' (set by its own step) and its rows' -- or 1.0 where they do not apply (inter-modal tile)
+        const bool weigh = SW && ti.cmod == rmod;
+        float kpe[NH];
+        const bool weigh_cur = SW && ((KIND == 1 ? (TPR * rb + jt >= per_mod ? 1 : 0) : (c_in >= per_mod ? 1 : 0)) == rmod);      // this tile: intra-modal?
+        u32x4 kqn[4];                                  // SW: this tile's column scales, loaded behind the barrier
+        const unsigned kq_soff = (unsigned)cur_tile_mt() * (unsigned)(QT * 4);
+        if (SW) {
+#pragma unroll
+            for (int s = 0; s < NH; ++s) kpe[s] = weigh ? kp[s] : 1.f;
+        }
         // the pending publication (flushed behind this step's barrier)
         const auto fa = lds_addr(lds + CS0 + (pbuf ? 4 * QT * 4 : 0) + l31 * 4);
         const unsigned f_voff = (pend && wave == (jt & 3) && half == 0) ? (unsigned)(l31 * 4) : 0xFFFFFF00u;
@@ -384,14 +419,26 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                 for (int idx = (16 * NH * h) / H1; idx < (16 * NH * (h + 1)) / H1; ++idx) {
                     const int s = idx >> 4, r = idx & 15;
                     accP[s][r] = fast_exp2(accP[s][r] * c2s - g.m2);
-                    if (idx > 0) { rowacc[(idx - 1) >> 4] += accP[(idx - 1) >> 4][(idx - 1) & 15]; pin_v(rowacc[(idx - 1) >> 4]); }
+                    if (idx > 0) {
+                        const int sp = (idx - 1) >> 4, rp = (idx - 1) & 15;
+                        if (SW) rowacc[sp] += accP[sp][rp] * __builtin_bit_cast(f32x4, kq[rp >> 2])[rp & 3];
+                        else rowacc[sp] += accP[sp][rp];
+                        pin_v(rowacc[sp]);
+                    }
                 }
             } else if constexpr (h < H2) {
                 constexpr int n = H2 - H1, i = h - H1;
-                if constexpr (h == H1) { rowacc[NH - 1] += accP[NH - 1][15]; pin_v(rowacc[NH - 1]); }
+                if constexpr (h == H1) {      // (KS = 2: a new invocation of this lambda: the scale is read again)
+                    if (SW) rowacc[NH - 1] += accP[NH - 1][15] * __builtin_bit_cast(f32x4, kq[3])[3];
+                    else rowacc[NH - 1] += accP[NH - 1][15];
+                    pin_v(rowacc[NH - 1]);
+                }
                 if (CSUM) {
 #pragma unroll
-                    for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) es[r] = NH == 2 ? accP[0][r] + accP[NH - 1][r] : accP[0][r];
+                    for (int r = (16 * i) / n; r < (16 * (i + 1)) / n; ++r) {
+                        if (SW) { es[r] = accP[0][r] * kpe[0]; if (NH == 2) es[r] += accP[NH - 1][r] * kpe[NH - 1]; }
+                        else es[r] = NH == 2 ? accP[0][r] + accP[NH - 1][r] : accP[0][r];
+                    }
                 }
                 if (ST && !(CROSSCLR_ZABL & 2)) {
 #pragma unroll
@@ -462,6 +509,16 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             }
         };
 
+        // this tile's column scales have landed (they went out at the barrier, in front of the DMA pieces: only those may still be in flight); an
+        // inter-modal tile's become 1.0 -- its epilogue then multiplies exactly like an intra-modal one's
+        auto scales_landed = [&]() {
+            wait_dma_keep<NXO>();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) after_wait(kqn[q]);
+            const u32x4 ones = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kqn[q] = weigh_cur ? kqn[q] : ones;
+        };
         static_for<DK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             // ---- head: the fragments of k-steps k and k + 1 are complete (one counted wait per two k-steps); at k-step KB + 2 the flush's reads too
@@ -485,6 +542,12 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                 if (!(CROSSCLR_ZABL & 8)) barrier_only();
                 f01 = lds_read2_b32_async<0, QT>(fa);
                 f23 = lds_read2_b32_async<2 * QT, 3 * QT>(fa);
+                if constexpr (SW && KH == 0) {       // this tile's column scales: IN FRONT of the step's DMA pieces (the closing vmcnt(NXO) covers them)
+                    kqn[0] = buf_load_b128_async<0>(rs_k, kq_voff, kq_soff);
+                    kqn[1] = buf_load_b128_async<32>(rs_k, kq_voff, kq_soff);
+                    kqn[2] = buf_load_b128_async<64>(rs_k, kq_voff, kq_soff);
+                    kqn[3] = buf_load_b128_async<96>(rs_k, kq_voff, kq_soff);
+                }
             }
             const bf16x8 a = __builtin_bit_cast(bf16x8, fr[k]);
             constexpr int kp = KH * DK + k;          // the k-step inside the row fragments
@@ -499,6 +562,7 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
                 const f32x2 c01 = __builtin_bit_cast(f32x2, f01), c23 = __builtin_bit_cast(f32x2, f23);
                 buf_store4(rs_cp, f_voff, f_soff, (c01[0] + c01[1]) + (c23[0] + c23[1]));
             }
+            if constexpr (SW && KH == 0 && k == KWAIT) scales_landed();
             chore(IdxC<KH * SPS + NH * k>{});
             sched_fence();
             if constexpr (NH == 2) { if constexpr (kp == 0) mfma_first_va(accC[NH - 1], a, pf[NH - 1][kp]); else mfma_va(accC[NH - 1], a, pf[NH - 1][kp]); }
@@ -512,6 +576,15 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         for (int q = 0; q < PF; ++q) after_wait(nn[q]);
 #pragma unroll
         for (int q = 0; q < PF; ++q) nx[q] = nn[q];
+        if constexpr (SW && KH == 0 && KWAIT >= DK) scales_landed();
+        if constexpr (SW && KH == KS - 1) {          // from here on the tile is "the tile behind the cursor"
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kq[q] = KS == 1 ? kqn[q] : kq_next[q];
+        }
+        if constexpr (SW && KS == 2 && KH == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kq_next[q] = kqn[q];
+        }
         pend = 0;
         if constexpr (EPI && CSUM && KH == KS - 1) {
             if (!(CROSSCLR_ZABL & 64)) publish(k2[0], ti.cs_off);
@@ -520,6 +593,8 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         }
         dma_advance();
         cstage = nstage;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) abase[q] += ring_step;
     };
 
     // a tile = KS stages
@@ -537,10 +612,12 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
         w += n;
         row0w = rb * RBLK + RW * wave;
         rmod = uniform(row0w / g.bpad);
-        c_in = KIND == 1 ? 0 : j % per_rank;       // (j > 0 only in a range's first segment: one division per thread block)
+        c_u = KIND == 1 ? 0 : j / per_rank;        // (j > 0 only in a range's first segment: one division per thread block)
+        c_in = KIND == 1 ? 0 : j - c_u * per_rank;
 #pragma unroll
         for (int s = 0; s < NH; ++s) {
             rowacc[s] = 0.f;
+            kp[s] = SW ? ks[row0w + 32 * s + l31] : 1.f;
             st_soff[s] = !ST ? 0u : (KIND == 1 ? (unsigned)(stash_tile_index(TPR, NT, TPR * rb + NH * wave + s, TPR * rb) * 2048)
                                                : (unsigned)(TPR * rb + NH * wave + s) * (unsigned)NT * 2048u);
             const bf16_t* src = x + (size_t)(row0w + 32 * s + l31) * (DK * KS * 16) + 8 * half;      // (the ROW operand)
@@ -553,15 +630,14 @@ __global__ void __launch_bounds__(256, 1) fast_fwd_pair_kernel(const bf16_t* x, 
             primed = true;
             wait_dma();
             barrier_only();
-            const auto xa = lds_addr(lds + cstage);
-            static_for<PF>([&](auto qc) { constexpr int q = decltype(qc)::value; nx[q] = lds_read_b128_async<(q >> 3) * 256>(xa + off8[q & 7]); });
+            static_for<PF>([&](auto qc) { constexpr int q = decltype(qc)::value; nx[q] = lds_read_b128_async<(q >> 3) * 256>(abase[q & 7]); });
             wait_lgkm_n<0>();
 #pragma unroll
             for (int q = 0; q < PF; ++q) after_wait(nx[q]);
         }
         // phase 1: masked tiles one by one, up to and including the first tile that can stay owed (set A)
         bool owedA = false;
-        auto next_tile = [&]() { ++j; --n; if (KIND != 1 && ++c_in == per_rank) c_in = 0; };
+        auto next_tile = [&]() { ++j; --n; if (KIND != 1 && ++c_in == per_rank) { c_in = 0; ++c_u; } };
         while (n > 0) {
             tile(IdxC<0>{}, accA, accB, j);
             next_tile();

@@ -491,6 +491,18 @@ def _alloc_stash(nbytes: int, dev) -> Optional[torch.Tensor]:
         return None
 
 
+def _alloc_rect_stash(nbytes: int, dev) -> torch.Tensor:
+    """The saved exponentials of a block against other ranks.  The ranks agreed on the scheme from a trial allocation at the first step
+    (`_check_equal_rows_per_rank`); memory pressure later cannot be renegotiated inside a step -- the peers already sit in their collectives --
+    so a failure names the knobs instead of surfacing as a bare OOM on one rank and a hang on the others."""
+    try:
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    except torch.OutOfMemoryError as e:
+        raise RuntimeError(f"CrossCLR (sharded): could not allocate {nbytes / 2 ** 20:.0f} MiB for the saved exponentials of a remote block on this "
+                           "rank (the other ranks are waiting in a collective and will time out); set CROSSCLR_DISABLE_REMOTE_SAVE=1 (remote "
+                           "blocks recompute in the backward) or CROSSCLR_DISABLE_SAVE=1 on EVERY rank") from e
+
+
 def _sw(k_rows, k_cols, lw) -> "ctypes.POINTER(nat.SampleWeights) | None":
     if k_rows is None and lw is None:
         return None
@@ -793,7 +805,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                 gather.wait_peer(peer)
                 cs = outbox[out_row[peer]]
                 if save_remote:
-                    st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
+                    st = _alloc_rect_stash(lib.crossclr_rect_stash_bytes(pp, 1), dev)
                     nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), peer, 1, 1, ws.temperature, ws.negative_w,
                                                              sw_all, _ptr(part), group_of * plan.fwd_slots, _ptr(cs), _ptr(st), stream))
                     ws.saved_blocks.append((peer, 1, st))
@@ -807,7 +819,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
                 gather.wait_peer(peer)
             colsum = torch.empty(npairs * n2, **f32)
             if save_remote:
-                st = torch.empty(lib.crossclr_rect_stash_bytes(pp, npairs), dtype=torch.uint8, device=dev)
+                st = _alloc_rect_stash(lib.crossclr_rect_stash_bytes(pp, npairs), dev)
                 nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), peers[0], npairs, 1, ws.temperature,
                                                          ws.negative_w, sw_all, _ptr(part), plan.fwd_slots, _ptr(colsum), _ptr(st), stream))
                 ws.saved_blocks.append((peers[0], npairs, st))
@@ -827,7 +839,7 @@ def _forward_impl(video: torch.Tensor, text: torch.Tensor, temperature: float, n
         if opp is not None:   # both sides evaluate their own rows of the antipodal block
             gather.wait_peer(opp)
             if save_remote:
-                st = torch.empty(lib.crossclr_rect_stash_bytes(pp, 1), dtype=torch.uint8, device=dev)
+                st = _alloc_rect_stash(lib.crossclr_rect_stash_bytes(pp, 1), dev)
                 nat.check(lib.crossclr_forward_rect_save(pp, _ptr(ws.xhat), _ptr(ws.xcols), opp, 1, 0, ws.temperature, ws.negative_w,
                                                          sw_all, _ptr(part), group_of * plan.fwd_slots, None, _ptr(st), stream))
                 ws.saved_blocks.append((opp, 1, st))

@@ -41,13 +41,15 @@ template __global__ void fast_fwd_pipe_kernel<8, 1, false, true> FSIG;
 template __global__ void fast_fwd_pipe_kernel<8, 3, true, true> FSIG;
 template __global__ void fast_fwd_pipe_kernel<32, 1, false, true> FSIG;  // the headline forward
 template __global__ void fast_fwd_pipe_kernel<64, 2, false, true, 1> FSIG;
-#define ZSIG (const bf16_t*, const bf16_t*, Geo, FwdWork, float*, float*, int*, unsigned char*, unsigned, FwdPerm)
+#define ZSIG (const bf16_t*, const bf16_t*, Geo, FwdWork, float*, float*, int*, unsigned char*, unsigned, FwdPerm, const float*, const float*)
 template __global__ void fast_fwd_pair_kernel<32, true> ZSIG;            // round 5's headline forward (one unbroken MFMA stream per wave)
 template __global__ void fast_fwd_pair_kernel<8, false> ZSIG;            // every read of a tile in the double-cadence zone
 template __global__ void fast_fwd_pair_kernel<24, true> ZSIG;            // ring of 4 x 24 KiB: wrap by comparison
 template __global__ void fast_fwd_pair_kernel<32, true, 1, 2> ZSIG;      // D = 1024: one 32-row half per wave, the tile in two ring stages
 template __global__ void fast_fwd_pair_kernel<32, true, 2, 1, 3> ZSIG;   // pairs launch of a sharded run (column sums for the partner, rectangular stash)
 template __global__ void fast_fwd_pair_kernel<16, false, 2, 1, 2> ZSIG;  // rectangular launch without column sums
+template __global__ void fast_fwd_pair_kernel<32, true, 1, 2, 1, true> ZSIG;   // sample weights (wide operands): the tile's column scales by asm buffer loads (vmcnt-counted)
+template __global__ void fast_fwd_pair_kernel<24, true, 1, 2, 3, true> ZSIG;   // ... pairs launch (BASELINE config 5's remote blocks)
 }
 '''
 
@@ -60,9 +62,9 @@ def test_no_asm_loaded_register_is_read_before_its_wait(tmp_path):
                            "-DCROSSCLR_KERNELS_ONLY", "-I", CSRC, str(src), "-o", str(asm)], stderr=subprocess.DEVNULL)
     text = asm.read_text()
     kernels = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", text, re.M)
-    assert len(kernels) == 26, kernels
+    assert len(kernels) == 28, kernels
     scratch = [int(x) for x in re.findall(r";\s*ScratchSize:\s*(\d+)", text)]
-    assert len(scratch) >= 26 and all(s == 0 for s in scratch), scratch
+    assert len(scratch) >= 28 and all(s == 0 for s in scratch), scratch
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py"), str(asm)], capture_output=True, text=True)
     assert r.returncode == 0 and "flagged: 0" in r.stdout, r.stdout[-2000:]
     # and the audit itself must be able to see the loads it is meant to guard

@@ -53,3 +53,26 @@ def test_pair_forward_is_bit_identical_to_the_pipe_forward(B, D, blocks, monkeyp
     assert torch.equal(gvn, gvo) and torch.equal(gtn, gto)
     model = float(orc.bf16_operand_model_loss(v, t, 0.05, 0.8))
     assert abs(ln.item() - model) <= 2e-6 * max(1.0, abs(model))
+
+
+@pytest.mark.parametrize("B,D,blocks", [(128, 600, 1), (256, 1000, 2), (256, 700, 0)])
+def test_pair_forward_with_sample_weights_is_bit_identical(B, D, blocks, monkeypatch):
+    """Per-sample weights (negative scales k, loss weights omega) on the wide instantiations <DK, ST, 1, 2, KIND, SW = true>: the tile's column
+    scales travel in registers from the tile's step to its epilogue; inter-modal tiles multiply by 1.0."""
+    if blocks:
+        monkeypatch.setenv("CROSSCLR_FWD_BLOCKS", str(blocks))
+    v, t = orc.make_inputs("randn", B, D, 43)
+    g = torch.Generator().manual_seed(B + D)
+    keep = lambda: (torch.rand(B, generator=g) > 0.3).float() * (0.5 + torch.rand(B, generator=g))
+    kw = dict(negative_scale=(keep(), keep()), loss_weight=(torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5))
+
+    def wstep():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad, tt.grad
+    monkeypatch.delenv("CROSSCLR_FWD_PAIR", raising=False)
+    ln, gvn, gtn = wstep()
+    monkeypatch.setenv("CROSSCLR_FWD_PAIR", "0")
+    lo, gvo, gto = wstep()
+    assert ln == lo and torch.equal(gvn, gvo) and torch.equal(gtn, gto)

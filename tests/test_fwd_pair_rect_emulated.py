@@ -20,7 +20,7 @@ def emulated_library():
     nat.use_library_for_testing(None)
 
 
-def rect_outputs(world, rank, b, D, dev="cpu", stream=0):
+def rect_outputs(world, rank, b, D, dev="cpu", stream=0, weighted=False):
     """Every rectangular launch shape the sharded host path uses, for `rank` of `world`: returns the tensors they wrote."""
     lib = nat.library()
     plan = nat.make_plan(b, D, world, rank, nat.MODE_BF16)
@@ -38,18 +38,25 @@ def rect_outputs(world, rank, b, D, dev="cpu", stream=0):
     xhat = xs[rank]
     n2 = 2 * plan.bpad
     out = {}
+    sw = None
+    if weighted:      # negative scales of every rank's rows (statistics layout), some of them zero (pruned)
+        gk = torch.Generator().manual_seed(9)
+        k_all = ((torch.rand(world * n2, generator=gk) > 0.3).float() * (0.5 + torch.rand(world * n2, generator=gk))).to(dev)
+        k_rows = k_all[rank * n2:(rank + 1) * n2]
+        sw = L._sw(k_rows, k_all, None)
+        out["_keepalive"] = k_all
     npairs = (world - 1) // 2
     part = torch.zeros(plan.fwd_ws_floats, **f32)
     if npairs:
         first = (rank + 1) % world
         colsum = torch.zeros(npairs * n2, **f32)
-        nat.check(lib.crossclr_forward_pairs(pp, p(xhat), p(xcols), first, npairs, 0.05, 0.8, None, p(part), plan.fwd_slots, p(colsum), stream))
+        nat.check(lib.crossclr_forward_pairs(pp, p(xhat), p(xcols), first, npairs, 0.05, 0.8, sw, p(part), plan.fwd_slots, p(colsum), stream))
         out["pairs_part"], out["pairs_colsum"] = part.clone(), colsum.clone()
         nb = lib.crossclr_rect_stash_bytes(pp, npairs)
         if nb:
             st = torch.zeros(nb, dtype=torch.uint8, device=dev)
             part.zero_(); colsum.zero_()
-            nat.check(lib.crossclr_forward_rect_save(pp, p(xhat), p(xcols), first, npairs, 1, 0.05, 0.8, None, p(part), plan.fwd_slots, p(colsum),
+            nat.check(lib.crossclr_forward_rect_save(pp, p(xhat), p(xcols), first, npairs, 1, 0.05, 0.8, sw, p(part), plan.fwd_slots, p(colsum),
                                                      p(st), stream))
             out["rect_part"], out["rect_colsum"], out["rect_stash"] = part.clone(), colsum.clone(), st
     if world % 2 == 0:
@@ -57,10 +64,10 @@ def rect_outputs(world, rank, b, D, dev="cpu", stream=0):
         nb = lib.crossclr_rect_stash_bytes(pp, 1)
         st = torch.zeros(max(nb, 1), dtype=torch.uint8, device=dev)
         part.zero_()
-        nat.check(lib.crossclr_forward_rect_save(pp, p(xhat), p(xcols), opp, 1, 0, 0.05, 0.8, None, p(part), 2 * plan.fwd_slots, None, p(st), stream))
+        nat.check(lib.crossclr_forward_rect_save(pp, p(xhat), p(xcols), opp, 1, 0, 0.05, 0.8, sw, p(part), 2 * plan.fwd_slots, None, p(st), stream))
         out["opp_part"], out["opp_stash"] = part.clone(), st
     part.zero_()       # every other rank, the own one skipped (the plain sharded scheme)
-    nat.check(lib.crossclr_forward_w(pp, p(xhat), p(xcols), world, 0, rank, 0.05, 0.8, None, p(part), plan.fwd_slots, stream))
+    nat.check(lib.crossclr_forward_w(pp, p(xhat), p(xcols), world, 0, rank, 0.05, 0.8, sw, p(part), plan.fwd_slots, stream))
     out["skip_part"] = part.clone()
     return out
 
@@ -75,3 +82,13 @@ def test_rectangular_and_pair_launches_are_bit_identical(world, rank, b, D, monk
     for k in new:
         assert torch.equal(new[k], old[k]), k
     assert any(float(new[k].float().abs().sum()) > 0 for k in new if k.endswith("part"))
+
+
+@pytest.mark.parametrize("world,rank,b,D", [(3, 1, 128, 600), (4, 2, 128, 1000)])
+def test_weighted_rectangular_and_pair_launches_are_bit_identical(world, rank, b, D, monkeypatch):
+    monkeypatch.delenv("CROSSCLR_FWD_PAIR", raising=False)
+    new = rect_outputs(world, rank, b, D, weighted=True)
+    monkeypatch.setenv("CROSSCLR_FWD_PAIR", "0")
+    old = rect_outputs(world, rank, b, D, weighted=True)
+    for k in new:
+        assert torch.equal(new[k], old[k]), k

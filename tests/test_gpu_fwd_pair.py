@@ -77,3 +77,41 @@ def test_rectangular_and_pair_launches_are_bit_identical(world, rank, b, D, monk
         for k in new:
             assert torch.equal(new[k], old[k]), k
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,D", [(1024, 1024), (2048, 768), (8192, 1024)])
+def test_weighted_pair_forward_is_bit_identical(B, D, monkeypatch):
+    """Sample weights on the wide instantiations (BASELINE config 5's width): column scales by vmcnt-counted asm loads, blended to 1.0 for
+    inter-modal tiles -- loss and gradients bit for bit against fast_fwd_pipe_kernel<..., SW>."""
+    import crossclr_amd
+    g = torch.Generator().manual_seed(B + D)
+    v = torch.randn(B, D, generator=g).cuda()
+    t = (0.6 * v.cpu() + torch.randn(B, D, generator=g)).cuda()
+    keep = lambda: ((torch.rand(B, generator=g) > 0.3).float() * (0.5 + torch.rand(B, generator=g))).cuda()
+    kw = dict(negative_scale=(keep(), keep()), loss_weight=((torch.rand(B, generator=g) + 0.5).cuda(), (torch.rand(B, generator=g) + 0.5).cuda()))
+
+    def wstep():
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        loss = crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16", **kw)
+        loss.backward()
+        return loss.item(), vv.grad.clone(), tt.grad.clone()
+    monkeypatch.setenv("CROSSCLR_FWD_PAIR", "0")
+    lo, gvo, gto = wstep()
+    monkeypatch.delenv("CROSSCLR_FWD_PAIR")
+    for _ in range(3):
+        ln, gvn, gtn = wstep()
+        assert ln == lo and torch.equal(gvn, gvo) and torch.equal(gtn, gto)
+
+
+@pytest.mark.parametrize("world,rank,b,D", [(3, 1, 256, 1024), (8, 4, 1024, 1024), (4, 2, 384, 768)])
+def test_weighted_rectangular_and_pair_launches_are_bit_identical(world, rank, b, D, monkeypatch):
+    from test_fwd_pair_rect_emulated import rect_outputs
+    stream = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("CROSSCLR_FWD_PAIR", "0")
+    old = rect_outputs(world, rank, b, D, dev="cuda", stream=stream, weighted=True)
+    monkeypatch.delenv("CROSSCLR_FWD_PAIR")
+    for _ in range(2):
+        new = rect_outputs(world, rank, b, D, dev="cuda", stream=stream, weighted=True)
+        for k in new:
+            assert torch.equal(new[k], old[k]), k
+    torch.cuda.synchronize()
