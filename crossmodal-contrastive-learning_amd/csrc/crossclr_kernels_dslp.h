@@ -34,6 +34,13 @@ namespace crossclr {
 #define CROSSCLR_PABL 0        // timing ablations (WRONG results): bit0 no E DMA, bit1 no fragment loads, bit2 no weight VALU, bit3 no W write,
                                // bit5 no barrier, bit6 no A reads, bit7 no MFMA, bit8 no VMEM wait in front of Q3, bit9 no closing VMEM wait,
                                // bit10 no LDS waits, bit11 E from a 2-MiB window (L2-resident), bit12 fragments from 8 tiles (always L2 hits)
+                               // bit13 every block starts its walk over the column tiles' FRAGMENTS at another tile (L2-channel hot spots?)
+                               // MODELS of other block shapes (instruction and byte mix only; profiles/r05_pabl.txt):
+                               // bit14 half the fragment loads, bit15 every E piece fetched twice (same address: the second hits L2),
+                               // bit16 (with 15) the second from another part of the stash (a second HBM stream), bit17 weights, staged
+                               // reads, W writes and A reads twice  -> 14+15(+16)+17 = a 256-row x Dpad/2 block;
+                               // bit18 no k-step-1 A reads of mirrored tiles (their fragments kept in registers)
+                               // bit19 / bit20: wave w idles 32 w / 64 w cycles behind every barrier (are the four waves' VMEM bursts colliding?)
 #endif
 #ifndef CROSSCLR_PSPREAD
 #define CROSSCLR_PSPREAD 0
@@ -63,7 +70,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
     constexpr int WPAIR = 2 * 4 * 2048;    // one W slot: [2 tiles][4 row groups][2 KiB]
     constexpr int ESTG = 4 * 4096;         // one stage of the E ring: [4 waves][2 tiles x 2 KiB]
     constexpr int SSTG = 4 * 256;          // one stage of a statistics ring: [4 waves][64 floats = the pair's columns]
-    constexpr int NEO = 4 + 1 + (SW ? 1 : 0);   // VMEM operations per wave and pair behind the fragment loads: E pieces + statistics (+ k)
+    constexpr int NEO = ((CROSSCLR_PABL & 32768) ? 8 : 4) + 1 + (SW ? 1 : 0);   // VMEM operations per wave and pair behind the fragment loads: E pieces + statistics (+ k)
     constexpr int W0 = 0, E0 = W0 + 2 * WPAIR, S0 = E0 + NSE * ESTG, K0 = S0 + NSE * SSTG;
     constexpr int O0 = K0 + (SW ? NSE * SSTG : 0);      // the block's own statistics: rz[128] | wrz[128] | k[128]
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad (per part) in {128, 256, 384, 512}");
@@ -187,6 +194,11 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
         if constexpr (k < 4) {
             const unsigned off = ((CROSSCLR_PABL & 2048) ? 0x1FF800u : 0xFFFFFFFFu) & (k < 2 ? e.a : e.b);
             lds_dma16_buf(rs_e, (unsigned)(lane * 16 + 1024 * (k & 1)), off, ebuf + so + 2048 * (k >> 1) + 1024 * (k & 1));
+            if (CROSSCLR_PABL & 32768) {
+                unsigned off2 = off;
+                if (CROSSCLR_PABL & 65536) { off2 = off + (stash_bytes >> 1) & ~2047u; if (off2 >= stash_bytes) off2 -= (stash_bytes >> 1) & ~2047u; }
+                lds_dma16_buf(rs_e, (unsigned)(lane * 16 + 1024 * (k & 1)), off2, ebuf + so + 2048 * (k >> 1) + 1024 * (k & 1));
+            }
         } else if constexpr (k == 4) {
             lds_dma4_buf(cu.same ? rs_wrz : rs_rz, (unsigned)(lane * 4), cu.mt * (unsigned)(QT * 4), sbuf + (so >> 4));
         } else if constexpr (SW) {
@@ -196,6 +208,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
     auto load_xf = [&](auto setc, auto dic, auto ksc, unsigned so) {
         constexpr int S = decltype(setc)::value, di = decltype(dic)::value, kk = decltype(ksc)::value;
         if (CROSSCLR_PABL & 2) return;
+        if ((CROSSCLR_PABL & 16384) && (di & 1)) return;
         constexpr int off = (2 * di + kk) * 1024;
         BS[S][di][kk] = buf_load_b128_async<(off & 4095)>(rs_xf, off >= 4096 ? xfv1 : xfv0, (CROSSCLR_PABL & 4096) ? so % (unsigned)(8 * QT * RBG) : so);
     };
@@ -253,6 +266,16 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
         const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
         const float zz = weighted ? (rs * kq[j] + cs[j] * kr) : (rs + cs[j]);
         pk[th].e[4 * r4 + j] = (CROSSCLR_PABL & 4) ? ev.e[4 * r4 + j] : f32_to_bf16_bits(v * zz);
+    };
+    // (model bit17: the same element once more from an opaque copy of the exponential, into a second packed tile)
+    auto weigh1_again = [&](auto mir, bool same_mod, const Staged& st, Bits8 (&pk2)[2], int th, int r4, int j) {
+        constexpr bool MIR = decltype(mir)::value;
+        const float rs = MIR ? __builtin_bit_cast(float, st.rs) : (same_mod ? rzp_intra : rzp_inter);
+        const f32x4 cs = __builtin_bit_cast(f32x4, st.cs[2 * th + r4]);
+        const Bits8 ev = __builtin_bit_cast(Bits8, st.e[th]);
+        float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
+        asm volatile("" : "+v"(v));
+        pk2[th].e[4 * r4 + j] = f32_to_bf16_bits(v * (rs + cs[j]));
     };
     // wofs: byte offset of the W slot being WRITTEN (0 / WPAIR); which: tile a / b of the pair
     auto write_w = [&](auto mir, unsigned wofs, int which, const Bits8 (&pk)[2]) {
@@ -324,6 +347,8 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
 
         // loop-carried scalars of iteration j (pair at tile t): all bumped by constants in ONE slot
         unsigned xo_b = (cur_of(t).mt + 1u) * (unsigned)(QT * RBG);   // fragment offset of tile b; local block: tile a' = xo_b + QT * RBG
+        const unsigned xo_total = (unsigned)NT * (unsigned)(QT * RBG);
+        if (CROSSCLR_PABL & 8192) { xo_b += (unsigned)(2 * ((blockIdx.x * 7 + blockIdx.y * 3) % (NT / 2))) * (unsigned)(QT * RBG); if (xo_b >= xo_total) xo_b -= xo_total; }
         // RECT: the cursors of the pairs at t + 2 (fragments of tile a', weights), t + 4, t + 6 (statistics DMA) travel with the loop -- one
         // reciprocal division per iteration (the pair at t + 8)
         Cur c2 = cur_of(t + 2), c4 = cur_of(t + 4), c6 = cur_of(t + 6);
@@ -338,11 +363,13 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
             Pair Am[2][4];             // mirrored
             Staged st;
             Bits8 pk[2];
+            Bits8 pk2[2];
             const Cur cn = RECT ? c2 : cur_of(t + 2);               // the pair being weighed
             const Cur cd = RECT ? c6 : cur_of(t + 6);               // the pair whose exponentials / statistics this iteration requests
             const bool same_n = cn.same;
             const unsigned wa_rd = wofs, wa_wr = wofs ^ (unsigned)WPAIR;
-            const unsigned xo_a2 = RECT ? cn.mt * (unsigned)(QT * RBG) : xo_b + (unsigned)(QT * RBG);
+            unsigned xo_a2 = RECT ? cn.mt * (unsigned)(QT * RBG) : xo_b + (unsigned)(QT * RBG);
+            if ((CROSSCLR_PABL & 8192) && xo_a2 >= xo_total) xo_a2 -= xo_total;
             const unsigned e_wr = e_rd ^ (unsigned)(2 * ESTG);
             const EOff enext = eoff_of(t + 6);
             const auto wa = lds_addr(lds + W0 + wa_rd + (MC ? rd_mir : rd_dir));
@@ -350,11 +377,15 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
             auto read_a = [&](auto bufc, auto pic, auto thc, auto whichc) {
                 constexpr int BUF = decltype(bufc)::value, pi = decltype(pic)::value, th = decltype(thc)::value, wh = decltype(whichc)::value;
                 if (CROSSCLR_PABL & 64) return;
-                if (MC) {
-                    Am[BUF][pi].lo = lds_read_tr16_b64_async<wh * 8192 + pi * 2048 + th * 1024>(wa);
-                    Am[BUF][pi].hi = lds_read_tr16_b64_async<wh * 8192 + pi * 2048 + th * 1024 + 512>(wa);
-                } else {
-                    Ad[BUF][pi] = lds_read_b128_async<wh * 8192 + pi * 2048 + th * 1024>(wa);
+                if ((CROSSCLR_PABL & 262144) && MC && th == 1) return;
+#pragma unroll
+                for (int rep = 0; rep < ((CROSSCLR_PABL & 131072) ? 2 : 1); ++rep) {
+                    if (MC) {
+                        Am[BUF][pi].lo = lds_read_tr16_b64_async<wh * 8192 + pi * 2048 + th * 1024>(wa);
+                        Am[BUF][pi].hi = lds_read_tr16_b64_async<wh * 8192 + pi * 2048 + th * 1024 + 512>(wa);
+                    } else {
+                        Ad[BUF][pi] = lds_read_b128_async<wh * 8192 + pi * 2048 + th * 1024>(wa);
+                    }
                 }
             };
             auto a_landed = [&](auto bufc) {
@@ -394,14 +425,23 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
                     if constexpr (SPREAD && h2 == WS) { if (!(CROSSCLR_PABL & 1024)) wait_lgkm_all(); staged_landed(IdxC<MN>{}, st); }
                     static_for<NS1>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        if constexpr ((RS0 + i < WS ? RS0 + i : WS - 1) == h2 && h2 < WS + (SPREAD ? 0 : 1)) read_staged(IdxC<MN>{}, ic, wh, e_rd, same_n, st);
+                        if constexpr ((RS0 + i < WS ? RS0 + i : WS - 1) == h2 && h2 < WS + (SPREAD ? 0 : 1)) {
+                            read_staged(IdxC<MN>{}, ic, wh, e_rd, same_n, st);
+                            if (CROSSCLR_PABL & 131072) read_staged(IdxC<MN>{}, ic, wh, e_rd, same_n, st);
+                        }
                     });
                     static_for<16>([&](auto qc) {
                         constexpr int k = decltype(qc)::value;
                         constexpr int at = WS + 1 + (k * LW) / 16 < WR ? WS + 1 + (k * LW) / 16 : WR;
-                        if constexpr (at == h2) weigh1(IdxC<MN>{}, same_n, st, pk, k >> 3, (k >> 2) & 1, k & 3);
+                        if constexpr (at == h2) {
+                            weigh1(IdxC<MN>{}, same_n, st, pk, k >> 3, (k >> 2) & 1, k & 3);
+                            if (CROSSCLR_PABL & 131072) weigh1_again(IdxC<MN>{}, same_n, st, pk2, k >> 3, (k >> 2) & 1, k & 3);
+                        }
                     });
-                    if constexpr (h2 == WR) write_w(IdxC<MN>{}, wa_wr, wh, pk);
+                    if constexpr (h2 == WR) {
+                        write_w(IdxC<MN>{}, wa_wr, wh, pk);
+                        if (CROSSCLR_PABL & 131072) write_w(IdxC<MN>{}, wa_wr, wh, pk2);
+                    }
                 }
                 // ---- A reads of the NEXT quarter: 4 items from slot 1 over the first 3/4 of the quarter (complete well ahead of the
                 // boundary wait; behind the staged wait in program order: it must not cover a read issued in its own slot)
@@ -441,7 +481,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
                             a_landed(IdxC<0>{});
                             if constexpr (CROSSCLR_PSPREAD == 0) staged_landed(IdxC<MN>{}, st);
                             // tile b's k-step-0 fragments: 3 DI - 1 VMEM operations were issued behind the last of them
-                            if (!(CROSSCLR_PABL & (3 | 256))) wait_dma_keep<3 * DI - 1>();
+                            if (!(CROSSCLR_PABL & (3 | 256))) wait_dma_keep<((CROSSCLR_PABL & 16384) ? (3 * DI) / 2 : 3 * DI - 1)>();
 #pragma unroll
                             for (int d = 0; d < DI; ++d) after_wait(BS[1][d][0]);
                         }
@@ -461,11 +501,16 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
             if constexpr (RECT) {       // (behind the closing waits: scalar arithmetic only, no asm load in flight)
                 xo_b = (c2.mt + 1u) * (unsigned)(QT * RBG);
                 c2 = c4; c4 = c6; c6 = cur_of(t + 8);
-            } else xo_b += (unsigned)(2 * QT * RBG);
+            } else {
+                xo_b += (unsigned)(2 * QT * RBG);
+                if ((CROSSCLR_PABL & 8192) && xo_b >= xo_total) xo_b -= xo_total;
+            }
             t += 2;
             e_rd = (e_rd + (unsigned)ESTG) & (unsigned)(NSE * ESTG - 1);
             wofs ^= (unsigned)WPAIR;
             if (!(CROSSCLR_PABL & 32)) barrier_keep_dma();
+            if (CROSSCLR_PABL & 524288) { for (int i = 0; i < wave; ++i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); } }
+            if (CROSSCLR_PABL & 1048576) { for (int i = 0; i < wave; ++i) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); } }
         };
         if constexpr (TR) {            // every tile mirrored (the last iteration weighs a pair past the end: never consumed)
             while (t < t_end) body(IdxC<true>{}, IdxC<true>{});

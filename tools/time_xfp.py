@@ -37,5 +37,16 @@ def timed(fn, n=30):
 xfp = lambda: lib.crossclr_backward_saved_xfp(pp, p(xf), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(got), 0, stream)
 xf1 = lambda: lib.crossclr_backward_saved_xf(pp, p(xf), p(stash), 0.03, 0.8, p(rz), p(wrz), None, p(got), 0, stream)
 timed(xf1)
+if label == "clocks":       # engine clock and package power while the pair kernel runs back to back (rocm-smi from a second process)
+    import subprocess, time
+    for _ in range(2000): nat.check(xfp())
+    samples = []
+    for _ in range(3):
+        for _ in range(3000): nat.check(xfp())
+        o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout
+        samples.append(" | ".join(l.strip() for l in o.splitlines() if "sclk" in l or "Power" in l))
+    torch.cuda.synchronize()
+    print("# under load: " + " ## ".join(samples), flush=True)
+    sys.exit(0)
 r = [(timed(xfp), timed(xf1)) for _ in range(3)]
 print(f"{label:28s} xfp " + " ".join(f"{a:.4f}" for a, _ in r) + "   xf " + " ".join(f"{b:.4f}" for _, b in r), flush=True)
