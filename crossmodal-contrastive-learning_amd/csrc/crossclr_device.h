@@ -87,6 +87,13 @@ template <int MASK> __device__ __forceinline__ float lane_xor(float v) {
     return __builtin_bit_cast(float, r);
 }
 #define CROSSCLR_SHARED __shared__
+// A few values handed from thread block to thread block inside one launch WITHOUT an agent-scope fence (whose release writes back every dirty
+// line of the XCD's L2 and whose acquire drops the CU's L1: ~5 us in fwd_finish_kernel, profiles/r05k_kernel_stats.csv): the producer's store is
+// written through to the coherence point (sc1) and COMPLETE before its ticket atomic is issued; the consumer, having seen every ticket, reads
+// with sc1 loads (past its L1; MI355X_MICROARCH.md, inter-workgroup visibility: "16 B sc1 stores AND sc1 loads").
+__device__ __forceinline__ void handoff_store_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void handoff_stores_complete() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ double handoff_load_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #endif
 

@@ -509,8 +509,10 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
             e_rd = (e_rd + (unsigned)ESTG) & (unsigned)(NSE * ESTG - 1);
             wofs ^= (unsigned)WPAIR;
             if (!(CROSSCLR_PABL & 32)) barrier_keep_dma();
+#ifndef CROSSCLR_EMU
             if (CROSSCLR_PABL & 524288) { for (int i = 0; i < wave; ++i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); } }
             if (CROSSCLR_PABL & 1048576) { for (int i = 0; i < wave; ++i) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); } }
+#endif
         };
         if constexpr (TR) {            // every tile mirrored (the last iteration weighs a pair past the end: never consumed)
             while (t < t_end) body(IdxC<true>{}, IdxC<true>{});

@@ -705,21 +705,26 @@ __global__ void __launch_bounds__(256) fwd_finish_kernel(const float* part, int 
     acc = wave_sum_f64(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss_ws[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (ticket == nullptr) return;      // (crossclr_forward_finish*: fwd_finish_reduce_kernel adds the block partials up)
+    const double block_sum = (red[0] + red[1]) + (red[2] + red[3]);
+    if (ticket == nullptr) {            // (crossclr_forward_finish*: fwd_finish_reduce_kernel adds the block partials up)
+        if (threadIdx.x == 0) loss_ws[1 + blockIdx.x] = block_sum;
+        return;
+    }
     // crossclr_step_forward: the block that arrives LAST adds the partials up itself -- the same 64 lanes, strides and shuffle order as
-    // fwd_finish_reduce_kernel, hence the same bits -- and clears the ticket for whoever uses this workspace next.  Partials travel
-    // through agent-scope release (fence + atomic) / acquire (atomic + fence): the XCDs' L2s are not coherent with each other.
+    // fwd_finish_reduce_kernel, hence the same bits -- and clears the ticket for whoever uses this workspace next.  The partials travel
+    // as written-through stores, complete before the block's ticket, and are read past the L1 (crossclr_device.h, handoff_*): no
+    // agent-scope fence (its release writes back every line of the statistics the launch has just written to the XCD's L2):
+    // -2 us per step, profiles/r05n_ab_rowkernels.txt; tests/test_gpu_step_handoff.py alternates two batches on one workspace.
     if (threadIdx.x == 0) {
-        __threadfence();
+        handoff_store_f64(&loss_ws[1 + blockIdx.x], block_sum);
+        handoff_stores_complete();
         last_block = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!last_block || threadIdx.x >= 64) return;
-    __threadfence();
     const int nblocks = (int)gridDim.x;
     double tot = 0.0;
-    for (int k = threadIdx.x; k < nblocks; k += 64) tot += __builtin_nontemporal_load(&loss_ws[1 + k]);
+    for (int k = threadIdx.x; k < nblocks; k += 64) tot += handoff_load_f64(&loss_ws[1 + k]);
     tot = wave_sum_f64(tot);
     if (threadIdx.x == 0) { loss_ws[0] = tot; if (nblocks >= 1) loss_ws[1] = tot * scale; *ticket = 0; }
 }

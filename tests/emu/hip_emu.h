@@ -121,6 +121,10 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 inline void __syncthreads() { emu::t_block->bar.wait(); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+// crossclr_device.h, handoff_*: values handed from block to block inside a launch (the emulated blocks are host threads: sequentially consistent atomics)
+inline void handoff_store_f64(double* p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
+inline void handoff_stores_complete() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline double handoff_load_f64(const double* p) { double v; __atomic_load(const_cast<double*>(p), &v, __ATOMIC_SEQ_CST); return v; }
 
 namespace crossclr {
 
