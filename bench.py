@@ -17,9 +17,9 @@ batch is scored once per step); samples/s = B_global / t_step is reported next t
 Rank 0 prints ONE JSON line.
 
 Timing: `--prewarm` (default 40) untimed settle steps, then `--warmup` untimed steps, then exactly `--steps` timed steps
-between barrier + synchronize fences, max over ranks -> `ms_per_step` / `value` (wall clock, the contract's number).  Every
-timed step is also bracketed by HIP events on the compute stream: `ms_per_step_event_median` is the median of those
-(SURVEY.md 8(d)).  The settle steps exist because an MI355X that has just been handed to the process runs its first
+between barrier + synchronize fences, max over ranks -> `ms_per_step` / `value` (wall clock, the contract's number).  A second,
+untimed pass of `--steps` steps is bracketed step by step by HIP events on the compute stream: `ms_per_step_event_median` is the
+median of those (inside the timed window the two marker packets per step cost the device 5 us per step).  The settle steps exist because an MI355X that has just been handed to the process runs its first
 ~20-50 steps ~9 % slower (clock ramp); they are reported as `prewarm_steps` and named in `config.workload`.
 
 `--gpus N` without a torch.distributed launcher (WORLD_SIZE unset) re-executes itself under
@@ -416,22 +416,25 @@ def main():
         every step; with several ranks a few extra diagnostic steps with events around every wait on a collective."""
         for _ in range(args.warmup):
             loss = step()
-        # HIP events on the compute stream around every timed step (they cost ~1 us each and do not synchronise)
-        ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            if ev:
-                ev[i][0].record()
             loss = step()
-            if ev:
-                ev[i][1].record()
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
+        # HIP events around every step of a SECOND pass of K steps, outside the timed region: an event record is a marker packet in the
+        # stream, two per step cost the device 5 us per step (profiles/r05p_window.txt) -- the contract's window holds the steps alone
+        ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        if ev:
+            for i in range(args.steps):
+                ev[i][0].record()
+                loss = step()
+                ev[i][1].record()
+            fence()
         ev_ms = sorted(a.elapsed_time(z) for a, z in ev) if ev else []
         # ---- multi-rank diagnostics (untimed, after the measured region): per rank, the HIP-event time of a step and how much of it
         # the compute stream spent WAITING for collectives (events around every wait: communication not hidden behind compute) ----
@@ -639,6 +642,7 @@ def main():
         "ms_per_step": t_step * 1e3,
         "ms_per_step_event_median": ev_ms[len(ev_ms) // 2] if ev_ms else None,
         "ms_per_step_event_min_max": [ev_ms[0], ev_ms[-1]] if ev_ms else None,
+        "event_pass": "a second pass of the same K steps right after the timed window, HIP events around every step",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
         "samples_per_s": B / t_step,
