@@ -91,7 +91,23 @@ class _Workspace:
     __slots__ = ("plan", "xhat", "xcols", "inv_norm", "diag", "logz", "rz", "wrz", "rz_cols", "wrz_cols",
                  "loss_sum", "temperature", "negative_w", "world", "rank", "in_dtype", "sharded",
                  "k_rows", "k_cols", "lw", "stats_work", "stash", "shift", "shift_cols", "prenormalized",
-                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf", "xf_all", "step")
+                 "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf", "xf_all", "step", "lazy")
+
+    def __getattr__(self, name):
+        # (reached only for a slot that holds nothing yet.)  The step path leaves the views of its slab -- which only tools, tests and the
+        # fused projection's backward look at -- as (offset, bytes, dtype) entries and carves them on first use: eight dtype views per
+        # forward cost the host ~40 us (tools/host_profile.py), as much as everything in front of the first launch.
+        if name != "lazy":
+            try:
+                lazy = object.__getattribute__(self, "lazy")
+            except AttributeError:
+                lazy = None
+            if lazy and name in lazy:
+                off, nbytes, dt = lazy[name]
+                val = _carve(self.step[1], off, nbytes, dt)
+                setattr(self, name, val)
+                return val
+        raise AttributeError(name)
 
 
 _plan_cache: dict = {}
@@ -589,15 +605,18 @@ def _forward_step(video, text, temperature, negative_w, plan, mode, negative_sca
                                             ws.temperature, ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), flags, _ptr(slab), lay.total_bytes,
                                             _ptr(ws.loss_sum), _stream_for(video)))
     n2 = 2 * plan.bpad
-    view = lambda off, nbytes, dt: None if off == nat.STEP_NONE else _carve(slab, off, nbytes, dt)
-    ws.xhat = view(lay.xhat, plan.operand_bytes, torch.uint8)
-    ws.inv_norm, ws.diag = view(lay.inv_norm, 4 * n2, torch.float32), view(lay.diag, 4 * plan.bpad, torch.float32)
-    ws.logz, ws.rz, ws.wrz = (view(o, 4 * n2, torch.float32) for o in (lay.logz, lay.rz, lay.wrz))
-    ws.shift = view(lay.shift, 4 * n2, torch.float32)
-    ws.xf = view(lay.xf, lay.xf_bytes, torch.uint8)
-    ws.stash = view(lay.stash, lay.stash_bytes, torch.uint8)
-    ws.xcols, ws.rz_cols, ws.wrz_cols, ws.shift_cols = ws.xhat, ws.rz, ws.wrz, ws.shift
     ws.step = (flags, slab, lay.total_bytes, lay.backward_scratch_bytes)
+    ws.lazy = lazy = {}
+    for names, off, nbytes, dt in ((("xhat", "xcols"), lay.xhat, plan.operand_bytes, torch.uint8),
+                                   (("inv_norm",), lay.inv_norm, 4 * n2, torch.float32), (("diag",), lay.diag, 4 * plan.bpad, torch.float32),
+                                   (("logz",), lay.logz, 4 * n2, torch.float32), (("rz", "rz_cols"), lay.rz, 4 * n2, torch.float32),
+                                   (("wrz", "wrz_cols"), lay.wrz, 4 * n2, torch.float32), (("shift", "shift_cols"), lay.shift, 4 * n2, torch.float32),
+                                   (("xf",), lay.xf, lay.xf_bytes, torch.uint8), (("stash",), lay.stash, lay.stash_bytes, torch.uint8)):
+        for name in names:
+            if off == nat.STEP_NONE:
+                setattr(ws, name, None)
+            else:
+                lazy[name] = (off, nbytes, dt)      # carved on first use (_Workspace.__getattr__)
     global _last_step_backward_kernel, _last_step_saved
     _last_step_backward_kernel, _last_step_saved = lay.backward_kernel, bool(lay.saved)
     return ws.loss_sum[1], ws      # = sum / (2 B), written by the finish kernel
