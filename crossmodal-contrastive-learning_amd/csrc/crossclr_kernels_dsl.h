@@ -373,7 +373,9 @@ __device__ __forceinline__ void dsl_wave(unsigned char* lds, const bf16_t* cols,
 #pragma unroll
         for (int j = 2 * hh; j < 2 * hh + 2; ++j) {
             const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
-            const float zz = weighted ? (rs * kq[j] + cs[j] * kr) : (rs + cs[j]);
+            // (one expression for every tile of a weighted launch: scales of 1.0 for the other modality's tiles give rs + cs exactly;
+            //  crossclr_kernels_dslp.h forms the same FMA from ones it reads out of LDS)
+            const float zz = SW ? __builtin_fmaf(rs, kq[j], cs[j] * (weighted ? kr : 1.f)) : (rs + cs[j]);
             pk[th].e[4 * r4 + j] = (CROSSCLR_DABL & 4) ? ev.e[4 * r4 + j] : f32_to_bf16_bits(v * zz);
         }
     };

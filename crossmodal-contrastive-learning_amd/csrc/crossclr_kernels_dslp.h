@@ -73,9 +73,10 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
     constexpr int NEO = ((CROSSCLR_PABL & 32768) ? 8 : 4) + 1 + (SW ? 1 : 0);   // VMEM operations per wave and pair behind the fragment loads: E pieces + statistics (+ k)
     constexpr int W0 = 0, E0 = W0 + 2 * WPAIR, S0 = E0 + NSE * ESTG, K0 = S0 + NSE * SSTG;
     constexpr int O0 = K0 + (SW ? NSE * SSTG : 0);      // the block's own statistics: rz[128] | wrz[128] | k[128]
+    constexpr int O1 = O0 + 3 * 512;                    // SW: 64 floats of 1.0 -- the negative scales of a tile of the OTHER modality
     static_assert(DK % 8 == 0 && DK >= 8 && DK <= 32, "Dpad (per part) in {128, 256, 384, 512}");
-    static_assert(O0 + 3 * 512 <= 160 * 1024, "LDS budget");
-    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[O0 + 3 * 512];
+    static_assert(O1 + 256 <= 160 * 1024, "LDS budget");
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[O1 + 256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = uniform(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
         own[tid] = rz[row0b + tid];
         own[128 + tid] = wrz[row0b + tid];
         own[256 + tid] = SW ? ks[row0b + tid] : 1.f;
+        if (tid < 64) reinterpret_cast<float*>(lds + O1)[tid] = 1.f;
     }
     const float rzp_inter = rz[row0w + l31];
     const float rzp_intra = wrz[row0w + l31];
@@ -226,9 +228,13 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
             const auto ed = lds_addr(ebuf + so + 2048 * which + 16 * lane);
             st.e[0] = lds_read_b128_async<0>(ed);
             st.e[1] = lds_read_b128_async<1024>(ed);
+            // SW: W = E (rs k_q + cs k_r) for EVERY tile -- one multiply and one FMA per element, no select: a tile of the other modality reads
+            // its column scales and the row's own scale as 1.0 (the ones at O1), which makes the sum rs + cs exactly
             if (MIR) {
                 st.rs = lds_read_b32_async<0>(lds_addr(sbuf + (so >> 4) + 128 * which + 4 * l31));
-                if (SW) st.kr = lds_read_b32_async<0>(lds_addr(kbuf + (so >> 4) + 128 * which + 4 * l31));
+                if (SW) st.kr = lds_read_b32_async<0>(same ? lds_addr(kbuf + (so >> 4) + 128 * which + 4 * l31) : lds_addr(lds + O1 + 4 * l31));
+            } else if (SW) {
+                st.kr = __builtin_bit_cast(unsigned, same ? kp : 1.f);
             }
         } else if constexpr (P == 1) {
             // quad (th, r4): columns 16th + 8r4 + 4half ..+3 -- of the tile (direct) or of this wave's own row group (mirrored)
@@ -238,7 +244,8 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
             st.cs[2] = lds_read_b128_async<64>(sa);
             st.cs[3] = lds_read_b128_async<96>(sa);
         } else if constexpr (SW) {
-            const auto ka = MIR ? lds_addr(lds + O0 + 1024 + 128 * wave + 16 * half) : lds_addr(kbuf + (so >> 4) + 128 * which + 16 * half);
+            const auto ka = !same ? lds_addr(lds + O1 + 16 * half)
+                                  : (MIR ? lds_addr(lds + O0 + 1024 + 128 * wave + 16 * half) : lds_addr(kbuf + (so >> 4) + 128 * which + 16 * half));
             st.kc[0] = lds_read_b128_async<0>(ka);
             st.kc[1] = lds_read_b128_async<32>(ka);
             st.kc[2] = lds_read_b128_async<64>(ka);
@@ -256,15 +263,14 @@ __global__ void __launch_bounds__(256, 1) fast_bwd_xfp_kernel(const unsigned cha
     // order are those of crossclr_kernels_dsl.h: the two kernels produce the same bits).  One element = 3 VALU: a chore per MFMA slot.
     auto weigh1 = [&](auto mir, bool same_mod, const Staged& st, Bits8 (&pk)[2], int th, int r4, int j) {
         constexpr bool MIR = decltype(mir)::value;
-        const bool weighted = SW && same_mod;
         const float rs = MIR ? __builtin_bit_cast(float, st.rs) : (same_mod ? rzp_intra : rzp_inter);
-        const float kr = MIR ? (SW ? __builtin_bit_cast(float, st.kr) : 1.f) : kp;
+        const float kr = SW ? __builtin_bit_cast(float, st.kr) : 1.f;
         const f32x4 cs = __builtin_bit_cast(f32x4, st.cs[2 * th + r4]);
         f32x4 kq = {1.f, 1.f, 1.f, 1.f};
-        if (weighted) kq = __builtin_bit_cast(f32x4, st.kc[2 * th + r4]);
+        if (SW) kq = __builtin_bit_cast(f32x4, st.kc[2 * th + r4]);
         const Bits8 ev = __builtin_bit_cast(Bits8, st.e[th]);
         const float v = bf16_bits_to_f32(ev.e[4 * r4 + j]);
-        const float zz = weighted ? (rs * kq[j] + cs[j] * kr) : (rs + cs[j]);
+        const float zz = SW ? __builtin_fmaf(rs, kq[j], cs[j] * kr) : (rs + cs[j]);     // (crossclr_kernels_dsl.h: the same expression, the same bits)
         pk[th].e[4 * r4 + j] = (CROSSCLR_PABL & 4) ? ev.e[4 * r4 + j] : f32_to_bf16_bits(v * zz);
     };
     // (model bit17: the same element once more from an opaque copy of the exponential, into a second packed tile)
