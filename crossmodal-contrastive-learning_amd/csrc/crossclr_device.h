@@ -101,26 +101,41 @@ __device__ __forceinline__ double handoff_load_f64(const double* p) { return __h
 // Work list of the persistent forward, in COST UNITS (shared by the forward kernels, the plan and fwd_finish_kernel).
 // Items = (row block, column tile) pairs, row-block major; a thread block owns the items whose first unit falls into its
 // contiguous range of `per` units.  Rectangular lists (kind 2 / 3): one unit per item.  Symmetric lists (kind 1): the tpr tiles
-// of a row block's diagonal block take the masked, un-overlapped epilogue -- measured at twice a plain tile (tools/timeline.py:
-// the thread block that held the last row blocks' 24 diagonal tiles ran 193 us against a median of 150) -- and loading a row
-// block's fragments costs about one tile: item 0 = 3 units, items 1 .. tpr-1 = 2 units, the rest 1.
+// of a row block's diagonal block take the masked, un-overlapped epilogue and entering a row block means loading its fragments.
+// Costs measured on fast_fwd_pair_kernel by regressing the thread blocks' main-loop times of one launch on their ranges' composition
+// (tools/fwd_balance.py, profiles/r05u_fwd_balance.txt): a masked tile = 1.50 plain tiles, a row-block start = 1.82 -- in half-tile
+// units: plain 2, masked 3, item 0 (start + masked) 7.  (Round 4's kernel, whose plain tiles were slower: 1 / 2 / 3.)
 // ---------------------------------------------------------------------------------------------
+#ifndef CROSSCLR_FWD_COST_PLAIN
+#define CROSSCLR_FWD_COST_PLAIN 2
+#define CROSSCLR_FWD_COST_MASKED 3
+#define CROSSCLR_FWD_COST_FIRST 7
+#endif
+constexpr int kFwdCostPlain = CROSSCLR_FWD_COST_PLAIN, kFwdCostMasked = CROSSCLR_FWD_COST_MASKED, kFwdCostFirst = CROSSCLR_FWD_COST_FIRST;
 __host__ __device__ __forceinline__ int fwdw_items(int kind, int tpr, int NT, int rb) { return kind == 1 ? NT - tpr * rb : NT; }
 __host__ __device__ __forceinline__ int fwdw_item_prefix(int kind, int tpr, int NT, int rb) {      // items before row block rb
     return kind == 1 ? rb * NT - (tpr / 2) * rb * (rb - 1) : rb * NT;
 }
 __host__ __device__ __forceinline__ int fwdw_unit_prefix(int kind, int tpr, int NT, int rb) {      // units before row block rb
-    return kind == 1 ? rb * (NT + tpr + 1) - (tpr / 2) * rb * (rb - 1) : rb * NT;
+    // every row block of a symmetric list has its tpr diagonal tiles (NT = tpr * NB): first + (tpr - 1) masked + plain for the rest
+    return kind == 1 ? rb * (kFwdCostFirst + (tpr - 1) * kFwdCostMasked - tpr * kFwdCostPlain) + kFwdCostPlain * (rb * NT - (tpr / 2) * rb * (rb - 1))
+                     : rb * NT;
 }
 __host__ __device__ __forceinline__ int fwdw_unit_of_item(int kind, int tpr, int j) {              // first unit of item j of its row block
-    return kind != 1 ? j : (j == 0 ? 0 : (j < tpr ? 2 * j + 1 : j + tpr + 1));
+    if (kind != 1) return j;
+    if (j == 0) return 0;
+    return j < tpr ? kFwdCostFirst + (j - 1) * kFwdCostMasked : kFwdCostFirst + (tpr - 1) * kFwdCostMasked + (j - tpr) * kFwdCostPlain;
 }
 __host__ __device__ __forceinline__ int fwdw_item_at_unit(int kind, int tpr, int u) {              // first item whose first unit is >= u
     if (kind != 1) return u;
     if (u <= 0) return 0;
-    int j = u / 2 > 1 ? u / 2 : 1;
-    if (j >= tpr) j = u - tpr - 1 > tpr ? u - tpr - 1 : tpr;
-    return j;
+    const int base = kFwdCostFirst + (tpr - 1) * kFwdCostMasked;      // first unit of item tpr
+    if (u > base - kFwdCostMasked) {                                  // beyond the first unit of item tpr - 1
+        const int j = tpr + (u - base + kFwdCostPlain - 1) / kFwdCostPlain;
+        return j > tpr ? j : tpr;
+    }
+    const int j = 1 + (u - kFwdCostFirst + kFwdCostMasked - 1) / kFwdCostMasked;
+    return u <= kFwdCostFirst ? 1 : j;
 }
 __host__ __device__ __forceinline__ int fwdw_first_block(int kind, int tpr, int NT, int per, int rb) {
     return fwdw_unit_prefix(kind, tpr, NT, rb) / per;
@@ -159,8 +174,8 @@ static inline FwdWork fwd_make_work(int kind, int bpad, int usable_col_tiles, in
     w.total = fwd_prefix(w, w.NB);
     const int units = fwdw_unit_prefix(kind, tpr, w.NT, w.NB);
     // every thread block between a row block's first and last one must hold at least one of its items (its slot is summed):
-    // a range is never shorter than the longest item (3 units in a symmetric list)
-    const int min_per = kind == 1 ? 3 : 2;
+    // a range is never shorter than the longest item (item 0 of a symmetric list)
+    const int min_per = kind == 1 ? kFwdCostFirst : 2;
     int nb = units / min_per;
     if (nb > max_blocks) nb = max_blocks;
     if (nb < 1) nb = 1;

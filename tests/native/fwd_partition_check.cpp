@@ -4,8 +4,8 @@
 //   * every thread block from a row block's first to its last one owns at least one of its items (fwd_finish_kernel sums those slots),
 //     and no other block owns any;
 //   * a row block never needs more slots than fwd_max_slots says;
-//   * symmetric lists: the cost of the heaviest range (tiles + one extra per diagonal tile + one per row block entered) stays within
-//     a few units of the mean -- the equal-length cut this replaces was off by a third at B = 8192.
+//   * symmetric lists: the cost of the heaviest range (plain and masked tiles + entering a row block, at the measured costs the list
+//     is cut by) stays within a few tiles of the mean -- the equal-length cut this replaces was off by a third at B = 8192.
 #include "crossclr_device.h"
 #include <stdio.h>
 #include <vector>
@@ -33,8 +33,13 @@ static int check(int kind, int bpad, int usable, int max_blocks, int tpr, bool v
             const bool inside = b >= fb && b <= lb;
             if ((owned > 0) != inside) { printf("kind %d bpad %d rb %d: block %d owns %d items but first/last = %d/%d\n", kind, bpad, rb, b, owned, fb, lb); ++bad; }
             if (owned > 0) {
-                cost[b] += owned + 1;                                         // + entering the row block
-                if (kind == 1) { const int d0 = lo - i0, d1 = hi - i0; cost[b] += (d1 < tpr ? d1 : tpr) - (d0 < tpr ? d0 : tpr) > 0 ? (d1 < tpr ? d1 : tpr) - (d0 < tpr ? d0 : tpr) : 0; }
+                // the measured model the list is cut by (crossclr_device.h): plain tile, masked tile, entering the row block
+                const int enter = kFwdCostFirst - kFwdCostMasked;
+                if (kind == 1) {
+                    const int d0 = lo - i0, d1 = hi - i0;
+                    const int masked = (d1 < tpr ? d1 : tpr) - (d0 < tpr ? d0 : tpr) > 0 ? (d1 < tpr ? d1 : tpr) - (d0 < tpr ? d0 : tpr) : 0;
+                    cost[b] += (long)(owned - masked) * kFwdCostPlain + (long)masked * kFwdCostMasked + enter;
+                } else cost[b] += owned + 1;
             }
         }
     }
@@ -69,7 +74,7 @@ static int check(int kind, int bpad, int usable, int max_blocks, int tpr, bool v
             if (worst_span > w.NT / 2) { printf("kind 1 bpad %d: an XCD's ranges start %d column tiles apart\n", bpad, worst_span); ++bad; }
         }
     }
-    if (kind == 1 && w.nblk >= 8 && worst > mean + 6) { printf("kind 1 bpad %d: heaviest range %ld vs mean %.1f\n", bpad, worst, mean); ++bad; }
+    if (kind == 1 && w.nblk >= 8 && worst > mean + 6 * kFwdCostPlain) { printf("kind 1 bpad %d: heaviest range %ld vs mean %.1f\n", bpad, worst, mean); ++bad; }
     return bad;
 }
 

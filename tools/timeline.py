@@ -27,6 +27,8 @@ stages = {
     "forward_save": lambda: lib.crossclr_forward_save(pp, p(ws.xhat), 0.03, 0.8, None, p(part), 0, p(ws.stash), stream),
     "backward_saved": lambda: lib.crossclr_backward_saved(pp, p(ws.xhat), p(ws.stash), 0.03, 0.8, p(ws.rz), p(ws.wrz), None, p(gbuf), 0, stream),
 }
+if ws.xf is not None:       # the step's own backward: the pair kernel on the fragment-major operand
+    stages["backward_saved_xfp"] = lambda: lib.crossclr_backward_saved_xfp(pp, p(ws.xf), p(ws.stash), 0.03, 0.8, p(ws.rz), p(ws.wrz), None, p(gbuf), 0, stream)
 TICK = 10.0   # ns per s_memrealtime tick
 
 
@@ -60,7 +62,7 @@ for name, fn in stages.items():
         sel = xcc == x
         print(f"     XCC {x}: {sel.sum():3d} blocks, start {start[sel].min():6.2f}..{start[sel].max():6.2f}, exit {end[sel].min():7.2f}..{end[sel].max():7.2f} us, "
               f"main loop median {pct((loop_end - first)[sel], 50):7.2f}, shader clock {np.median(clk[sel]):.3f} GHz")
-    if name == "backward_saved" and nb == 256:      # block = row block x (128 rows) + 128 * column slice y
+    if name.startswith("backward_saved") and nb == 256:      # block = row block x (128 rows) + 128 * column slice y
         ml = (loop_end - first).reshape(2, 128)
         for y in range(2):
             print(f"     slice {y}: main loop by row block, means of 16: " + " ".join(f"{ml[y, k:k + 16].mean():6.1f}" for k in range(0, 128, 16)))
