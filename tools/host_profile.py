@@ -29,6 +29,20 @@ for _ in range(N):
     fwd += b - a; bwd += c - b
 torch.cuda.synchronize()
 print(f"forward() {1e6 * fwd / N:.1f} us, backward() {1e6 * bwd / N:.1f} us")
+# the two C calls alone (ctypes marshalling + the library's launches)
+lib = crossclr_amd._native.library()
+acc = {"crossclr_step_forward": 0.0, "crossclr_step_backward": 0.0}
+orig = {k: getattr(lib, k) for k in acc}
+def wrap(name):
+    f = orig[name]
+    def g(*a):
+        t0 = time.perf_counter(); r = f(*a); acc[name] += time.perf_counter() - t0; return r
+    return g
+for k in acc: setattr(lib, k, wrap(k))
+for _ in range(N): step()
+torch.cuda.synchronize()
+for k in acc: setattr(lib, k, orig[k])
+print("inside the C calls: " + ", ".join(f"{k} {1e6 * v / N:.1f} us" for k, v in acc.items()))
 pr = cProfile.Profile(); pr.enable()
 for _ in range(N): step()
 pr.disable(); torch.cuda.synchronize()
