@@ -571,6 +571,9 @@ def main():
             dist.destroy_process_group()
         return
 
+    # (the timed steps were the last launches so far: which kernel templates the library took for them)
+    _lib = nat.library()
+    step_kernels = [(_lib.crossclr_last_kernel(i) or b"").decode() for i in (0, 1)]
     # ---- per-kernel HIP-event timing of the single-GPU stages (roofline of the dominant kernel) ----
     sw = crossclr_amd.influential_sample_weights(xv, xt, 0.9, 0.0035) if args.influential else (None, None)
     st = _profile.stage_times(v.detach(), t.detach(), TAU, NEG_W, args.mode, iters=20, warmup=3,
@@ -598,10 +601,12 @@ def main():
                 ex = 4.0 * b * b * d * (1.0 + (256.0 if st["fast_path"] else 128.0) / (2.0 * b)) / (st[k] * 1e-3) / 1e12
                 kernels[k].update(executed_tflops=round(ex, 2), frac_executed=round(ex / peak, 4))
     saved = bool(st.get("saved_path"))
+    # what the library itself launched for the step's forward / gradient product (crossclr_last_kernel, ABI 7; asked right after the step's own
+    # passes, before the recomputing / alternative entry points of the per-kernel table run)
+    launched = {"forward": step_kernels[0], "gradient_product": step_kernels[1]}
     if args.fwd_only:
         # (whole 128-row batches without sample weights take round 5's forward: csrc/crossclr_kernels_symp.h)
-        fwd_name = "fast_fwd_pair_kernel" if (b % 128 == 0 and not args.influential and os.environ.get("CROSSCLR_FWD_PAIR", "1") != "0") else "fast_fwd_pipe_kernel"
-        dom, dom_kernel = "forward", (fwd_name if st["fast_path"] else "fwd_sums_kernel<float, false, 0, false>")
+        dom, dom_kernel = "forward", (launched["forward"] or ("fast_fwd_pipe_kernel" if st["fast_path"] else "fwd_sums_kernel"))
     else:
         dom = "backward_saved" if saved else "backward"
         dom_kernel = (("fast_bwd_dsl_kernel" if st["fast_path"] else "bwd_saved32_kernel") if saved
@@ -644,6 +649,10 @@ def main():
         "ms_per_step_event_min_max": [ev_ms[0], ev_ms[-1]] if ev_ms else None,
         "event_pass": "a second pass of the same K steps right after the timed window, HIP events around every step",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "methodology": "since round 5: the K timed steps start after an adaptive settle loop (`settle_steps_used`, three 20-step chunks within 1 %, "
+                       "cap 400) and carry no per-step events (those are a second pass: `event_pass`); rounds 1-4 timed the K steps right after the "
+                       "warm-up with events inside the window -- `value` is not comparable across that change (BENCH_r04 -> r05: 0.4649 -> 0.4183 "
+                       "ms/step, of which ~0.02 is methodology, see DESIGN.md 3.3)",
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
         "samples_per_s": B / t_step,
         "config": {"workload": (f"PLUMBING CHECK, NOT A MEASUREMENT ({world} ranks share ONE GPU, collectives over gloo): " if args.share_gpu else "") +
@@ -675,6 +684,7 @@ def main():
                      "whole_step_frac": round(step_tf / peak, 4),
                      },
         "kernels": kernels,
+        "launched": launched,
     }
     if args.fwd_only and world == 1:
         ex = 4.0 * b * b * d * (1.0 + (256.0 if st["fast_path"] else 128.0) / (2.0 * b)) / (dom_ms * 1e-3) / 1e12

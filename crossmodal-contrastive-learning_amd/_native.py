@@ -19,7 +19,7 @@ HIP_LIBRARY = os.environ.get("CROSSCLR_HIP_LIBRARY", os.path.join(_HERE, "libcro
 MODE_FP32, MODE_BF16 = 0, 1
 IN_F32, IN_F16, IN_BF16, IN_F64 = 0, 1, 2, 3
 E_RANGE = -2
-ABI_VERSION = 6
+ABI_VERSION = 7
 LAUNCH_GROUPS = 8      # CROSSCLR_LAUNCH_GROUPS of include/crossclr.h
 
 
@@ -40,11 +40,13 @@ class SampleWeights(ctypes.Structure):
 
 
 class StepLayout(ctypes.Structure):
-    """crossclr_step_layout: what crossclr_step_plan decided for one step and where the pieces live in its workspace."""
-    _fields_ = [("total_bytes", ctypes.c_size_t), ("backward_scratch_bytes", ctypes.c_size_t)] + \
+    """crossclr_step_layout: what crossclr_step_plan decided for one step and where the pieces live in its two workspace regions
+    (offsets into [persistent | transient]); handed unmodified to crossclr_step_forward and crossclr_step_backward."""
+    _fields_ = [(n, ctypes.c_size_t) for n in ("total_bytes", "persistent_bytes", "transient_bytes", "backward_scratch_bytes")] + \
                [(n, ctypes.c_size_t) for n in ("xhat", "inv_norm", "diag", "logz", "rz", "wrz", "part", "shift", "xf", "stash", "gbuf", "ticket")] + \
                [("stash_bytes", ctypes.c_size_t), ("xf_bytes", ctypes.c_size_t),
-                ("two_pass", ctypes.c_int), ("saved", ctypes.c_int), ("backward_kernel", ctypes.c_int)]
+                ("temperature", ctypes.c_float), ("negative_weight", ctypes.c_float), ("flags", ctypes.c_uint),
+                ("two_pass", ctypes.c_int), ("saved", ctypes.c_int), ("backward_kernel", ctypes.c_int), ("check", ctypes.c_uint)]
 
 
 STEP_NO_SAVE, STEP_FORWARD_ONLY, STEP_PRENORMALIZED, STEP_NO_XFP, STEP_NO_XF, STEP_EAGER = 1, 2, 4, 8, 16, 32
@@ -163,14 +165,21 @@ _SIGNATURES = {
     "crossclr_maxmargin_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P]),
     "crossclr_maxmargin_backward_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                                           _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P]),
-    # ABI version 6: the whole single-device step behind two calls (the kernel-selection policy lives in the library)
+    # ABI version 6: the whole single-device step behind two calls (the kernel-selection policy lives in the library);
+    # ABI version 7: the layout crossclr_step_plan wrote is handed to both calls, the workspace is a persistent and a transient region
     "crossclr_step_plan": (ctypes.c_int, [ctypes.POINTER(Plan), ctypes.c_float, ctypes.c_float, ctypes.c_uint, ctypes.c_size_t,
                                           ctypes.POINTER(StepLayout)]),
-    "crossclr_step_forward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_float,
-                                             ctypes.c_float, ctypes.POINTER(SampleWeights), ctypes.c_uint, _P, ctypes.c_size_t, _P, _P]),
-    "crossclr_step_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_float,
-                                              ctypes.c_float, ctypes.POINTER(SampleWeights), ctypes.c_uint, _P, ctypes.c_size_t, _P, _P, _P, _P,
-                                              ctypes.c_long, ctypes.c_long, _P]),
+    "crossclr_step_forward": (ctypes.c_int, [ctypes.POINTER(Plan), ctypes.POINTER(StepLayout), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                             ctypes.POINTER(SampleWeights), _P, _P, _P, _P]),
+    "crossclr_step_backward": (ctypes.c_int, [ctypes.POINTER(Plan), ctypes.POINTER(StepLayout), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                              ctypes.POINTER(SampleWeights), _P, _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P]),
+    # ABI version 7: second-order terms (double backward of the loss) in closed form on the device
+    "crossclr_second_order_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Plan)]),
+    "crossclr_second_order": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                             ctypes.POINTER(SampleWeights), ctypes.c_int, _P, _P, ctypes.c_long, ctypes.c_long, _P, _P, ctypes.c_size_t,
+                                             _P, _P, ctypes.c_long, ctypes.c_long, _P, _P]),
+    # ABI version 7 (reporting aid): the kernel template the process's most recent forward (0) / gradient-product (1) launch went to
+    "crossclr_last_kernel": (ctypes.c_char_p, [ctypes.c_int]),
     # measurement aid (bench.py: the matrix pipe's sustained rate on this device, in the run that quotes it)
     "crossclr_mfma_sustained": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, _P]),
 }

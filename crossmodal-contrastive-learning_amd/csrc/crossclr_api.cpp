@@ -4,6 +4,7 @@
 // the kernel source lane by lane on CPU threads -- test infrastructure only.
 #include "../../include/crossclr.h"
 #include "crossclr_kernels_generic.h"
+#include "crossclr_kernels_hvp.h"
 #ifndef CROSSCLR_NO_FAST
 #include "crossclr_kernels_fast.h"
 #include "crossclr_kernels_project.h"
@@ -33,13 +34,25 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// which kernel template the most recent forward (0) / gradient-product (1) launch of this process went to (crossclr_last_kernel; pointers to
+// string literals, written whole: a reader on another thread -- autograd runs backward() on its own -- sees the old or the new name)
+static const char* volatile g_last_kernel[2] = {"", ""};
+namespace crossclr {
+void note_kernel(int which, const char* name) { g_last_kernel[which & 1] = name; }
+}  // namespace crossclr
+static void note_generic_launch(const char* what) {      // (the generic kernels are launched from this file: their launch_status label names them)
+    if (!strncmp(what, "fwd_sums_kernel", 15)) crossclr::note_kernel(0, what);
+    else if (!strncmp(what, "bwd_kernel", 10) || !strncmp(what, "bwd_saved32_kernel", 18)) crossclr::note_kernel(1, what);
+}
+
 #ifdef CROSSCLR_EMU
 #define LAUNCH(kernel, grid, block, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)
-static int launch_status(const char*) { return CROSSCLR_OK; }
+static int launch_status(const char* what) { note_generic_launch(what); return CROSSCLR_OK; }
 #else
 #define LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 static int launch_status(const char* what) {
+    note_generic_launch(what);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CROSSCLR_E_HIP, "%s: %s", what, hipGetErrorString(e));
     return CROSSCLR_OK;
@@ -48,6 +61,7 @@ static int launch_status(const char* what) {
 
 extern "C" int crossclr_abi_version(void) { return CROSSCLR_ABI_VERSION; }
 extern "C" const char* crossclr_last_error(void) { return g_err; }
+extern "C" const char* crossclr_last_kernel(int which) { return g_last_kernel[which & 1]; }
 extern "C" const char* crossclr_backend(void) {
 #ifdef CROSSCLR_EMU
     return "emu-host";
@@ -1685,11 +1699,17 @@ __global__ void __launch_bounds__(256, 1) mfma_sustained_kernel(float* out, int 
 }  // namespace crossclr
 
 // ------------------------------------------------------------------------------------------------
-// The whole step behind two calls (include/crossclr.h, ABI 6): the kernel-selection policy that used to live in the Python module.
-// Composition of the entry points above; every decision is a pure function of (plan, temperature, negative_weight, flags, workspace_bytes).
+// The whole step behind two calls (include/crossclr.h, ABI 6 / 7): the kernel-selection policy that used to live in the Python module.
+// Composition of the entry points above.  crossclr_step_plan decides everything -- it is the only one of the three that reads the
+// environment -- and writes the decision into the layout; forward and backward act on the layout they are handed (sealed with a check word).
 static size_t step_max_stash_bytes() {
     const char* e = getenv("CROSSCLR_MAX_STASH_GB");
-    const double gb = e ? atof(e) : 8.0;
+    double gb = 8.0;
+    if (e) {
+        char* end = nullptr;
+        const double v = strtod(e, &end);
+        if (end != e && isfinite(v)) gb = v < 0.0 ? 0.0 : (v > 1024.0 ? 1024.0 : v);      // (garbage: the default; negative: no stash)
+    }
     return (size_t)(gb * (double)((size_t)1 << 30));
 }
 // Padded widths at which the fragment-major saved backward beats the LDS-staged one (profiles/r03_xf_widths.txt: wins from 512 up, ties at
@@ -1713,6 +1733,24 @@ static bool step_use_xf(const crossclr_plan* p) {
     return false;
 }
 static size_t step_align(size_t x) { return (x + 255) / 256 * 256; }
+// FNV-1a over the plan and every layout field in front of `check`: a layout the library did not write for this plan is refused
+static unsigned step_check(const crossclr_plan* plan, const crossclr_step_layout* L) {
+    unsigned h = 2166136261u;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 16777619u;
+    };
+    // (field by field: struct padding is not part of the value)
+    const int pi[] = {plan->b, plan->D, plan->world, plan->rank, plan->mode, plan->bpad, plan->Dpad, plan->fast_path, plan->fast_bwd,
+                      plan->fwd_blocks, plan->fwd_slots, plan->bwd_slices, plan->loss_ws_doubles};
+    const size_t pz[] = {plan->fwd_ws_floats, plan->operand_bytes, plan->gbuf_bytes, plan->stash_bytes, plan->xf_bytes};
+    const size_t lz[] = {L->total_bytes, L->persistent_bytes, L->transient_bytes, L->backward_scratch_bytes, L->xhat, L->inv_norm, L->diag,
+                         L->logz, L->rz, L->wrz, L->part, L->shift, L->xf, L->stash, L->gbuf, L->ticket, L->stash_bytes, L->xf_bytes};
+    const int li[] = {(int)L->flags, L->two_pass, L->saved, L->backward_kernel};
+    mix(pi, sizeof(pi)); mix(pz, sizeof(pz)); mix(lz, sizeof(lz)); mix(li, sizeof(li));
+    mix(&L->temperature, sizeof(float)); mix(&L->negative_weight, sizeof(float));
+    return h ? h : 1u;
+}
 
 extern "C" int crossclr_step_plan(const crossclr_plan* plan, float temperature, float negative_weight, unsigned flags,
                                   size_t workspace_bytes, crossclr_step_layout* L) {
@@ -1720,45 +1758,66 @@ extern "C" int crossclr_step_plan(const crossclr_plan* plan, float temperature, 
     if (plan->world != 1) return fail(CROSSCLR_E_ARG, "crossclr_step_* is the single-device step (plan->world == 1); sharded runs compose the fine-grained entry points around their collectives");
     if (!(temperature > 0.f) || !isfinite(temperature) || !isfinite(negative_weight)) return fail(CROSSCLR_E_ARG, "temperature must be > 0 and finite, negative_weight finite");
     const bool two_pass = needs_row_shift(temperature, negative_weight);
+    const bool fwd_only = (flags & CROSSCLR_STEP_FORWARD_ONLY) != 0;
     const bool may_save = !(flags & (CROSSCLR_STEP_NO_SAVE | CROSSCLR_STEP_FORWARD_ONLY));
+    const bool eager = (flags & CROSSCLR_STEP_EAGER) && !fwd_only;
     const size_t stash_full = two_pass ? crossclr_stash_bytes_s(plan) : plan->stash_bytes;
+    const size_t max_stash = step_max_stash_bytes();
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool saved = attempt == 0 && may_save && stash_full > 0 && stash_full <= step_max_stash_bytes();
+        const bool saved = attempt == 0 && may_save && stash_full > 0 && stash_full <= max_stash;
         if (attempt == 0 && !saved) continue;
-        const bool xf = saved && !two_pass && plan->xf_bytes > 0 && step_use_xf(plan);
+        // which saved backward: the fragment-major copy is only laid out (and written by the forward's first kernel) when a kernel that reads it is allowed
+        int backward_kernel = saved ? 1 : 0;
+        if (saved && !two_pass && plan->xf_bytes > 0 && step_use_xf(plan)) {
+            const char* e = getenv("CROSSCLR_XFP");
+            const bool xfp_ok = plan->stash_bytes < ((size_t)1 << 32) && !(e && e[0] == '0') && !(flags & CROSSCLR_STEP_NO_XFP);
+            const bool xf1_ok = plan->Dpad <= 1024 && !(flags & CROSSCLR_STEP_NO_XF);     // (wide plans: the pair kernel or the LDS-staged one)
+            backward_kernel = xfp_ok ? 3 : (xf1_ok ? 2 : 1);
+        }
+        const bool xf = backward_kernel >= 2;
         memset(L, 0, sizeof(*L));
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off += step_align(bytes); return o; };
         const size_t n2 = (size_t)2 * plan->bpad;
-        L->xhat = take(plan->operand_bytes);
-        L->inv_norm = take(4 * n2);
+        L->shift = L->xf = L->stash = L->gbuf = CROSSCLR_STEP_NONE;
+        // region 1 (persistent): what the backward call reads
+        if (eager) {                    // the finish kernel alone: 1 / ||x|| and the gradient slices
+            L->inv_norm = take(4 * n2);
+            L->gbuf = take(plan->gbuf_bytes);
+        } else if (!fwd_only) {         // the gradient product (from saved exponentials, or recomputed: also what a backward without `transient` does)
+            L->xhat = take(plan->operand_bytes);
+            L->inv_norm = take(4 * n2);
+            L->rz = take(4 * n2);
+            L->wrz = take(4 * n2);
+            if (two_pass) L->shift = take(4 * n2);
+        }
+        L->persistent_bytes = off;
+        // region 2 (transient)
+        if (eager || fwd_only) {
+            L->xhat = take(plan->operand_bytes);
+            if (fwd_only) L->inv_norm = take(4 * n2);
+            L->rz = take(4 * n2);
+            L->wrz = take(4 * n2);
+            if (two_pass) L->shift = take(4 * n2);
+        }
         L->diag = take(4 * (size_t)plan->bpad);
         L->logz = take(4 * n2);
-        L->rz = take(4 * n2);
-        L->wrz = take(4 * n2);
         L->part = take(4 * plan->fwd_ws_floats);
         L->ticket = take(4);
-        L->shift = two_pass ? take(4 * n2) : CROSSCLR_STEP_NONE;
-        L->xf = xf ? take(plan->xf_bytes) : CROSSCLR_STEP_NONE;
-        L->stash = saved ? take(stash_full) : CROSSCLR_STEP_NONE;
-        const bool eager = (flags & CROSSCLR_STEP_EAGER) && !(flags & CROSSCLR_STEP_FORWARD_ONLY);
-        L->gbuf = eager ? take(plan->gbuf_bytes) : CROSSCLR_STEP_NONE;
+        if (xf) L->xf = take(plan->xf_bytes);
+        if (saved) L->stash = take(stash_full);
         L->xf_bytes = xf ? plan->xf_bytes : 0;
         L->stash_bytes = saved ? stash_full : 0;
         L->total_bytes = off;
-        L->backward_scratch_bytes = ((flags & CROSSCLR_STEP_FORWARD_ONLY) || eager) ? 0 : plan->gbuf_bytes;
+        L->transient_bytes = off - L->persistent_bytes;
+        L->backward_scratch_bytes = (fwd_only || eager) ? 0 : plan->gbuf_bytes;
+        L->temperature = temperature;
+        L->negative_weight = negative_weight;
+        L->flags = flags;
         L->two_pass = two_pass ? 1 : 0;
         L->saved = saved ? 1 : 0;
-        L->backward_kernel = 0;
-        if (saved) {
-            L->backward_kernel = 1;
-            if (xf) {
-                const char* e = getenv("CROSSCLR_XFP");
-                const bool xfp_ok = plan->stash_bytes < ((size_t)1 << 32) && !(e && e[0] == '0') && !(flags & CROSSCLR_STEP_NO_XFP);
-                const bool xf1_ok = plan->Dpad <= 1024 && !(flags & CROSSCLR_STEP_NO_XF);     // (wide plans: the pair kernel or the LDS-staged one)
-                L->backward_kernel = xfp_ok ? 3 : (xf1_ok ? 2 : 1);
-            }
-        }
+        L->backward_kernel = backward_kernel;
+        L->check = step_check(plan, L);
         if (workspace_bytes == 0 || off <= workspace_bytes) return CROSSCLR_OK;
     }
     return fail(CROSSCLR_E_WORKSPACE, "workspace of %zu bytes is below the recomputing layout's %zu", workspace_bytes, L->total_bytes);
@@ -1767,24 +1826,40 @@ extern "C" int crossclr_step_plan(const crossclr_plan* plan, float temperature, 
 namespace {
 struct StepBufs {
     crossclr_step_layout L;
-    unsigned char* w;
-    void* xhat() const { return w + L.xhat; }
-    float* f(size_t off) const { return off == CROSSCLR_STEP_NONE ? nullptr : reinterpret_cast<float*>(w + off); }
-    void* v(size_t off) const { return off == CROSSCLR_STEP_NONE ? nullptr : static_cast<void*>(w + off); }
+    unsigned char *persistent, *transient;
+    unsigned char* at(size_t off) const {
+        if (off == CROSSCLR_STEP_NONE) return nullptr;
+        if (off < L.persistent_bytes) return persistent + off;
+        return transient ? transient + (off - L.persistent_bytes) : nullptr;
+    }
+    void* xhat() const { return at(L.xhat); }
+    float* f(size_t off) const { return reinterpret_cast<float*>(at(off)); }
+    void* v(size_t off) const { return at(off); }
 };
 }  // namespace
-static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, float temperature, float negative_weight, const float* k,
-                                 float* gbuf, void* stream);
+static int step_bind(const crossclr_plan* plan, const crossclr_step_layout* layout, void* persistent, void* transient, bool transient_needed,
+                     StepBufs* B) {
+    if (!plan || !layout) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (layout->check == 0 || layout->check != step_check(plan, layout))
+        return fail(CROSSCLR_E_ARG, "this crossclr_step_layout was not written by crossclr_step_plan for this plan (or was modified since)");
+    if (layout->persistent_bytes > 0 && !persistent) return fail(CROSSCLR_E_ARG, "persistent is NULL (layout.persistent_bytes = %zu)", layout->persistent_bytes);
+    if (transient_needed && layout->transient_bytes > 0 && !transient) return fail(CROSSCLR_E_ARG, "transient is NULL (layout.transient_bytes = %zu)", layout->transient_bytes);
+    B->L = *layout;
+    B->persistent = static_cast<unsigned char*>(persistent);
+    B->transient = static_cast<unsigned char*>(transient);
+    return CROSSCLR_OK;
+}
+static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, const float* k, float* gbuf, bool from_saved, void* stream);
 
-extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
-                                     float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
-                                     void* workspace, size_t workspace_bytes, double* loss_ws, void* stream) {
-    if (!workspace || !loss_ws || !video || !text) return fail(CROSSCLR_E_ARG, "NULL argument");
-    if (workspace_bytes == 0) return fail(CROSSCLR_E_WORKSPACE, "workspace_bytes must be the size of the buffer (crossclr_step_plan reports what is needed)");
+extern "C" int crossclr_step_forward(const crossclr_plan* plan, const crossclr_step_layout* layout, const void* video, const void* text,
+                                     long ld_video, long ld_text, int in_dtype, const crossclr_sample_weights* sw,
+                                     void* persistent, void* transient, double* loss_ws, void* stream) {
+    if (!loss_ws || !video || !text) return fail(CROSSCLR_E_ARG, "NULL argument");
     StepBufs B;
-    if (int rc = crossclr_step_plan(plan, temperature, negative_weight, flags, workspace_bytes, &B.L)) return rc;
-    B.w = static_cast<unsigned char*>(workspace);
+    if (int rc = step_bind(plan, layout, persistent, transient, true, &B)) return rc;
     const crossclr_step_layout& L = B.L;
+    const float temperature = L.temperature, negative_weight = L.negative_weight;
+    const unsigned flags = L.flags;
     const float* k = sw ? sw->neg_scale_rows : nullptr;
     const float* lw = sw ? sw->loss_weight : nullptr;
     const crossclr_sample_weights sw_k = {k, k, nullptr}, sw_klw = {k, k, lw};
@@ -1793,7 +1868,7 @@ extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* vide
     const bool pre = (flags & CROSSCLR_STEP_PRENORMALIZED) != 0;
     int rc;
     // loss.py:79-80 (+ the packed operand, 1 / ||x||, the positive pairs' cosines; with a fragment-major saved backward to follow: its operand copy)
-    int* ticket = reinterpret_cast<int*>(B.w + L.ticket);      // cleared by this first kernel, taken by the finish kernel's blocks
+    int* ticket = reinterpret_cast<int*>(B.at(L.ticket));      // cleared by this first kernel, taken by the finish kernel's blocks
     if (L.xf != CROSSCLR_STEP_NONE)
         rc = pre ? normalize_xf_any<false>(plan, video, text, ld_video, ld_text, in_dtype, B.xhat(), B.v(L.xf), B.f(L.inv_norm), B.f(L.diag), stream, ticket)
                  : normalize_xf_any<true>(plan, video, text, ld_video, ld_text, in_dtype, B.xhat(), B.v(L.xf), B.f(L.inv_norm), B.f(L.diag), stream, ticket);
@@ -1810,7 +1885,7 @@ extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* vide
         rc = forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, B.f(L.shift),
                                  B.f(L.logz), B.f(L.rz), B.f(L.wrz), loss_ws, stream, ticket);
         if (rc || L.gbuf == CROSSCLR_STEP_NONE) return rc;
-        return step_gradient_product(plan, B, temperature, negative_weight, k, B.f(L.gbuf), stream);
+        return step_gradient_product(plan, B, k, B.f(L.gbuf), L.saved != 0, stream);
     }
     // loss.py:83-100, 59-60: soft-max denominators of the local block (and, saving, its exponentials)
     rc = L.saved ? crossclr_forward_save(plan, B.xhat(), temperature, negative_weight, pk, B.f(L.part), 0, B.v(L.stash), stream)
@@ -1820,21 +1895,22 @@ extern "C" int crossclr_step_forward(const crossclr_plan* plan, const void* vide
     rc = forward_finish_impl(plan, B.f(L.part), plan->fwd_slots, B.f(L.diag), temperature, negative_weight, pklw, nullptr, B.f(L.logz), B.f(L.rz),
                              B.f(L.wrz), loss_ws, stream, ticket);
     if (rc || L.gbuf == CROSSCLR_STEP_NONE) return rc;
-    return step_gradient_product(plan, B, temperature, negative_weight, k, B.f(L.gbuf), stream);      // CROSSCLR_STEP_EAGER
+    return step_gradient_product(plan, B, k, B.f(L.gbuf), L.saved != 0, stream);      // CROSSCLR_STEP_EAGER
 }
 
-// autograd of loss.py:83-112: gbuf = d(loss)/d(unit rows), unscaled, in column slices (independent of grad_out)
-static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, float temperature, float negative_weight, const float* k,
-                                 float* gbuf, void* stream) {
+// autograd of loss.py:83-112: gbuf = d(loss)/d(unit rows), unscaled, in column slices (independent of grad_out).
+// from_saved = false: the recomputing product (a step that did not save, or a backward whose caller has released the transient region)
+static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, const float* k, float* gbuf, bool from_saved, void* stream) {
     const crossclr_step_layout& L = B.L;
+    const float temperature = L.temperature, negative_weight = L.negative_weight;
     const crossclr_sample_weights sw_k = {k, k, nullptr};
     const crossclr_sample_weights* pk = k ? &sw_k : nullptr;
     float *rz = B.f(L.rz), *wrz = B.f(L.wrz);
     if (L.two_pass)
-        return L.saved ? crossclr_backward_saved_s(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream)
-                       : crossclr_backward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk,
-                                             B.f(L.shift), B.f(L.shift), gbuf, 0, stream);
-    if (L.saved) {
+        return from_saved ? crossclr_backward_saved_s(plan, B.xhat(), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream)
+                          : crossclr_backward_s(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk,
+                                                B.f(L.shift), B.f(L.shift), gbuf, 0, stream);
+    if (from_saved) {
         switch (L.backward_kernel) {
             case 3: return crossclr_backward_saved_xfp(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream);
             case 2: return crossclr_backward_saved_xf(plan, B.v(L.xf), B.v(L.stash), temperature, negative_weight, rz, wrz, pk, gbuf, 0, stream);
@@ -1844,17 +1920,15 @@ static int step_gradient_product(const crossclr_plan* plan, const StepBufs& B, f
     return crossclr_backward_w(plan, B.xhat(), B.xhat(), 1, plan->rank, -1, temperature, negative_weight, rz, wrz, rz, wrz, pk, gbuf, 0, stream);
 }
 
-extern "C" int crossclr_step_backward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
-                                      float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
-                                      void* workspace, size_t workspace_bytes, void* scratch, const double* grad_out,
+extern "C" int crossclr_step_backward(const crossclr_plan* plan, const crossclr_step_layout* layout, const void* video, const void* text,
+                                      long ld_video, long ld_text, int in_dtype, const crossclr_sample_weights* sw,
+                                      void* persistent, void* transient, void* scratch, const double* grad_out,
                                       void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext, void* stream) {
-    if (!workspace || !video || !text || !grad_out || !grad_video || !grad_text) return fail(CROSSCLR_E_ARG, "NULL argument");
-    if (flags & CROSSCLR_STEP_FORWARD_ONLY) return fail(CROSSCLR_E_ARG, "the forward of this step was declared CROSSCLR_STEP_FORWARD_ONLY");
-    if (workspace_bytes == 0) return fail(CROSSCLR_E_WORKSPACE, "workspace_bytes must be the size given to crossclr_step_forward");
+    if (!video || !text || !grad_out || !grad_video || !grad_text) return fail(CROSSCLR_E_ARG, "NULL argument");
     StepBufs B;
-    if (int rc = crossclr_step_plan(plan, temperature, negative_weight, flags, workspace_bytes, &B.L)) return rc;
-    B.w = static_cast<unsigned char*>(workspace);
+    if (int rc = step_bind(plan, layout, persistent, transient, false, &B)) return rc;
     const crossclr_step_layout& L = B.L;
+    if (L.flags & CROSSCLR_STEP_FORWARD_ONLY) return fail(CROSSCLR_E_ARG, "the forward of this step was declared CROSSCLR_STEP_FORWARD_ONLY");
     const float* k = sw ? sw->neg_scale_rows : nullptr;
     const float* lw = sw ? sw->loss_weight : nullptr;
     const crossclr_sample_weights sw_lw = {nullptr, nullptr, lw};
@@ -1864,11 +1938,162 @@ extern "C" int crossclr_step_backward(const crossclr_plan* plan, const void* vid
     } else {
         if (!scratch) return fail(CROSSCLR_E_ARG, "scratch is NULL (layout.backward_scratch_bytes bytes)");
         gbuf = static_cast<float*>(scratch);
-        if (int rc = step_gradient_product(plan, B, temperature, negative_weight, k, gbuf, stream)) return rc;
+        // (transient == NULL: released after an earlier backward through this step -- everything the recomputing product reads is persistent)
+        if (int rc = step_gradient_product(plan, B, k, gbuf, L.saved != 0 && transient != nullptr, stream)) return rc;
     }
     // autograd of loss.py:79-80 + the positive-pair term, x grad_out, in the input dtype
-    return crossclr_backward_finish_p(plan, gbuf, video, text, ld_video, ld_text, in_dtype, B.f(L.inv_norm), temperature, lw ? &sw_lw : nullptr, grad_out,
-                                      grad_video, grad_text, ld_gvideo, ld_gtext, (flags & CROSSCLR_STEP_PRENORMALIZED) ? 1 : 0, stream);
+    return crossclr_backward_finish_p(plan, gbuf, video, text, ld_video, ld_text, in_dtype, B.f(L.inv_norm), L.temperature, lw ? &sw_lw : nullptr, grad_out,
+                                      grad_video, grad_text, ld_gvideo, ld_gtext, (L.flags & CROSSCLR_STEP_PRENORMALIZED) ? 1 : 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second-order terms (include/crossclr.h, ABI 7; crossclr_kernels_hvp.h): what autograd's double backward through loss.py:79-114 computes,
+// composed of the exact-fp32 first-order entry points above and the two passes of hvp_kernel.
+namespace {
+struct HvpLayout {
+    size_t xhat, vhat, inv_norm, diag, logz, rz, wrz, shift, drz, dwrz, part, loss_ws, gbuf1, dzpart, gbuf2, dgo_rows, total;
+    int nz;
+};
+}  // namespace
+static int hvp_layout(const crossclr_plan* plan, HvpLayout* H) {
+    if (!plan) return fail(CROSSCLR_E_ARG, "plan is NULL");
+    if (plan->world != 1) return fail(CROSSCLR_E_ARG, "crossclr_second_order is single-device (plan->world == 1)");
+    if (plan->mode != CROSSCLR_MODE_FP32 || plan->fast_path) return fail(CROSSCLR_E_ARG, "crossclr_second_order takes a CROSSCLR_MODE_FP32 plan (second-order terms are formed from exact-fp32 products)");
+    const size_t n2 = (size_t)2 * plan->bpad;
+    const int rb = 2 * plan->bpad / 64, ntiles = 2 * plan->bpad / 64;
+    int nz = (1024 + rb - 1) / rb;
+    if (nz > ntiles) nz = ntiles;
+    if (nz > 16) nz = 16;
+    if (nz < 1) nz = 1;
+    H->nz = nz;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += step_align(bytes); return o; };
+    H->xhat = take(plan->operand_bytes);
+    H->vhat = take(plan->operand_bytes);
+    H->inv_norm = take(4 * n2);
+    H->diag = take(4 * (size_t)plan->bpad);
+    H->logz = take(4 * n2);
+    H->rz = take(4 * n2);
+    H->wrz = take(4 * n2);
+    H->shift = take(4 * n2);
+    H->drz = take(4 * n2);
+    H->dwrz = take(4 * n2);
+    H->part = take(4 * plan->fwd_ws_floats);
+    H->loss_ws = take(8 * (size_t)(plan->loss_ws_doubles > 2 ? plan->loss_ws_doubles : 2));
+    H->gbuf1 = take(plan->gbuf_bytes);
+    H->dzpart = take(4 * (size_t)nz * n2);
+    H->gbuf2 = take(4 * (size_t)nz * n2 * plan->Dpad);
+    H->dgo_rows = take(8 * n2);
+    H->total = off;
+    return CROSSCLR_OK;
+}
+extern "C" size_t crossclr_second_order_workspace_bytes(const crossclr_plan* plan) {
+    HvpLayout H;
+    return hvp_layout(plan, &H) ? 0 : H.total;
+}
+
+template <typename TIN>
+static int second_order_impl(const crossclr_plan* plan, const HvpLayout& H, const Geo& g, const TIN* video, const TIN* text, long ldv, long ldt,
+                             float temperature, float negative_weight, const float* k, const float* lw, int prenormalized, bool two_pass,
+                             const TIN* uvideo, const TIN* utext, long lduv, long ldut, const double* grad_out, unsigned char* w,
+                             TIN* hvideo, TIN* htext, long ldhv, long ldht, double* d_grad_out, void* stream) {
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(w + off); };
+    const int n2 = 2 * plan->bpad;
+    const float* shift = two_pass ? F(H.shift) : nullptr;
+    // v = the tangent of the unit rows along u
+    LAUNCH((hvp_tangent_kernel<TIN>), dim3((unsigned)((n2 + 3) / 4)), dim3(256), stream, video, text, ldv, ldt, uvideo, utext, lduv, ldut, g,
+           F(H.inv_norm), prenormalized, F(H.vhat));
+    if (int rc = launch_status("hvp_tangent_kernel")) return rc;
+    const int rb = n2 / 64, ntiles = n2 / 64;
+    const int tps = (ntiles + H.nz - 1) / H.nz;
+    const float* X = F(H.xhat);
+    const float* V = F(H.vhat);
+    // pass 1: dZ, then the tangents of omega / Z
+    if (k) LAUNCH((hvp_kernel<64, true, 1>), dim3(rb, 1, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), kNoF, kNoF, k, shift, F(H.dzpart), tps);
+    else LAUNCH((hvp_kernel<64, false, 1>), dim3(rb, 1, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), kNoF, kNoF, kNoF, shift, F(H.dzpart), tps);
+    if (int rc = launch_status("hvp_kernel (row sums)")) return rc;
+    LAUNCH(hvp_stats_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), stream, F(H.dzpart), H.nz, n2, F(H.rz), lw, negative_weight, F(H.drz), F(H.dwrz));
+    if (int rc = launch_status("hvp_stats_kernel")) return rc;
+    // pass 2: dG in column slices
+#define CROSSCLR_LH(DC)                                                                                                                              \
+    do {                                                                                                                                             \
+        if (k) LAUNCH((hvp_kernel<DC, true, 2>), dim3(rb, plan->Dpad / DC, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz), F(H.dwrz), \
+                      k, shift, F(H.gbuf2), tps);                                                                                                    \
+        else LAUNCH((hvp_kernel<DC, false, 2>), dim3(rb, plan->Dpad / DC, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz), F(H.dwrz),  \
+                    kNoF, shift, F(H.gbuf2), tps);                                                                                                   \
+    } while (0)
+    if (plan->Dpad % 128 == 0) CROSSCLR_LH(128);
+    else CROSSCLR_LH(64);
+#undef CROSSCLR_LH
+    if (int rc = launch_status("hvp_kernel (product)")) return rc;
+    // the row-local chain: normalisation, positive pairs, x grad_out; and <u, dL/d(rows)>
+    double* dgo_rows = reinterpret_cast<double*>(w + H.dgo_rows);
+    LAUNCH((hvp_finish_kernel<TIN>), dim3((unsigned)((2 * plan->b + 3) / 4)), dim3(256), stream, F(H.gbuf1), plan->bwd_slices, F(H.gbuf2), H.nz, video, text,
+           ldv, ldt, uvideo, utext, lduv, ldut, g, F(H.inv_norm), 1.f / temperature, plan->b * plan->world, grad_out, lw, prenormalized, hvideo, htext,
+           ldhv, ldht, dgo_rows);
+    if (int rc = launch_status("hvp_finish_kernel")) return rc;
+    LAUNCH(hvp_reduce_kernel, dim3(1), dim3(64), stream, dgo_rows, 2 * plan->b, d_grad_out);
+    return launch_status("hvp_reduce_kernel");
+}
+
+extern "C" int crossclr_second_order(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                                     float temperature, float negative_weight, const crossclr_sample_weights* sw, int prenormalized,
+                                     const void* u_video, const void* u_text, long ld_uvideo, long ld_utext, const double* grad_out,
+                                     void* workspace, size_t workspace_bytes, void* h_video, void* h_text, long ld_hvideo, long ld_htext,
+                                     double* d_grad_out, void* stream) {
+    if (!video || !text || !u_video || !u_text || !grad_out || !workspace || !h_video || !h_text || !d_grad_out) return fail(CROSSCLR_E_ARG, "NULL argument");
+    HvpLayout H;
+    if (int rc = hvp_layout(plan, &H)) return rc;
+    if (workspace_bytes < H.total) return fail(CROSSCLR_E_WORKSPACE, "workspace of %zu bytes, crossclr_second_order_workspace_bytes says %zu", workspace_bytes, H.total);
+    if (prenormalized != 0 && prenormalized != 1) return fail(CROSSCLR_E_ARG, "prenormalized must be 0 or 1");
+    if (ld_video < plan->D || ld_text < plan->D || ld_uvideo < plan->D || ld_utext < plan->D || ld_hvideo < plan->D || ld_htext < plan->D)
+        return fail(CROSSCLR_E_ARG, "row stride smaller than D");
+    unsigned char* w = static_cast<unsigned char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(w + off); };
+    const float* k = sw ? sw->neg_scale_rows : nullptr;
+    const float* lw = sw ? sw->loss_weight : nullptr;
+    const crossclr_sample_weights sw_k = {k, k, nullptr}, sw_klw = {k, k, lw};
+    const crossclr_sample_weights* pk = k ? &sw_k : nullptr;
+    const crossclr_sample_weights* pklw = (k || lw) ? &sw_klw : nullptr;
+    const bool two_pass = needs_row_shift(temperature, negative_weight);
+    Geo g;
+    if (int rc = make_geo(plan, 1, plan->rank, -1, temperature, negative_weight, &g, true)) return rc;
+    // the first-order pieces, exact fp32: unit rows, soft-max statistics, the gradient product (loss.py:79-112 and its autograd)
+    int rc = prenormalized ? normalize_any<false>(plan, video, text, ld_video, ld_text, in_dtype, w + H.xhat, F(H.inv_norm), F(H.diag), stream)
+                           : normalize_any<true>(plan, video, text, ld_video, ld_text, in_dtype, w + H.xhat, F(H.inv_norm), F(H.diag), stream);
+    if (rc) return rc;
+    double* loss_ws = reinterpret_cast<double*>(w + H.loss_ws);
+    if (two_pass) {
+        rc = crossclr_forward_rowmax(plan, w + H.xhat, w + H.xhat, 1, plan->rank, -1, temperature, negative_weight, pk, F(H.part), F(H.shift), 0, stream);
+        if (rc) return rc;
+        rc = crossclr_forward_s(plan, w + H.xhat, w + H.xhat, 1, plan->rank, -1, temperature, negative_weight, pk, F(H.shift), F(H.part), 0, stream);
+        if (rc) return rc;
+        rc = forward_finish_impl(plan, F(H.part), plan->fwd_slots, F(H.diag), temperature, negative_weight, pklw, F(H.shift), F(H.logz), F(H.rz), F(H.wrz),
+                                 loss_ws, stream, nullptr);
+        if (rc) return rc;
+        rc = crossclr_backward_s(plan, w + H.xhat, w + H.xhat, 1, plan->rank, -1, temperature, negative_weight, F(H.rz), F(H.wrz), F(H.rz), F(H.wrz), pk,
+                                 F(H.shift), F(H.shift), F(H.gbuf1), 0, stream);
+    } else {
+        rc = crossclr_forward_w(plan, w + H.xhat, w + H.xhat, 1, plan->rank, -1, temperature, negative_weight, pk, F(H.part), 0, stream);
+        if (rc) return rc;
+        rc = forward_finish_impl(plan, F(H.part), plan->fwd_slots, F(H.diag), temperature, negative_weight, pklw, nullptr, F(H.logz), F(H.rz), F(H.wrz),
+                                 loss_ws, stream, nullptr);
+        if (rc) return rc;
+        rc = crossclr_backward_w(plan, w + H.xhat, w + H.xhat, 1, plan->rank, -1, temperature, negative_weight, F(H.rz), F(H.wrz), F(H.rz), F(H.wrz), pk,
+                                 F(H.gbuf1), 0, stream);
+    }
+    if (rc) return rc;
+    switch (in_dtype) {
+#define CROSSCLR_SO(TIN) second_order_impl<TIN>(plan, H, g, (const TIN*)video, (const TIN*)text, ld_video, ld_text, temperature, negative_weight, k, lw, \
+                                                prenormalized, two_pass, (const TIN*)u_video, (const TIN*)u_text, ld_uvideo, ld_utext, grad_out, w,       \
+                                                (TIN*)h_video, (TIN*)h_text, ld_hvideo, ld_htext, d_grad_out, stream)
+        case CROSSCLR_IN_F32: return CROSSCLR_SO(float);
+        case CROSSCLR_IN_F64: return CROSSCLR_SO(double);
+        case CROSSCLR_IN_F16: return CROSSCLR_SO(in_f16);
+        case CROSSCLR_IN_BF16: return CROSSCLR_SO(in_bf16);
+#undef CROSSCLR_SO
+        default: return fail(CROSSCLR_E_ARG, "bad in_dtype %d", in_dtype);
+    }
 }
 
 extern "C" int crossclr_mfma_sustained(float* out, int blocks, int iters, unsigned seed, int zero_operands, void* stream) {

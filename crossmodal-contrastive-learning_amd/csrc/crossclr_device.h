@@ -28,6 +28,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef unsigned short bf16_t;  // storage type of a bf16 element in memory
 
 constexpr int kRowPad = 128;     // rows of every packed operand are padded to this
+// host side: the launchers record which kernel template a forward (0) / gradient-product (1) launch of this thread went to
+// (crossclr_last_kernel, include/crossclr.h; defined in crossclr_api.cpp)
+void note_kernel(int which, const char* name);
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -91,9 +94,21 @@ template <int MASK> __device__ __forceinline__ float lane_xor(float v) {
 // line of the XCD's L2 and whose acquire drops the CU's L1: ~5 us in fwd_finish_kernel, profiles/r05k_kernel_stats.csv): the producer's store is
 // written through to the coherence point (sc1) and COMPLETE before its ticket atomic is issued; the consumer, having seen every ticket, reads
 // with sc1 loads (past its L1; MI355X_MICROARCH.md, inter-workgroup visibility: "16 B sc1 stores AND sc1 loads").
+// This ordering is a property of the TARGET, not of the HIP memory model (relaxed atomics give no happens-before): it rests on gfx942 / gfx950
+// writing agent-scope atomic stores through to the coherence point and on vmcnt counting stores (gfx10+ count them in vscnt).  The device pass
+// of any other target gets the portable form: a release fence in front of the ticket, an acquire fence behind it.
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__) || defined(__gfx942__)
 __device__ __forceinline__ void handoff_store_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void handoff_stores_complete() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ double handoff_load_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+__device__ __forceinline__ void handoff_store_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void handoff_stores_complete() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ double handoff_load_f64(const double* p) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 #endif
 

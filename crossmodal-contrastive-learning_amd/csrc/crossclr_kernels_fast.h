@@ -828,6 +828,7 @@ int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, c
 CROSSCLR_LEAF int fast_forward_pair(const crossclr_plan* p, const Geo& g, const FwdWork& wk, const void* rows, const void* cols, float* part,
                                     float* colpart, int* header, int kind, const float* krows, const float* kcols, void* stash,
                                     size_t stash_bytes, const FwdPerm& perm, void* stream) {
+    note_kernel(0, "fast_fwd_pair_kernel");
     const bf16_t* r = (const bf16_t*)rows;
     const bf16_t* c = (const bf16_t*)cols;
     unsigned char* st = (unsigned char*)stash;
@@ -924,6 +925,7 @@ CROSSCLR_LEAF int fast_forward_pipe(const crossclr_plan* p, const Geo& g, const 
             col_segs * 2 * p->bpad * p->Dpad * 2 < ((size_t)1 << 32))
             return fast_forward_pair(p, g, wk, rows, cols, part, colpart, header, kind, krows, kcols, stash, sbytes, perm, stream);
     }
+    note_kernel(0, "fast_fwd_pipe_kernel");
 #define CROSSCLR_LP3(DK, KIND, SW, ST) \
     CROSSCLR_FAST_LAUNCH((fast_fwd_pipe_kernel<DK, KIND, SW, ST>), grid, block, stream, r, c, g, wk, part, colpart, header, krows, kcols, st, perm)
 #define CROSSCLR_LP2(DK, KIND)                                   \
@@ -1021,6 +1023,7 @@ struct SavedLaunch {      // one launch of a saved backward, as the leaves below
 int launch_saved_xfp(const SavedLaunch& a);
 #else
 CROSSCLR_LEAF int launch_saved_xfp(const SavedLaunch& a) {
+    note_kernel(1, "fast_bwd_xfp_kernel");
     const crossclr_plan* p = a.p;
     const Geo& g = a.g;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
@@ -1067,6 +1070,7 @@ CROSSCLR_LEAF int launch_saved_xfp(const SavedLaunch& a) {
 int launch_saved_xf1(const SavedLaunch& a);
 #else
 CROSSCLR_LEAF int launch_saved_xf1(const SavedLaunch& a) {
+    note_kernel(1, "fast_bwd_dsl_kernel (fragment-major, one tile)");
     const crossclr_plan* p = a.p;
     const Geo& g = a.g;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
@@ -1108,6 +1112,7 @@ CROSSCLR_LEAF int launch_saved_xf1(const SavedLaunch& a) {
 int launch_saved_lds(const SavedLaunch& a);
 #else
 CROSSCLR_LEAF int launch_saved_lds(const SavedLaunch& a) {
+    note_kernel(1, "fast_bwd_dsl_kernel (LDS-staged)");
     const crossclr_plan* p = a.p;
     const Geo& g = a.g;
     dim3 grid(2 * p->bpad / 128, p->bwd_slices), block(256);
@@ -1160,6 +1165,7 @@ int launch_saved_wide(const SavedLaunch& a);
 int launch_saved_wide_xfp(const SavedLaunch& a);
 #else
 CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
+    note_kernel(1, "fast_bwd_dsl_kernel (wide, column parts)");
     const crossclr_plan* p = a.p;
     const Geo& g = a.g;
     dim3 block(256);
@@ -1195,6 +1201,7 @@ CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
 }
 // the same on the fragment-major operand with the pair kernel (crossclr_kernels_dslp.h): what the module takes from 4096 padded rows on
 CROSSCLR_LEAF int launch_saved_wide_xfp(const SavedLaunch& a) {
+    note_kernel(1, "fast_bwd_xfp_kernel (wide, column parts)");
     const crossclr_plan* p = a.p;
     const Geo& g = a.g;
     dim3 block(256);
@@ -1272,6 +1279,7 @@ CROSSCLR_LEAF int fast_backward16(const crossclr_plan* p, const Geo& g, const vo
                                   const float* rz_rows, const float* wrz_rows, const float* rz_cols,
                                   const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
                                   const float* kcols, void* stream) {
+    note_kernel(1, "fast_bwd16_kernel (recomputing)");
     const bool sw = krows != nullptr && kcols != nullptr;
     const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
     const int ntiles = (g.col_ranks - (skipping ? 1 : 0)) * 2 * p->bpad / 32;   // usable column tiles
@@ -1304,6 +1312,7 @@ CROSSCLR_LEAF int fast_backward(const crossclr_plan* p, const Geo& g, const void
                                 const float* rz_rows, const float* wrz_rows, const float* rz_cols,
                                 const float* wrz_cols, float* gbuf, int accumulate, const float* krows,
                                 const float* kcols, void* stream) {
+    note_kernel(1, "fast_bwd_kernel (recomputing)");
     const bool sw = krows != nullptr && kcols != nullptr;
     const bool skipping = g.skip_rank >= g.col_rank0 && g.skip_rank < g.col_rank0 + g.col_ranks;
     const int ntiles = (g.col_ranks - (skipping ? 1 : 0)) * 2 * p->bpad / 32;   // usable column tiles

@@ -101,7 +101,7 @@ class _Workspace:
                  "saved_blocks", "recompute_ranges", "exchange", "k_work", "group", "partner_peers", "xf", "xf_all", "step", "lazy")
 
     def __getattr__(self, name):
-        # (reached only for a slot that holds nothing yet.)  The step path leaves the views of its slab -- which only tools, tests and the
+        # (reached only for a slot that holds nothing yet.)  The step path leaves the views of its workspace -- which only tools, tests and the
         # fused projection's backward look at -- as (offset, bytes, dtype) entries and carves them on first use: eight dtype views per
         # forward cost the host ~40 us (tools/host_profile.py), as much as everything in front of the first launch.
         if name != "lazy":
@@ -111,10 +111,30 @@ class _Workspace:
                 lazy = None
             if lazy and name in lazy:
                 off, nbytes, dt = lazy[name]
-                val = _carve(self.step[1], off, nbytes, dt)
+                lay, persistent, transient = self.step
+                if off < lay.persistent_bytes:
+                    val = _carve(persistent, off, nbytes, dt)
+                elif transient is not None:
+                    val = _carve(transient, off - lay.persistent_bytes, nbytes, dt)
+                else:
+                    val = None      # (lived in the transient region, which has been given back)
                 setattr(self, name, val)
                 return val
         raise AttributeError(name)
+
+    def release_transient(self) -> None:
+        """Step path: give the transient workspace region (saved exponentials, fragment-major copy, partial sums: most of the bytes) back to
+        the allocator.  Called once nothing the step will still launch reads it: right after crossclr_step_forward with
+        CROSSCLR_STEP_EAGER, after the first backward otherwise (a later backward through the same graph recomputes).  Stream-ordered:
+        the caching allocator reuses the block on the stream the kernels were enqueued on."""
+        if self.step is None or self.step[2] is None:
+            return
+        lay, persistent, _ = self.step
+        self.step = (lay, persistent, None)
+        lazy = self.lazy or {}
+        for name, (off, _, _) in lazy.items():
+            if off >= lay.persistent_bytes:
+                setattr(self, name, None)
 
 
 _plan_cache: dict = {}
@@ -597,22 +617,29 @@ def _forward_step(video, text, temperature, negative_w, plan, mode, negative_sca
     if save_for_backward and os.environ.get("CROSSCLR_EAGER_BACKWARD", "1") != "0":
         flags |= nat.STEP_EAGER
     flags, lay = _step_flags(plan, flags, ws.temperature, ws.negative_w, ws.k_rows is not None, dev)
+    # Two caller-owned regions (include/crossclr.h, ABI 7): `persistent` is what crossclr_step_backward reads (with the eager gradient product:
+    # 1 / ||x|| and the gradient slices), `transient` the rest -- saved exponentials, fragment-major copy, partial sums -- which the autograd
+    # function gives back as soon as nothing reads it any more (`_Workspace.release_transient`).
+    def regions():
+        return (torch.empty(lay.persistent_bytes, dtype=torch.uint8, device=dev) if lay.persistent_bytes else None,
+                torch.empty(lay.transient_bytes, dtype=torch.uint8, device=dev))
     try:
-        slab = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+        persistent, transient = regions()
     except torch.OutOfMemoryError:
         if not lay.saved:
             raise
+        persistent = transient = None
         flags |= nat.STEP_NO_SAVE          # the saved exponentials do not fit: the recomputing pair
         nat.check(lib.crossclr_step_plan(ctypes.byref(plan), ws.temperature, ws.negative_w, flags, 0, ctypes.byref(lay)))
-        slab = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+        persistent, transient = regions()
     # (the loss the caller gets back is a 0-dim view of this buffer: its own small allocation, so it never pins the workspace)
     ws.loss_sum = torch.empty(max(2, plan.loss_ws_doubles), dtype=torch.float64, device=dev)
     with _Range("crossclr.step_forward"):
-        nat.check(lib.crossclr_step_forward(ctypes.byref(plan), _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
-                                            ws.temperature, ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), flags, _ptr(slab), lay.total_bytes,
+        nat.check(lib.crossclr_step_forward(ctypes.byref(plan), ctypes.byref(lay), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
+                                            ws.in_dtype, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(persistent), _ptr(transient),
                                             _ptr(ws.loss_sum), _stream_for(video)))
     n2 = 2 * plan.bpad
-    ws.step = (flags, slab, lay.total_bytes, lay.backward_scratch_bytes)
+    ws.step = (lay, persistent, transient)
     ws.lazy = lazy = {}
     for names, off, nbytes, dt in ((("xhat", "xcols"), lay.xhat, plan.operand_bytes, torch.uint8),
                                    (("inv_norm",), lay.inv_norm, 4 * n2, torch.float32), (("diag",), lay.diag, 4 * plan.bpad, torch.float32),
@@ -633,8 +660,8 @@ def _backward_step(ws, video, text, grad_out):
     lib = nat.library()
     plan = ws.plan
     dev = video.device
-    flags, slab, nbytes, scratch_bytes = ws.step
-    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev) if scratch_bytes else None
+    lay, persistent, transient = ws.step
+    scratch = torch.empty(lay.backward_scratch_bytes, dtype=torch.uint8, device=dev) if lay.backward_scratch_bytes else None
     if grad_out.dtype == torch.float64 and grad_out.device == dev and grad_out.numel() == 1:
         go = grad_out.detach().reshape(1)
     else:
@@ -642,9 +669,12 @@ def _backward_step(ws, video, text, grad_out):
     gv = torch.empty(video.shape, dtype=video.dtype, device=dev)
     gt = torch.empty(text.shape, dtype=text.dtype, device=dev)
     with _Range("crossclr.step_backward"):
-        nat.check(lib.crossclr_step_backward(ctypes.byref(plan), _ptr(video), _ptr(text), video.stride(0), text.stride(0), ws.in_dtype,
-                                             ws.temperature, ws.negative_w, _sw(ws.k_rows, ws.k_rows, ws.lw), flags, _ptr(slab), nbytes,
+        nat.check(lib.crossclr_step_backward(ctypes.byref(plan), ctypes.byref(lay), _ptr(video), _ptr(text), video.stride(0), text.stride(0),
+                                             ws.in_dtype, _sw(ws.k_rows, ws.k_rows, ws.lw), _ptr(persistent), _ptr(transient),
                                              _ptr(scratch), _ptr(go), _ptr(gv), _ptr(gt), gv.stride(0), gt.stride(0), _stream_for(video)))
+    # (without the eager gradient product this launch was the last reader of the saved exponentials: a second backward through the same graph
+    #  -- retain_graph=True -- finds transient == None and the library recomputes the product from the persistent region)
+    ws.release_transient()
     return gv, gt
 
 
@@ -1250,57 +1280,69 @@ def _refuse_double_backward(what: str) -> None:
     """The autograd engine runs `backward` with grad mode ON exactly when the caller asked for a graph through it
     (`create_graph=True`).  The closed-form kernels of the projection / ranking paths are not twice differentiable --
     raise instead of silently handing back a gradient that autograd would treat as a constant.  (The CrossCLR criterion itself
-    carries second-order terms: `_second_order_grads`.)"""
+    carries second-order terms: `_CrossCLRGradFunction`, crossclr_second_order.)"""
     if torch.is_grad_enabled():
         raise RuntimeError(f"{what}: differentiating through the backward (create_graph=True / double backward) is not "
                            "supported by the HIP kernels; use the eager reference for second-order terms")
 
 
-_second_order_warned = False
+class _CrossCLRGradFunction(torch.autograd.Function):
+    """The criterion's backward as a differentiable function of (video, text, grad_out) -- what `create_graph=True` asks for (gradient
+    penalties, Hessian-vector products, meta-gradients: the reference's eager ops, trainer/loss.py:79-114, are twice differentiable).
+    forward = the HIP backward of the step that is being differentiated (same kernels, same bits as the ordinary backward);
+    backward = crossclr_second_order (include/crossclr.h; csrc/crossclr_kernels_hvp.h): grad_out * Hessian . u and <u, dL/d(rows)> in closed
+    form on the device, exact-fp32 products whatever mode the first-order step ran in, no B x B tensor.  Single device."""
+
+    @staticmethod
+    def forward(ctx, video, text, grad_out, ws, video_c, text_c, args):
+        with _device_of(video_c):
+            gv, gt = _backward_impl(ws, video_c, text_c, grad_out)
+        ctx.save_for_backward(video, text, grad_out)
+        ctx.args = args
+        return gv, gt
+
+    @staticmethod
+    def backward(ctx, u_video, u_text):
+        if torch.is_grad_enabled():      # (= create_graph=True on THIS level: the caller wants to differentiate the double backward again)
+            raise RuntimeError("CrossCLR_onlyIntraModality: third-order terms (create_graph=True through the double backward) are not "
+                               "supported by the HIP kernels -- drop create_graph on the outer autograd call, or use the eager reference")
+        video, text, grad_out = ctx.saved_tensors
+        temperature, negative_w, negative_scale, loss_weight, prenormalized = ctx.args
+        lib = nat.library()
+        dev = video.device
+        b, D = video.shape
+        v, t = _row_major(video.detach()), _row_major(text.detach())
+        uv = torch.zeros_like(v) if u_video is None else _row_major(u_video.detach().to(v.dtype))
+        ut = torch.zeros_like(t) if u_text is None else _row_major(u_text.detach().to(t.dtype))
+        plan = _plan_for(b, D, 1, 0, nat.MODE_FP32)
+        k = _pack_pair(negative_scale, b, plan.bpad, dev, "negative_scale")
+        lw = _pack_pair(loss_weight, b, plan.bpad, dev, "loss_weight")
+        go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
+        hv, ht = torch.empty_like(v), torch.empty_like(t)
+        dgo = torch.empty(1, dtype=torch.float64, device=dev)
+        with _device_of(v), _Range("crossclr.second_order"):
+            nbytes = lib.crossclr_second_order_workspace_bytes(ctypes.byref(plan))
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            nat.check(lib.crossclr_second_order(ctypes.byref(plan), _ptr(v), _ptr(t), v.stride(0), t.stride(0), _IN_DTYPE[v.dtype], float(temperature),
+                                                float(negative_w), _sw(k, k, lw), 1 if prenormalized else 0, _ptr(uv), _ptr(ut), uv.stride(0),
+                                                ut.stride(0), _ptr(go), _ptr(work), nbytes, _ptr(hv), _ptr(ht), hv.stride(0), ht.stride(0),
+                                                _ptr(dgo), _stream_for(v)))
+        need = ctx.needs_input_grad
+        return (hv if need[0] else None, ht if need[1] else None, dgo.reshape(grad_out.shape).to(grad_out.dtype) if need[2] else None,
+                None, None, None, None)
 
 
-def _differentiable_loss(video, text, temperature, negative_w, negative_scale, loss_weight, prenormalized):
-    """The criterion as a chain of differentiable device ops (float64 soft-max like the reference's, trainer/loss.py:79-114, written
-    in the closed form of DESIGN.md section 6: Z_p = sum_q e^{A_pq} + sum_{q != p} k_q e^{w S_pq} + k_p e^0,
-    L = sum_p omega_p (log Z_p - A_pp) / 2B).  NOT the product's first-order path: it exists so that `create_graph=True` (gradient
-    penalties, meta-gradients) -- which the reference's eager ops allow -- works through this module too; it materialises the
-    [B, 2B] float64 logits exactly as the reference does."""
-    F = torch.nn.functional
-    b = video.shape[0]
-    vn = video if prenormalized else F.normalize(video, dim=1)
-    tn = text if prenormalized else F.normalize(text, dim=1)
-    inv_tau = 1.0 / float(temperature)
-    off = 1.0 - torch.eye(b, dtype=torch.float64, device=video.device)
-    inter = (vn @ tn.t()).double() * inv_tau
-    pos = inter.diagonal()
-
-    def side(a, intra_rows, k, omega):
-        intra = (intra_rows @ intra_rows.t()).double() * inv_tau * off * float(negative_w)      # masked diagonal: logit 0, not -inf
-        m = torch.maximum(a.max(dim=1).values, intra.max(dim=1).values).detach()
-        ei, ea = torch.exp(a - m[:, None]), torch.exp(intra - m[:, None])
-        if k is not None:
-            ea = ea * k.double()[None, :]
-        nll = torch.log(ei.sum(1) + ea.sum(1)) + m - pos
-        return (nll * omega.double()).sum() if omega is not None else nll.sum()
-
-    kv, kt = negative_scale if negative_scale is not None else (None, None)
-    ov, ot = loss_weight if loss_weight is not None else (None, None)
-    return (side(inter, vn, kv, ov) + side(inter.t(), tn, kt, ot)) / (2.0 * b)
-
-
-def _second_order_grads(video, text, grad_out, temperature, negative_w, group, negative_scale, loss_weight, prenormalized):
-    global _second_order_warned
+def _second_order_grads(ctx, video, text, grad_out):
     import torch.distributed as dist
+    temperature, negative_w, group, negative_scale, loss_weight, prenormalized = ctx.second_order
     if group is not None and dist.get_world_size(group) > 1:
         raise RuntimeError("CrossCLR_onlyIntraModality: create_graph=True (double backward) is not available for the row-sharded "
                            "loss; gather the features (all_gather_with_grad) and call the criterion without a process group")
-    if not _second_order_warned:
-        _second_order_warned = True
-        warnings.warn("CrossCLR: create_graph=True -- the gradient is formed by differentiable device ops (float64 [B, 2B] logits, "
-                      "as in the reference) instead of the HIP backward kernels, so that it can be differentiated again", stacklevel=3)
-    with torch.enable_grad():
-        loss = _differentiable_loss(video, text, temperature, negative_w, negative_scale, loss_weight, prenormalized)
-        return torch.autograd.grad(loss, (video, text), grad_out.to(loss.dtype), create_graph=True, allow_unused=True)
+    if not video.is_cuda and nat.backend() != "emu-host":
+        raise RuntimeError("the HIP path needs inputs on the GPU (got a CPU tensor); there is no CPU fallback")
+    video_c, text_c = ctx.row_major
+    return _CrossCLRGradFunction.apply(video, text, grad_out, ctx.ws, video_c, text_c,
+                                       (temperature, negative_w, negative_scale, loss_weight, prenormalized))
 
 
 class _CrossCLRFunction(torch.autograd.Function):
@@ -1311,6 +1353,8 @@ class _CrossCLRFunction(torch.autograd.Function):
         with _device_of(video_c):
             loss, ws = _forward_impl(video_c, text_c, temperature, negative_w, compute_mode, group, negative_scale, loss_weight,
                                      save_for_backward=needs_grad, prenormalized=prenormalized)
+        if ws.step is not None and (ws.step[0].flags & nat.STEP_EAGER):
+            ws.release_transient()      # the gradient product is enqueued already: backward() reads the persistent region only
         ctx.ws = ws
         ctx.second_order = (float(temperature), float(negative_w), group, negative_scale, loss_weight, bool(prenormalized))
         ctx.save_for_backward(video, text)      # (the inputs themselves: a graph through the backward needs their identity)
@@ -1321,8 +1365,9 @@ class _CrossCLRFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         video, text = ctx.saved_tensors
         if torch.is_grad_enabled() and (video.requires_grad or text.requires_grad or grad_out.requires_grad):
-            # create_graph=True: the reference's eager ops (loss.py:79-114) are twice differentiable, so is this path
-            gv, gt = _second_order_grads(video, text, grad_out, *ctx.second_order)
+            # create_graph=True: the reference's eager ops (loss.py:79-114) are twice differentiable, so is this path (the same HIP
+            # backward, recorded as a node whose own backward is the closed-form double backward on the device)
+            gv, gt = _second_order_grads(ctx, video, text, grad_out)
             return (gv if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
                     None, None, None, None, None, None, None)
         video_c, text_c = ctx.row_major

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define CROSSCLR_LAUNCH_GROUPS 8   /* launch groups the forward workspace has room for */
-#define CROSSCLR_ABI_VERSION 6
+#define CROSSCLR_ABI_VERSION 7
 
 /* input element types (crossclr_normalize / crossclr_backward_finish) */
 #define CROSSCLR_IN_F32 0
@@ -451,59 +451,102 @@ int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* g
                                        long ld_s, int in_dtype, const float* ones, const float* active, const double* grad_out,
                                        void* grad_im, void* grad_s, long ld_gim, long ld_gs, void* stream);
 
-/* ---- THE WHOLE STEP BEHIND TWO CALLS (ABI 6; single device: plan->world == 1) -----------------------------------------------
+/* ---- THE WHOLE STEP BEHIND TWO CALLS (ABI 6; layout handed from call to call and split workspace: ABI 7.  Single device: plan->world == 1)
  * What the reference's one class is to its caller (trainer/loss.py:68-114 `forward`, and autograd's backward through it): a binding needs
  * nothing but crossclr_make_plan, crossclr_step_plan, crossclr_step_forward and crossclr_step_backward.  The library chooses the kernels:
  *   two-pass soft-max when max(1, |negative_weight|) / temperature > 128 (crossclr_needs_row_shift), the fixed-shift kernels otherwise;
  *   save-for-backward (the forward leaves its exponentials in the workspace, the backward is the gradient product alone) whenever the plan
  *     offers it, the caller did not forbid it (CROSSCLR_STEP_NO_SAVE / _FORWARD_ONLY), the stash is at most CROSSCLR_MAX_STASH_GB (default 8)
- *     and the workspace the caller brought is large enough -- otherwise the recomputing pair;
+ *     and the workspace budget the caller named is large enough -- otherwise the recomputing pair;
  *   the fragment-major operand copy + the pair kernel (crossclr_backward_saved_xfp), the one-tile fragment-major kernel (_xf) or the
  *     LDS-staged saved backward, by padded width and batch (measured break-even: Dpad in {512, 768, 1024, wide plans} from 2048 / 4096 padded
  *     rows; CROSSCLR_XF_WIDTHS overrides) -- CROSSCLR_STEP_NO_XFP / _NO_XF take a hand-scheduled kernel out (a caller that verifies
  *     them on its device first, as this repository's Python module does, passes the verdict here).
- * All of it is a pure function of (plan, temperature, negative_weight, flags, workspace_bytes): crossclr_step_plan reports the decision and
- * the workspace layout, and forward and backward of one step must be given the same five values.
- * Buffers (caller-owned, device): `workspace` (layout.total_bytes; must reach the backward unmodified), `loss_ws` (max(2,
- * plan->loss_ws_doubles) doubles: loss_ws[1] = the mean loss of loss.py:114 after the forward), `scratch` (layout.backward_scratch_bytes, backward
- * only), the inputs and the gradients.  sw (optional): neg_scale_rows = k[2][bpad], loss_weight = omega[2][bpad] (neg_scale_cols is ignored:
- * the local block's columns are its rows).  Nothing is allocated, nothing synchronises; errors as everywhere (CROSSCLR_E_WORKSPACE:
- * workspace_bytes below even the recomputing layout).                                                                               */
+ * crossclr_step_plan makes ALL of these decisions, once, and writes them into a crossclr_step_layout; crossclr_step_forward and
+ * crossclr_step_backward act on the layout they are given and decide nothing themselves (they never read the environment), so the two
+ * calls of one step cannot disagree: hand both the SAME layout, unmodified.
+ *
+ * The workspace is TWO caller-owned device regions (ABI 7), so that a caller can give most of it back early:
+ *   `persistent` (layout.persistent_bytes): everything crossclr_step_backward reads.  With CROSSCLR_STEP_EAGER that is 1 / ||x|| and the
+ *       gradient slices (67 MB at b = 8192, D = 512); otherwise the packed operand and the row statistics (17 MB).
+ *   `transient`  (layout.transient_bytes): the rest -- saved exponentials (0.27 GB at that shape), fragment-major copy, partial sums.
+ *       With CROSSCLR_STEP_EAGER it is dead as soon as crossclr_step_forward has returned (stream-ordered: free it on the launch
+ *       stream); otherwise crossclr_step_backward reads it once more, and a backward that is given transient == NULL (a second backward
+ *       through the same step after the caller released it) recomputes the similarity product from the persistent region instead.
+ *   One allocation works too: transient = (char*)persistent + layout.persistent_bytes (offsets below are into that concatenation).
+ * Other buffers (caller-owned, device): `loss_ws` (max(2, plan->loss_ws_doubles) doubles: loss_ws[1] = the mean loss of loss.py:114 after
+ * the forward), `scratch` (layout.backward_scratch_bytes, backward only), the inputs and the gradients.  sw (optional): neg_scale_rows =
+ * k[2][bpad], loss_weight = omega[2][bpad] (neg_scale_cols is ignored: the local block's columns are its rows).  Nothing is allocated,
+ * nothing synchronises; errors as everywhere (CROSSCLR_E_WORKSPACE: workspace_bytes below even the recomputing layout; CROSSCLR_E_ARG: a
+ * layout that crossclr_step_plan did not write for this plan).                                                                       */
 #define CROSSCLR_STEP_NO_SAVE 1u        /* the backward recomputes the similarity product (smallest workspace)            */
 #define CROSSCLR_STEP_FORWARD_ONLY 2u   /* no backward will follow (evaluation / no_grad): implies NO_SAVE                 */
 #define CROSSCLR_STEP_PRENORMALIZED 4u  /* the rows are unit vectors already (loss.py:79-80 skipped; gradients w.r.t. the unit rows) */
 #define CROSSCLR_STEP_NO_XFP 8u         /* do not take crossclr_backward_saved_xfp                                         */
 #define CROSSCLR_STEP_NO_XF 16u         /* do not take crossclr_backward_saved_xf either (LDS-staged saved backward)       */
 #define CROSSCLR_STEP_EAGER 32u         /* crossclr_step_forward ALSO enqueues the gradient product of the backward (it does not depend on grad_out: only the
-                                           finish kernel scales by it) into a gbuf region of the workspace; crossclr_step_backward is then the finish kernel
-                                           alone.  Same kernels, same results; the GPU does not idle while the host walks from forward() to backward()
-                                           (autograd's thread hand-over), and a second backward through the same step re-runs the finish only. */
+                                           finish kernel scales by it) into a gbuf region of the persistent workspace; crossclr_step_backward is then the finish
+                                           kernel alone.  Same kernels, same results; the GPU does not idle while the host walks from forward() to backward()
+                                           (autograd's thread hand-over), a second backward through the same step re-runs the finish only, and the transient
+                                           region can be released right after the forward call.  Cost: a forward whose backward() is never called has still
+                                           paid for the gradient product. */
 #define CROSSCLR_STEP_NONE ((size_t)-1) /* a layout offset that this step does not have                                    */
 
 typedef struct crossclr_step_layout {
-    size_t total_bytes;             /* bytes of `workspace` this layout needs                                          */
-    size_t backward_scratch_bytes;  /* bytes of crossclr_step_backward's `scratch` (the gradient slices, plan->gbuf_bytes) */
-    /* byte offsets into `workspace` (256-byte aligned; CROSSCLR_STEP_NONE: not part of this step) */
+    size_t total_bytes;             /* persistent_bytes + transient_bytes                                              */
+    size_t persistent_bytes;        /* region 1: what crossclr_step_backward reads (256-byte multiple; may be 0: FORWARD_ONLY) */
+    size_t transient_bytes;         /* region 2: dead after the forward call (EAGER) / after the first backward call   */
+    size_t backward_scratch_bytes;  /* bytes of crossclr_step_backward's `scratch` (the gradient slices, plan->gbuf_bytes; 0 with EAGER) */
+    /* byte offsets into the concatenation [persistent | transient] (256-byte aligned; an offset >= persistent_bytes lives in `transient`
+       at offset - persistent_bytes; CROSSCLR_STEP_NONE: not part of this step) */
     size_t xhat, inv_norm, diag, logz, rz, wrz, part, shift, xf, stash;
-    size_t gbuf;                    /* CROSSCLR_STEP_EAGER: the gradient slices live in the workspace (backward_scratch_bytes == 0)             */
+    size_t gbuf;                    /* CROSSCLR_STEP_EAGER: the gradient slices live in the persistent region (backward_scratch_bytes == 0)     */
     size_t ticket;                  /* one int: cleared by the step's first kernel, counts the finish kernel's blocks (its last block forms the loss) */
     size_t stash_bytes, xf_bytes;   /* sizes of xf and stash                                                           */
+    float temperature, negative_weight;   /* what the layout was planned for (the step calls take them from here)     */
+    unsigned flags;                 /* CROSSCLR_STEP_* the layout was planned for                                      */
     int two_pass;                   /* 1: per-row soft-max shifts (small temperature)                                  */
     int saved;                      /* 1: the forward saves its exponentials                                           */
     int backward_kernel;            /* 0 recomputing, 1 saved (LDS-staged / generic), 2 saved fragment-major, 3 saved fragment-major pair kernel */
+    unsigned check;                 /* written by crossclr_step_plan over (plan, the fields above); the step calls refuse a layout whose check does not match */
 } crossclr_step_layout;
 
-/* workspace_bytes = 0: the best layout for these arguments (ask, allocate layout.total_bytes, pass that number on);
- * otherwise the best layout that fits into workspace_bytes.                                                            */
+/* workspace_bytes = 0: the best layout for these arguments (ask, allocate layout.persistent_bytes + layout.transient_bytes);
+ * otherwise the best layout whose total_bytes fits into workspace_bytes.  The only step call that reads the environment
+ * (CROSSCLR_MAX_STASH_GB, CROSSCLR_XF_WIDTHS, CROSSCLR_XFP).                                                           */
 int crossclr_step_plan(const crossclr_plan* plan, float temperature, float negative_weight, unsigned flags,
                        size_t workspace_bytes, crossclr_step_layout* layout);
-int crossclr_step_forward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
-                          float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
-                          void* workspace, size_t workspace_bytes, double* loss_ws, void* stream);
-int crossclr_step_backward(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
-                           float temperature, float negative_weight, const crossclr_sample_weights* sw, unsigned flags,
-                           void* workspace, size_t workspace_bytes, void* scratch, const double* grad_out,
+int crossclr_step_forward(const crossclr_plan* plan, const crossclr_step_layout* layout, const void* video, const void* text,
+                          long ld_video, long ld_text, int in_dtype, const crossclr_sample_weights* sw,
+                          void* persistent, void* transient, double* loss_ws, void* stream);
+int crossclr_step_backward(const crossclr_plan* plan, const crossclr_step_layout* layout, const void* video, const void* text,
+                           long ld_video, long ld_text, int in_dtype, const crossclr_sample_weights* sw,
+                           void* persistent, void* transient, void* scratch, const double* grad_out,
                            void* grad_video, void* grad_text, long ld_gvideo, long ld_gtext, void* stream);
+
+/* ---- second-order terms (ABI 7; single device, exact-fp32 products) ------------------------------------------------------
+ * The reference's forward is a chain of eager PyTorch ops (trainer/loss.py:79-114), so autograd differentiates its backward again
+ * (create_graph=True: gradient penalties, Hessian-vector products).  This entry point is that double backward: with
+ * g = grad_out * dL/d(rows) what the first backward returned and (u_video, u_text) the cotangent handed in for g,
+ *     h_video, h_text = d<u, g>/d(video, text) = grad_out * (Hessian of the loss) . u       (input dtype, like the gradients)
+ *     d_grad_out[0]   = d<u, g>/d(grad_out)    = <u, dL/d(rows)>                            (one double, device)
+ * computed in closed form on the device (csrc/crossclr_kernels_hvp.h: the directional derivative of SURVEY.md 3.5's gradient along the
+ * tangent of the unit rows; two passes of a tiled kernel on the generic backward's skeleton + row kernels) -- no B x B tensor.
+ * `plan` must be a CROSSCLR_MODE_FP32 plan (whatever mode the first-order step ran in: the reference differentiates float64 logits here);
+ * the two-pass soft-max regime, per-sample weights (sw: neg_scale_rows = k[2][bpad], loss_weight = omega[2][bpad]) and prenormalized = 1
+ * (rows are unit vectors as given, derivatives w.r.t. them as given) are covered.  `workspace`: crossclr_second_order_workspace_bytes(plan)
+ * bytes, caller-owned, contents irrelevant before and after.  Nothing is allocated, nothing synchronises.                              */
+size_t crossclr_second_order_workspace_bytes(const crossclr_plan* plan);
+int crossclr_second_order(const crossclr_plan* plan, const void* video, const void* text, long ld_video, long ld_text, int in_dtype,
+                          float temperature, float negative_weight, const crossclr_sample_weights* sw, int prenormalized,
+                          const void* u_video, const void* u_text, long ld_uvideo, long ld_utext, const double* grad_out,
+                          void* workspace, size_t workspace_bytes, void* h_video, void* h_text, long ld_hvideo, long ld_htext,
+                          double* d_grad_out, void* stream);
+
+/* Which kernels the most recent forward (which = 0) / gradient-product (which = 1) launch of this process went to: the kernel template's name
+ * (e.g. "fast_fwd_pair_kernel", "fast_bwd_xfp_kernel"; "" before the first launch).  Reporting aid (bench.py labels its dominant kernel
+ * with it); no reference counterpart.                                                                                   */
+const char* crossclr_last_kernel(int which);
 
 /* Hardware assumption checks (MFMA fragment layouts, ds_read_b64_tr_b16 gather).  `out` is a
  * device buffer of at least 64 KiB; the caller compares it with the documented layouts.        */
