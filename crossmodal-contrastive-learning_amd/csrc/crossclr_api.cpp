@@ -2022,7 +2022,8 @@ static int second_order_impl(const crossclr_plan* plan, const HvpLayout& H, cons
         else LAUNCH((hvp_kernel<DC, false, 2>), dim3(rb, plan->Dpad / DC, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz), F(H.dwrz),  \
                     kNoF, shift, F(H.gbuf2), tps);                                                                                                   \
     } while (0)
-    if (plan->Dpad % 128 == 0) CROSSCLR_LH(128);
+    if (plan->Dpad % 256 == 0) CROSSCLR_LH(256);
+    else if (plan->Dpad % 128 == 0) CROSSCLR_LH(128);
     else CROSSCLR_LH(64);
 #undef CROSSCLR_LH
     if (int rc = launch_status("hvp_kernel (product)")) return rc;

@@ -64,11 +64,15 @@ __global__ void __launch_bounds__(256) hvp_tangent_kernel(const TIN* video, cons
 
 template <int DC, int PASS> struct HvpLds {
     static constexpr int kPX = 0, kQX = 64 * 128, kPV = 2 * 64 * 128, kQV = 3 * 64 * 128;
-    static constexpr int kWM = 4 * 64 * 128;                         // PASS 2: the two weight tiles [64][64] fp32 ...
+    // PASS 2: the two weight tiles [64][64] fp32 and the column slices [64][DC] of X and V.  DC = 256: the slices alone are 128 KiB, so the
+    // weight tiles take the place of the four K-tiles (dead between phase A and the next tile's first commit: one more barrier per tile) --
+    // 160 KiB, the whole LDS of a CU, for half the phase-A recomputation of DC = 128
+    static constexpr bool kAlias = PASS == 2 && DC > 128;
+    static constexpr int kWM = kAlias ? 0 : 4 * 64 * 128;
     static constexpr int kWW = kWM + 64 * 64 * 4;
-    static constexpr int kXQ = kWW + 64 * 64 * 4;                    // ... and the column slices [64][DC] of X and V
+    static constexpr int kXQ = 4 * 64 * 128 + (kAlias ? 0 : 2 * 64 * 64 * 4);
     static constexpr int kVQ = kXQ + 64 * DC * 4;
-    static constexpr int kTotal = PASS == 2 ? kVQ + 64 * DC * 4 : kWM + 2 * 64 * 4;      // PASS 1: two waves' partial row sums
+    static constexpr int kTotal = PASS == 2 ? kVQ + 64 * DC * 4 : 4 * 64 * 128 + 2 * 64 * 4;      // PASS 1: two waves' partial row sums
 };
 
 // grid = (2*bpad/64 row blocks, PASS 2: Dpad/DC output slices, column slices z).  Single device: rows and columns are the same operand.
@@ -125,6 +129,7 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
         for (int r = 0; r < 16; ++r) { accS[r] = 0.f; accT[r] = 0.f; }
         spx.fetch(xrow, pitch, 0, tid); sqx.fetch(xcol, pitch, 0, tid);
         spv.fetch(vrow, pitch, 0, tid); sqv.fetch(vcol, pitch, 0, tid);
+        if (L::kAlias) __syncthreads();      // (the previous tile's weight tiles live where the K-tiles are committed next: every wave past its phase C)
         for (int kc = 0; kc < nchunks; ++kc) {
             spx.commit(tPX, tid); sqx.commit(tQX, tid); spv.commit(tPV, tid); sqv.commit(tQV, tid);
             __syncthreads();      // also: every wave is past phase C of the previous tile
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
     if (PASS == 1) {
         // row p's share: the two wave halves (q = ..+4*half), then the two waves that hold the same rows (wq = 0, 1), in that order
         dz += wave_xor_f32(dz, 32);
-        float* red = reinterpret_cast<float*>(lds + L::kWM);
+        float* red = reinterpret_cast<float*>(lds + 4 * 64 * 128);
         __syncthreads();
         if (wq == 1 && half == 0) red[p_t] = dz;
         __syncthreads();
