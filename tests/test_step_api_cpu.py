@@ -188,3 +188,17 @@ def test_transient_region_is_released_and_a_second_backward_recomputes(B, D, mod
         assert (vv.grad - g1).abs().max().item() <= tol * scale
         if eager == "1":
             assert torch.equal(vv.grad, g1)
+
+
+def test_last_kernel_names_what_the_step_launched():
+    """crossclr_last_kernel (ABI 7, reporting aid: bench.py labels its dominant kernel with it): the kernel templates the step's forward and
+    gradient product went to, as the launchers recorded them -- here the exact-fp32 plan's generic kernels and a bf16 plan's register-resident ones."""
+    lib = nat.library()
+    v, t = orc.make_inputs("randn", 40, 24, 3)
+    vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="fp32").backward()
+    assert lib.crossclr_last_kernel(0).startswith(b"fwd_sums_kernel") and lib.crossclr_last_kernel(1).startswith(b"bwd_")
+    v, t = orc.make_inputs("randn", 256, 16, 3)
+    vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    crossclr_amd.crossclr_loss(vv, tt, 0.05, 0.8, compute_mode="bf16").backward()
+    assert lib.crossclr_last_kernel(0) == b"fast_fwd_pair_kernel" and lib.crossclr_last_kernel(1).startswith(b"fast_bwd_")

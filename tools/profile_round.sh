@@ -19,6 +19,7 @@ python bench.py --mode fp32 --fwd-only --rows 4096 --steps 50 > gpurun_out/${TAG
 python bench.py --mode fp32 --steps 30 > gpurun_out/${TAG}_bench_fp32.json 2>> gpurun_out/${TAG}_bench.err
 python bench.py --dim 1024 --steps 50 > gpurun_out/${TAG}_bench_d1024.json 2>> gpurun_out/${TAG}_bench.err
 python bench.py --dim 1024 --influential --steps 50 > gpurun_out/${TAG}_bench_influential_d1024.json 2>> gpurun_out/${TAG}_bench.err
+python tools/second_order_bench.py > gpurun_out/${TAG}_second_order.txt 2>&1      # create_graph=True: forward + backward + closed-form double backward
 # same command as the bench line (40 settle steps, 10 warm-up, 100 timed), profiled; its own JSON line is kept beside the summary so that the
 # HIP-event figure and the rocprofv3 figure of ONE process on ONE box can be compared (profiled passes run ~2 % slower: MICROARCH guide)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --sustained-steps 0 > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_stats.log
