@@ -10,7 +10,9 @@ registered child (`criterion`), same public attributes read at call time (`tempe
 `negative_w`, `logger`), float64 0-dim result on the inputs' device, gradients in the input dtype,
 `RuntimeError` for mismatched batch sizes and non-2-D inputs.  Underneath, the ~25 eager ops and
 the three host->device mask copies per step are replaced by five kernel launches through the
-C-ABI in include/crossclr.h; no B x B tensor is ever materialised.
+C-ABI in include/crossclr.h; no B x B tensor is ever materialised.  Like the reference's eager ops the
+criterion is twice differentiable: under `create_graph=True` the HIP backward is recorded as a node whose
+own backward is crossclr_second_order (Hessian-vector product in closed form on the device, exact fp32).
 
 Keyword-only additions (defaults reproduce the reference's single-process behaviour):
   compute_mode   "auto" | "fp32" | "bf16".  fp32 = exact-fp32 MFMA; bf16 = bf16 operands with
