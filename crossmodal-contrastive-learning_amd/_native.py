@@ -163,6 +163,9 @@ _SIGNATURES = {
     "crossclr_score_diag": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P]),
     "crossclr_score_rows": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P, _P, _P, _P]),
     "crossclr_maxmargin_backward": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P]),
+    "crossclr_maxmargin_mask_bytes": (ctypes.c_size_t, [ctypes.POINTER(Plan)]),
+    "crossclr_score_rows_save": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P]),
+    "crossclr_maxmargin_backward_saved": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, _P]),
     "crossclr_maxmargin_backward_finish": (ctypes.c_int, [ctypes.POINTER(Plan), _P, _P, _P, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                                           _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P]),
     # ABI version 6: the whole single-device step behind two calls (the kernel-selection policy lives in the library);

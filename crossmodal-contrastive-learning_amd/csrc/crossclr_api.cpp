@@ -1517,12 +1517,13 @@ static int score_geo(const crossclr_plan* p, float margin, Geo* g) {
 }
 template <typename T>
 static void score_launch(const crossclr_plan* plan, const Geo& g, const void* x, float* out, float* cnt, const float* diag, int mode,
-                         void* stream, float* colpart = nullptr) {
+                         void* stream, float* colpart = nullptr, unsigned char* hinge_mask = nullptr) {
     if (mode == 3 && colpart) {   // one pass: rows of modality 0 against the column tiles of modality 1, column statistics for the rest
         const int half_tiles = plan->bpad / 128, nsplit = plan->fwd_slots;
         const int tps = (half_tiles + nsplit - 1) / nsplit;
+        // (the kernel's `header` argument is free in this mode: it carries the optional hinge mask of crossclr_score_rows_save)
         LAUNCH((fwd_sums_kernel<T, false, 3, false, true>), dim3(plan->bpad / 128, nsplit), dim3(256), stream, (const T*)x, (const T*)x, g, tps, out,
-               (const float*)nullptr, diag, cnt, (int*)nullptr, colpart);
+               (const float*)nullptr, diag, cnt, reinterpret_cast<int*>(hinge_mask), colpart);
         return;
     }
     const int ntiles = 2 * plan->bpad / 128;
@@ -1542,16 +1543,32 @@ extern "C" int crossclr_score_diag(const crossclr_plan* plan, const void* xhat, 
     return launch_status("fwd_sums_kernel (positive-pair scores)");
 }
 
+static int score_rows_impl(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
+                           float* hinge, float* active, double* loss_sum, unsigned char* hinge_mask, void* stream);
 extern "C" int crossclr_score_rows(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
                                    float* hinge, float* active, double* loss_sum, void* stream) {
+    return score_rows_impl(plan, xhat, diag, margin, part, hinge, active, loss_sum, nullptr, stream);
+}
+extern "C" size_t crossclr_maxmargin_mask_bytes(const crossclr_plan* plan) {
+    if (!plan || plan->world != 1) return 0;
+    return (size_t)plan->bpad * (size_t)plan->bpad;
+}
+extern "C" int crossclr_score_rows_save(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
+                                        float* hinge, float* active, double* loss_sum, void* hinge_mask, void* stream) {
+    if (!hinge_mask) return fail(CROSSCLR_E_ARG, "NULL argument");
+    if (env_knobs().disable_symmetric) return fail(CROSSCLR_E_ARG, "CROSSCLR_DISABLE_SYMMETRIC: the hinge mask is written by the one-pass evaluation only");
+    return score_rows_impl(plan, xhat, diag, margin, part, hinge, active, loss_sum, static_cast<unsigned char*>(hinge_mask), stream);
+}
+static int score_rows_impl(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
+                           float* hinge, float* active, double* loss_sum, unsigned char* hinge_mask, void* stream) {
     if (!plan || !xhat || !diag || !part || !hinge || !active || !loss_sum) return fail(CROSSCLR_E_ARG, "NULL argument");
     Geo g;
     if (int rc = score_geo(plan, margin, &g)) return rc;
     if (plan->fwd_slots <= 0) return fail(CROSSCLR_E_ARG, "bad plan");
     float* cnt = part + (size_t)plan->fwd_slots * 2 * plan->bpad;     // launch group 1 of the forward workspace
     float* colpart = env_knobs().disable_symmetric ? nullptr : part + ws_colpart_off(plan);   // one pass for both directions
-    if (plan->mode == CROSSCLR_MODE_FP32) score_launch<float>(plan, g, xhat, part, cnt, diag, 3, stream, colpart);
-    else score_launch<bf16_t>(plan, g, xhat, part, cnt, diag, 3, stream, colpart);
+    if (plan->mode == CROSSCLR_MODE_FP32) score_launch<float>(plan, g, xhat, part, cnt, diag, 3, stream, colpart, hinge_mask);
+    else score_launch<bf16_t>(plan, g, xhat, part, cnt, diag, 3, stream, colpart, hinge_mask);
     if (int rc = launch_status("fwd_sums_kernel (score rows)")) return rc;
     const int nb = plan->loss_ws_doubles - 1;
     LAUNCH(score_finish_kernel, dim3(nb), dim3(256), stream, (const float*)part, (const float*)cnt, plan->fwd_slots, plan->bpad, plan->b,
@@ -1583,6 +1600,27 @@ extern "C" int crossclr_maxmargin_backward(const crossclr_plan* plan, const void
     if (int rc = score_geo(plan, margin, &g)) return rc;
     if (plan->mode == CROSSCLR_MODE_FP32) return maxmargin_backward_t<float>(plan, g, xhat, diag, gbuf, stream);
     return maxmargin_backward_t<bf16_t>(plan, g, xhat, diag, gbuf, stream);
+}
+
+template <typename T>
+static int maxmargin_backward_saved_t(const crossclr_plan* p, const Geo& g, const void* x, const unsigned char* mask, float* gbuf, void* stream) {
+    dim3 block(256);
+    const unsigned rb = 2 * p->bpad / 64, nz = (unsigned)p->bwd_slices;
+    const int ntiles = 2 * p->bpad / 64;
+    const int tps = (ntiles + p->bwd_slices - 1) / p->bwd_slices;
+#define CROSSCLR_LMS(DC) LAUNCH((maxmargin_saved_kernel<T, DC>), dim3(rb, p->Dpad / DC, nz), block, stream, (const T*)x, g, mask, gbuf, tps)
+    if (p->Dpad % 256 == 0) CROSSCLR_LMS(256);
+    else if (p->Dpad % 128 == 0) CROSSCLR_LMS(128);
+    else CROSSCLR_LMS(64);
+#undef CROSSCLR_LMS
+    return launch_status("maxmargin_saved_kernel");
+}
+extern "C" int crossclr_maxmargin_backward_saved(const crossclr_plan* plan, const void* xhat, const void* hinge_mask, float* gbuf, void* stream) {
+    if (!plan || !xhat || !hinge_mask || !gbuf) return fail(CROSSCLR_E_ARG, "NULL argument");
+    Geo g;
+    if (int rc = score_geo(plan, 0.f, &g)) return rc;
+    if (plan->mode == CROSSCLR_MODE_FP32) return maxmargin_backward_saved_t<float>(plan, g, xhat, static_cast<const unsigned char*>(hinge_mask), gbuf, stream);
+    return maxmargin_backward_saved_t<bf16_t>(plan, g, xhat, static_cast<const unsigned char*>(hinge_mask), gbuf, stream);
 }
 
 extern "C" int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* gbuf, const void* im, const void* s,

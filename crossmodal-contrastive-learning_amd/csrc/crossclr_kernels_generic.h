@@ -312,6 +312,11 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
     // MODE 2 over OTHER ranks' columns (rectangular launch, not SYM: `colpart` is free): the columns' shifts come from the gathered
     // [world][2 bpad] array passed in its place, indexed like the gathered statistics; the rows' shifts stay `shift`
     const float* shift_q = (!SYM && MODE == 2 && colpart != nullptr) ? colpart : shift;
+    // MODE 3 + SYM (`header` is unused there: no launch header): when not NULL it is the byte mask crossclr_score_rows_save asks for --
+    // per (video row, text column) the number of active hinges of the pair, 0 / 1 / 2 (0 for the positive pair and for padding), what
+    // maxmargin_saved_kernel multiplies the other modality's rows with instead of evaluating the scores again
+    unsigned char* hinge_mask = (MODE == 3 && SYM) ? reinterpret_cast<unsigned char*>(header) : nullptr;
+    (void)hinge_mask;
     CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + 2 * 128 * 4];
     unsigned char* tileP = lds;                 // row operand chunk   [128][128 B]
     unsigned char* tileQ = lds + 128 * 128;     // column operand chunk [128][128 B]
@@ -433,6 +438,7 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                     const bool ut_records = ST && sizeof(T) == 2 && MODE == 2 && !SYM && colpart != nullptr;   // (not `shift_q != shift`: rank 0's rows may BE the head of the gathered array)
                     if (kNeedColShift || ut_records)
                         shq = *reinterpret_cast<const f32x4*>(shift_q + ct.stat0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half);
+                    unsigned hinge_bytes = 0;      // (MODE 3 + SYM: active hinges of the four pairs, one byte each)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * r4 + j;
@@ -445,10 +451,14 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                             if (SYM && !masked && !pad_row && !(SW && same_mod && kp[pi] == 0.f)) es[qi][r] = fmaxf(es[qi][r], x);
                         } else if (MODE == 3) {
                             const float h = g.m2 + acc[qi][pi][r] - myshift[pi];
-                            if (!masked && h > 0.f) { rowacc[pi] += h; rowcnt[pi] += 1.f; }
+                            const bool ha = !masked && h > 0.f;
+                            if (ha) { rowacc[pi] += h; rowcnt[pi] += 1.f; }
                             if (SYM) {   // the same score seen from column q: against ITS positive pair
                                 const float hc = g.m2 + acc[qi][pi][r] - shq[j];
-                                if (!masked && !pad_row && hc > 0.f) { es[qi][r] += hc; ec[qi][r] += 1.f; }
+                                const bool hca = !masked && !pad_row && hc > 0.f;
+                                if (hca) { es[qi][r] += hc; ec[qi][r] += 1.f; }
+                                // the pair's weight in the backward (crossclr_maxmargin_backward_saved): its number of active hinges, 0 .. 2
+                                hinge_bytes |= (unsigned)((ha && !pad_row ? 1 : 0) + (hca ? 1 : 0)) << (8 * j);
                             }
                         } else if (MODE == 4) {
                             if (diag_tile && q_t == p_t) rowacc[pi] += acc[qi][pi][r];
@@ -465,6 +475,9 @@ __global__ void __launch_bounds__(256, 2) fwd_sums_kernel(const T* rows, const T
                             rowacc[pi] += e;
                         }
                     }
+                    if (MODE == 3 && SYM && hinge_mask)      // mask[video row][text column], bpad x bpad bytes: four columns of this lane's row
+                        *reinterpret_cast<unsigned*>(hinge_mask + (size_t)(r_in_mod0 + p_t) * g.bpad + ct.in_mod0 + 64 * wc + 32 * qi + 8 * r4 + 4 * half) = hinge_bytes;
+                    (void)hinge_bytes;
                     if constexpr (ST && sizeof(T) == 2) {
                         // bf16 plans beyond the register-resident kernels (Dpad > 1024): the record of tile (p32, q32), q32 >= 4 (p32 / 4) --
                         // [k-step th = r4 >> 1][lane][8 bf16], lane (p, half) holding E[p][16 th + 8 (r4 & 1) + 4 half + j] -- in the upper-
@@ -995,6 +1008,76 @@ __global__ void __launch_bounds__(256) bwd_kernel(const T* rows, const T* cols, 
             for (int r = 0; r < 16; ++r)
                 gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] = acc2[dt][r];
     }
+}
+
+// Max-margin ranking loss (trainer/loss.py:29-41), backward from the SAVED hinge mask (crossclr_score_rows_save): the weight of a pair is
+// the number of its active hinges, which the forward has already decided -- no similarity product here, phase C of bwd_kernel alone:
+//   G[p][d] += sum_q mask(p, q) x_q[d]      over the 64-column tiles q of the OTHER modality in this block's column slice.
+// mask[video row][text column] (bpad x bpad bytes): video rows read their tile as stored, text rows the transposed one (through LDS).
+// grid = (2*bpad/64, Dpad/DC, column slices); same slices / same output layout as bwd_kernel<..., LOSS = 1>.
+template <typename T, int DC>
+__global__ void __launch_bounds__(256) maxmargin_saved_kernel(const T* X, Geo g, const unsigned char* mask, float* gbuf, int tiles_per_slice) {
+    typedef BwdLds<T, DC> L;
+    CROSSCLR_SHARED __attribute__((aligned(16))) unsigned char lds[L::kTotal];
+    unsigned char* mt = lds;                 // the 64 x 64 byte tile of the mask (the K-tile area of bwd_kernel: no phase A here)
+    unsigned char* wt = lds + L::kW;
+    unsigned char* xq = lds + L::kXQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const size_t pitch = (size_t)g.Dpad * sizeof(T);
+    const int row0 = blockIdx.x * 64;
+    const int rmod = row0 / g.bpad;
+    const int r_in_mod0 = row0 - rmod * g.bpad;
+    const int d0 = blockIdx.y * DC;
+    const int wq = wave & 1, wp = wave >> 1;      // weight-tile roles: columns 32*wq.., rows 32*wp..
+    const int wr = wave & 1, wc = wave >> 1;      // product roles: rows 32*wr.., embedding columns wc*(DC/2)..
+    f32x16 acc2[DC / 64];
+#pragma unroll
+    for (int dt = 0; dt < DC / 64; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
+    const int p_t = 32 * wp + l31;
+    const int ntiles = 2 * g.bpad / 64;
+    const int t_begin = blockIdx.z * tiles_per_slice;
+    int t_stop = t_begin + tiles_per_slice;
+    if (t_stop > ntiles) t_stop = ntiles;
+    for (int u = t_begin; u < t_stop; ++u) {
+        const ColTile ct = col_tile(g, u, 64);
+        if (ct.mod == rmod) continue;      // (uniform for the block)
+        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(X) + ct.row0 * pitch;
+        __syncthreads();                   // every wave is past the product of the previous tile
+        {
+            constexpr int kPiecesPerRow = DC * (int)sizeof(T) / 16;
+            constexpr int kElemsPerPiece = 16 / (int)sizeof(T);
+            for (int id = tid; id < 64 * kPiecesPerRow; id += 256) {
+                const int q = id / kPiecesPerRow, c = id - q * kPiecesPerRow;
+                *reinterpret_cast<u32x4*>(xq + xq_off<T, DC>(q, c * kElemsPerPiece)) =
+                    *reinterpret_cast<const u32x4*>(cbase + (size_t)q * pitch + ((size_t)d0 + c * kElemsPerPiece) * sizeof(T));
+            }
+            // the mask tile, 64 rows of 64 bytes as stored: (video rows of the block, text columns) or (video columns, text rows of the block)
+            const int mr = tid >> 2, mc = (tid & 3) * 16;
+            const size_t vrow = rmod == 0 ? (size_t)(r_in_mod0 + mr) : (size_t)(ct.in_mod0 + mr);
+            const size_t tcol = rmod == 0 ? (size_t)ct.in_mod0 : (size_t)r_in_mod0;
+            *reinterpret_cast<u32x4*>(mt + mr * 64 + mc) = *reinterpret_cast<const u32x4*>(mask + vrow * g.bpad + tcol + mc);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int q0 = 32 * wq + 8 * r4 + 4 * half;
+            f32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (float)(rmod == 0 ? mt[p_t * 64 + q0 + j] : mt[(q0 + j) * 64 + p_t]);
+            w_store4(wt, p_t, q0, w, (T*)nullptr);
+        }
+        __syncthreads();
+        bwd_gemm2<DC>(wt, xq, wr, wc * (DC / 2), lane, acc2, (T*)nullptr);
+    }
+    float* gslice = gbuf + (size_t)blockIdx.z * 2 * g.bpad * g.Dpad;
+#pragma unroll
+    for (int dt = 0; dt < DC / 64; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] = acc2[dt][r];
 }
 
 // ---------------------------------------------------------------------------------------------

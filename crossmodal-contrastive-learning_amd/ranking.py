@@ -18,6 +18,7 @@ with margin 0 (count of candidates scoring strictly higher than the partner).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict
 
 import torch
@@ -33,10 +34,10 @@ def cosine_sim(emb1: torch.Tensor, emb2: torch.Tensor) -> torch.Tensor:
 
 
 class _Scores:
-    __slots__ = ("plan", "xhat", "ones", "diag", "hinge", "active", "loss_sum", "in_dtype", "margin")
+    __slots__ = ("plan", "xhat", "ones", "diag", "hinge", "active", "loss_sum", "in_dtype", "margin", "mask")
 
 
-def _score_rows(im: torch.Tensor, s: torch.Tensor, margin: float, compute_mode: str, normalize: bool) -> _Scores:
+def _score_rows(im: torch.Tensor, s: torch.Tensor, margin: float, compute_mode: str, normalize: bool, save_mask: bool = False) -> _Scores:
     lib = nat.library()
     b, D = im.shape
     dev = im.device
@@ -57,6 +58,16 @@ def _score_rows(im: torch.Tensor, s: torch.Tensor, margin: float, compute_mode: 
     part = torch.empty(plan.fwd_ws_floats, **f32)
     sc.hinge, sc.active = torch.empty(2 * plan.bpad, **f32), torch.empty(2 * plan.bpad, **f32)
     sc.loss_sum = torch.empty(plan.loss_ws_doubles, dtype=torch.float64, device=dev)
+    # With a backward to follow the same pass also leaves every pair's number of active hinges (one byte per pair, 64 MiB at B = 8192: the
+    # reference's autograd keeps two B x B float hinge matrices for this): the backward is then one product with that mask instead of a
+    # second evaluation of the scores.  CROSSCLR_MAXMARGIN_SAVE=0, or a library that declines (CROSSCLR_DISABLE_SYMMETRIC): the recomputing pair.
+    sc.mask = None
+    if save_mask and os.environ.get("CROSSCLR_MAXMARGIN_SAVE", "1") != "0":
+        mask = torch.empty(lib.crossclr_maxmargin_mask_bytes(pp), dtype=torch.uint8, device=dev)
+        if lib.crossclr_score_rows_save(pp, _ptr(sc.xhat), _ptr(sc.diag), sc.margin, _ptr(part), _ptr(sc.hinge), _ptr(sc.active),
+                                        _ptr(sc.loss_sum), _ptr(mask), stream) == 0:
+            sc.mask = mask
+            return sc
     nat.check(lib.crossclr_score_rows(pp, _ptr(sc.xhat), _ptr(sc.diag), sc.margin, _ptr(part), _ptr(sc.hinge), _ptr(sc.active),
                                       _ptr(sc.loss_sum), stream))
     return sc
@@ -67,7 +78,7 @@ class _MaxMarginFunction(torch.autograd.Function):
     def forward(ctx, im, s, margin, compute_mode):
         im_c, s_c = _row_major(im.detach()), _row_major(s.detach())
         with _device_of(im_c):
-            sc = _score_rows(im_c, s_c, margin, compute_mode, normalize=False)
+            sc = _score_rows(im_c, s_c, margin, compute_mode, normalize=False, save_mask=any(ctx.needs_input_grad[:2]))
         ctx.sc = sc
         ctx.save_for_backward(im_c, s_c)
         # (cost_s.sum() + cost_im.sum()).div(B * B) (loss.py:41), in the input dtype like the reference's eager ops
@@ -84,7 +95,10 @@ class _MaxMarginFunction(torch.autograd.Function):
         with _device_of(im_c):
             stream = _stream_for(im_c)
             gbuf = torch.empty(plan.gbuf_bytes // 4, dtype=torch.float32, device=dev)
-            nat.check(lib.crossclr_maxmargin_backward(pp, _ptr(sc.xhat), _ptr(sc.diag), sc.margin, _ptr(gbuf), stream))
+            if sc.mask is not None:
+                nat.check(lib.crossclr_maxmargin_backward_saved(pp, _ptr(sc.xhat), _ptr(sc.mask), _ptr(gbuf), stream))
+            else:
+                nat.check(lib.crossclr_maxmargin_backward(pp, _ptr(sc.xhat), _ptr(sc.diag), sc.margin, _ptr(gbuf), stream))
             go = grad_out.detach().to(device=dev, dtype=torch.float64).reshape(1).contiguous()
             g_im, g_s = torch.empty_like(im_c), torch.empty_like(s_c)
             nat.check(lib.crossclr_maxmargin_backward_finish(pp, _ptr(gbuf), _ptr(im_c), _ptr(s_c), im_c.stride(0), s_c.stride(0),

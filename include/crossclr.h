@@ -447,6 +447,16 @@ int crossclr_score_rows(const crossclr_plan* plan, const void* xhat, const float
                         float* hinge, float* active, double* loss_sum, void* stream);
 int crossclr_maxmargin_backward(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* gbuf,
                                 void* stream);
+/* ABI 7 -- the save-for-backward pair of the ranking loss: crossclr_score_rows_save is crossclr_score_rows (same bits) that also leaves,
+ * per (row of the first modality, row of the second), the number of ACTIVE hinges of the pair -- 0, 1 or 2; 0 for the positive pair and
+ * for padding -- as one byte: hinge_mask[bpad][bpad] (crossclr_maxmargin_mask_bytes; 64 MiB at b = 8192).  crossclr_maxmargin_backward_saved
+ * forms gbuf (the layout and slices of crossclr_maxmargin_backward, same crossclr_maxmargin_backward_finish behind it) from that mask:
+ * one product with the mask instead of evaluating the scores again (autograd of loss.py:30-41 keeps the two B x B hinge matrices for this).
+ * crossclr_score_rows_save fails with CROSSCLR_E_ARG under CROSSCLR_DISABLE_SYMMETRIC (the one-pass evaluation writes the mask).        */
+size_t crossclr_maxmargin_mask_bytes(const crossclr_plan* plan);
+int crossclr_score_rows_save(const crossclr_plan* plan, const void* xhat, const float* diag, float margin, float* part,
+                             float* hinge, float* active, double* loss_sum, void* hinge_mask, void* stream);
+int crossclr_maxmargin_backward_saved(const crossclr_plan* plan, const void* xhat, const void* hinge_mask, float* gbuf, void* stream);
 int crossclr_maxmargin_backward_finish(const crossclr_plan* plan, const float* gbuf, const void* im, const void* s, long ld_im,
                                        long ld_s, int in_dtype, const float* ones, const float* active, const double* grad_out,
                                        void* grad_im, void* grad_s, long ld_gim, long ld_gs, void* stream);

@@ -111,3 +111,23 @@ def test_max_margin_input_dtypes_and_strided_rows(dtype):
     assert abs(loss.item() - float(st["loss"])) <= eps * max(1.0, abs(float(st["loss"])))
     scale = float(st["grad_im"].abs().max())
     assert (av.grad.double().cpu() - st["grad_im"]).abs().max().item() <= max(eps, 2e-3) * scale * 4
+
+
+@pytest.mark.parametrize("mode,B,D", [("fp32", 8192, 512), ("bf16", 8192, 512), ("fp32", 1000, 300), ("fp32", 333, 1100), ("bf16", 2050, 96)])
+def test_backward_from_the_saved_hinge_mask_is_the_recomputing_backward_on_the_device(mode, B, D, monkeypatch):
+    """crossclr_score_rows_save + crossclr_maxmargin_backward_saved (one byte per pair: its number of active hinges; the backward is one
+    product with the mask) against the recomputing pair: same loss bits, same gradient bits -- the headline batch, ragged batches, wide rows."""
+    im, s = orc.make_inputs("cluster", B, D, 17)
+    im, s = torch.nn.functional.normalize(im, dim=1).cuda(), torch.nn.functional.normalize(s, dim=1).cuda()
+
+    def run():
+        a, b = im.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        loss = crossclr_amd.max_margin_loss(a, b, 0.1, compute_mode=mode)
+        saved = loss.grad_fn.sc.mask is not None
+        loss.backward()
+        return loss.item(), a.grad, b.grad, saved
+    l1, ga1, gb1, saved1 = run()
+    monkeypatch.setenv("CROSSCLR_MAXMARGIN_SAVE", "0")
+    l0, ga0, gb0, saved0 = run()
+    assert saved1 and not saved0 and l1 == l0
+    assert torch.equal(ga1, ga0) and torch.equal(gb1, gb0)

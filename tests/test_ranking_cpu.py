@@ -96,3 +96,32 @@ def test_emulated_retrieval_ranks(emulated_library, B, D, normalize):
         assert ((got[key] - ref[key]).abs() <= ties).all(), key
     assert got["v2t"].shape == (5,) and 0.0 <= float(got["v2t"][0]) <= float(got["v2t"][2]) <= 1.0
     assert torch.allclose(got["t2v"][:3], ref["t2v"][:3], atol=3.0 / B)
+
+
+@pytest.mark.parametrize("B,D,mode", [(70, 48, "fp32"), (300, 200, "fp32"), (130, 72, "bf16")])
+def test_backward_from_the_saved_hinge_mask_is_the_recomputing_backward(emulated_library, B, D, mode, monkeypatch):
+    """With a backward to follow, crossclr_score_rows_save also leaves every pair's number of active hinges (one byte per pair) and the
+    backward is one product with that mask (crossclr_maxmargin_backward_saved) instead of a second evaluation of the scores: same loss bits,
+    same gradient bits as the recomputing pair (the scores come from the same MFMA sequence), ragged batches and padding included."""
+    g = torch.Generator().manual_seed(B)
+    im, s = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    if mode == "bf16":
+        im, s = torch.nn.functional.normalize(im, dim=1), torch.nn.functional.normalize(s, dim=1)
+
+    def run():
+        a, b = im.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        loss = crossclr_amd.max_margin_loss(a, b, 0.1, compute_mode=mode)
+        saved = loss.grad_fn.sc.mask is not None
+        (1.5 * loss).backward()
+        return loss.item(), a.grad, b.grad, saved
+    l1, ga1, gb1, saved1 = run()
+    monkeypatch.setenv("CROSSCLR_MAXMARGIN_SAVE", "0")
+    l0, ga0, gb0, saved0 = run()
+    assert saved1 and not saved0
+    assert l1 == l0 and torch.equal(ga1, ga0) and torch.equal(gb1, gb0)
+    monkeypatch.delenv("CROSSCLR_MAXMARGIN_SAVE")
+    with torch.no_grad():      # nothing to save without a backward
+        assert crossclr_amd.max_margin_loss(im, s, 0.1, compute_mode=mode).item() == l1
+    monkeypatch.setenv("CROSSCLR_DISABLE_SYMMETRIC", "1")      # the two-pass evaluation writes no mask: the library declines, the module recomputes
+    l2, ga2, gb2, saved2 = run()
+    assert not saved2 and torch.allclose(ga2, ga1, rtol=1e-5, atol=1e-7)

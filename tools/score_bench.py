@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the score-statistics entry points (retrieval ranks / max-margin forward).  usage: score_bench.py [B] [D]"""
+"""Timing of the score-statistics entry points (retrieval ranks / max-margin forward and backward: the recomputing backward and the one from
+the saved hinge mask).  usage: score_bench.py [B] [D]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,4 +27,11 @@ for mode, name in ((nat.MODE_FP32, "fp32"), (nat.MODE_BF16, "bf16")):
         return e0.elapsed_time(e1) / 10
     td = timeit(lambda: lib.crossclr_score_diag(pp, p(x), p(diag), st))
     tr = timeit(lambda: lib.crossclr_score_rows(pp, p(x), p(diag), 0.0, p(part), p(hinge), p(act), p(ls), st))
-    print(f"B={B} D={D} {name}: fwd_slots={plan.fwd_slots} score_diag {td:.3f} ms, score_rows {tr:.3f} ms")
+    mask = torch.empty(lib.crossclr_maxmargin_mask_bytes(pp), dtype=torch.uint8, device="cuda")
+    gbuf = torch.empty(plan.gbuf_bytes // 4, **f32)
+    ts = timeit(lambda: lib.crossclr_score_rows_save(pp, p(x), p(diag), 0.1, p(part), p(hinge), p(act), p(ls), p(mask), st))
+    tb = timeit(lambda: lib.crossclr_maxmargin_backward(pp, p(x), p(diag), 0.1, p(gbuf), st))
+    g0 = gbuf.clone()
+    tbs = timeit(lambda: lib.crossclr_maxmargin_backward_saved(pp, p(x), p(mask), p(gbuf), st))
+    print(f"B={B} D={D} {name}: fwd_slots={plan.fwd_slots} score_diag {td:.3f} ms, score_rows {tr:.3f} ms (+ hinge mask: {ts:.3f}); max-margin backward "
+          f"recomputing {tb:.3f} ms, from the saved mask {tbs:.3f} ms ({tb / tbs:.2f}x; forward + backward {tr + tb:.3f} -> {ts + tbs:.3f} ms), same bits: {torch.equal(g0, gbuf)}")
