@@ -125,3 +125,23 @@ def test_second_order_entry_point_refuses_what_it_does_not_cover():
     assert b"FP32" in lib.crossclr_last_error()
     assert lib.crossclr_second_order_workspace_bytes(ctypes.byref(nat.make_plan(64, 32, 2, 0, nat.MODE_FP32))) == 0      # single device
     assert lib.crossclr_second_order_workspace_bytes(ctypes.byref(nat.make_plan(64, 32, 1, 0, nat.MODE_FP32))) > 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 3e-4), (torch.bfloat16, 3e-2), (torch.float16, 1e-2)])
+def test_double_backward_in_every_input_dtype(dtype, tol):
+    """Cotangents arrive and Hessian-vector products leave in the INPUT dtype (like the gradients); the arithmetic in between is the exact-fp32
+    closed form whatever the inputs are -- compared with autograd through the float64 oracle on the same (rounded) inputs."""
+    v, t = orc.make_inputs("randn", 24, 40, 6, dtype)
+    uv, ut = orc.make_inputs("randn", 24, 40, 1006, dtype)
+
+    def run(loss_fn, cast):
+        vv, tt = cast(v).requires_grad_(True), cast(t).requires_grad_(True)
+        gv, gt = torch.autograd.grad(loss_fn(vv, tt), (vv, tt), create_graph=True)
+        s = (cast(uv).double() * gv.double()).sum() + (cast(ut).double() * gt.double()).sum()
+        hv, ht = torch.autograd.grad(s, (vv, tt))
+        return hv, ht
+    got = run(lambda a, b: crossclr_amd.crossclr_loss(a, b, 0.05, 0.8, compute_mode="fp32"), lambda x: x.clone())
+    want = run(lambda a, b: orc.eager_loss(a, b, 0.05, 0.8), lambda x: x.double().clone())
+    assert got[0].dtype == dtype and got[1].dtype == dtype
+    scale = max(want[0].abs().max().item(), want[1].abs().max().item())
+    assert (got[0].double() - want[0]).abs().max().item() <= tol * scale and (got[1].double() - want[1]).abs().max().item() <= tol * scale
