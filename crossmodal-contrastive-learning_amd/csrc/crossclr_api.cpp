@@ -2053,16 +2053,18 @@ static int second_order_impl(const crossclr_plan* plan, const HvpLayout& H, cons
     LAUNCH(hvp_stats_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), stream, F(H.dzpart), H.nz, n2, F(H.rz), lw, negative_weight, F(H.drz), F(H.dwrz));
     if (int rc = launch_status("hvp_stats_kernel")) return rc;
     // pass 2: dG in column slices
-#define CROSSCLR_LH(DC)                                                                                                                              \
+#define CROSSCLR_LH(DC, NS)                                                                                                                          \
     do {                                                                                                                                             \
-        if (k) LAUNCH((hvp_kernel<DC, true, 2>), dim3(rb, plan->Dpad / DC, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz), F(H.dwrz), \
-                      k, shift, F(H.gbuf2), tps);                                                                                                    \
-        else LAUNCH((hvp_kernel<DC, false, 2>), dim3(rb, plan->Dpad / DC, H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz), F(H.dwrz),  \
-                    kNoF, shift, F(H.gbuf2), tps);                                                                                                   \
+        if (k) LAUNCH((hvp_kernel<DC, true, 2, NS>), dim3(rb, plan->Dpad / (DC * NS), H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz), \
+                      F(H.dwrz), k, shift, F(H.gbuf2), tps);                                                                                         \
+        else LAUNCH((hvp_kernel<DC, false, 2, NS>), dim3(rb, plan->Dpad / (DC * NS), H.nz), dim3(256), stream, X, V, g, F(H.rz), F(H.wrz), F(H.drz),  \
+                    F(H.dwrz), kNoF, shift, F(H.gbuf2), tps);                                                                                        \
     } while (0)
-    if (plan->Dpad % 256 == 0) CROSSCLR_LH(256);
-    else if (plan->Dpad % 128 == 0) CROSSCLR_LH(128);
-    else CROSSCLR_LH(64);
+    // (two 256-column slices per block where they divide the row: S and T of a tile are evaluated once for 512 output columns)
+    if (plan->Dpad % 512 == 0) CROSSCLR_LH(256, 2);
+    else if (plan->Dpad % 256 == 0) CROSSCLR_LH(256, 1);
+    else if (plan->Dpad % 128 == 0) CROSSCLR_LH(128, 1);
+    else CROSSCLR_LH(64, 1);
 #undef CROSSCLR_LH
     if (int rc = launch_status("hvp_kernel (product)")) return rc;
     // the row-local chain: normalisation, positive pairs, x grad_out; and <u, dL/d(rows)>

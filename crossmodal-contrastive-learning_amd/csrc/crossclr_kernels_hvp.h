@@ -80,7 +80,9 @@ template <int DC, int PASS> struct HvpLds {
 //   PASS 2: out[z][2*bpad][Dpad]    = this slice's share of dG_p (without 1 / tau, like the first-order gbuf)
 // rz / wrz: omega / Z and w omega / Z (crossclr_forward_finish); drz / dwrz: their tangents (hvp_stats_kernel; PASS 2 only);
 // k: negative scales (SW) or NULL; shift: per-row soft-max shifts of the two-pass regime (log2 domain) or NULL (g.m2 for every row).
-template <int DC, bool SW, int PASS>
+// NS (PASS 2): output slices of DC columns one block owns (grid.y = Dpad / (DC * NS)): the tile's S and T -- three of the five products -- are
+// evaluated once and multiplied with NS column slices that pass through the same LDS one after the other (NS * DC / 64 accumulators per wave).
+template <int DC, bool SW, int PASS, int NS = 1>
 __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V, Geo g, const float* rz, const float* wrz, const float* drz,
                                                   const float* dwrz, const float* k, const float* shift, float* out, int tiles_per_slice) {
     typedef Operand<float> Op;
@@ -95,15 +97,16 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
     const int row0 = blockIdx.x * 64;
     const int rmod = row0 / g.bpad;
     const int r_in_mod0 = row0 - rmod * g.bpad;
-    const int d0 = PASS == 2 ? blockIdx.y * DC : 0;
+    const int d0 = PASS == 2 ? blockIdx.y * DC * NS : 0;
     const unsigned char* xrow = reinterpret_cast<const unsigned char*>(X) + (size_t)row0 * pitch;
     const unsigned char* vrow = reinterpret_cast<const unsigned char*>(V) + (size_t)row0 * pitch;
     const int wq = wave & 1, wp = wave >> 1;      // phase A / B roles: S^T for columns 32*wq.., rows 32*wp..
     const int wr = wave & 1, wc = wave >> 1;      // phase C roles (PASS 2): rows 32*wr.., embedding columns wc*(DC/2)..
 
-    f32x16 acc2[PASS == 2 ? DC / 64 : 1];
+    constexpr int kAcc = PASS == 2 ? NS * (DC / 64) : 1;
+    f32x16 acc2[kAcc];
 #pragma unroll
-    for (int dt = 0; dt < (PASS == 2 ? DC / 64 : 1); ++dt)
+    for (int dt = 0; dt < kAcc; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[dt][r] = 0.f;
     float dz = 0.f;
@@ -119,6 +122,17 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
     int t_stop = t_begin + tiles_per_slice;
     if (t_stop > ntiles) t_stop = ntiles;
     KTileStage<64, 256> spx, sqx, spv, sqv;
+    // the column slices [64][DC] of X and V the product phase multiplies with, columns dcol .. dcol + DC - 1 of the tile's rows
+    auto load_slices = [&](const unsigned char* xcol, const unsigned char* vcol, int dcol) {
+        constexpr int kPiecesPerRow = DC * 4 / 16;
+        unsigned char *xq = lds + L::kXQ, *vq = lds + L::kVQ;
+        for (int id = tid; id < 64 * kPiecesPerRow; id += 256) {
+            const int q = id / kPiecesPerRow, c = id - q * kPiecesPerRow;
+            const size_t src = (size_t)q * pitch + ((size_t)dcol + c * 4) * sizeof(float);
+            *reinterpret_cast<u32x4*>(xq + xq_off<float, DC>(q, c * 4)) = *reinterpret_cast<const u32x4*>(xcol + src);
+            *reinterpret_cast<u32x4*>(vq + xq_off<float, DC>(q, c * 4)) = *reinterpret_cast<const u32x4*>(vcol + src);
+        }
+    };
     for (int u = t_begin; u < t_stop; ++u) {
         const ColTile ct = col_tile(g, u, 64);
         const unsigned char* xcol = reinterpret_cast<const unsigned char*>(X) + ct.row0 * pitch;
@@ -133,16 +147,7 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
         for (int kc = 0; kc < nchunks; ++kc) {
             spx.commit(tPX, tid); sqx.commit(tQX, tid); spv.commit(tPV, tid); sqv.commit(tQV, tid);
             __syncthreads();      // also: every wave is past phase C of the previous tile
-            if (PASS == 2 && kc == 0) {
-                constexpr int kPiecesPerRow = DC * 4 / 16;
-                unsigned char *xq = lds + L::kXQ, *vq = lds + L::kVQ;
-                for (int id = tid; id < 64 * kPiecesPerRow; id += 256) {
-                    const int q = id / kPiecesPerRow, c = id - q * kPiecesPerRow;
-                    const size_t src = (size_t)q * pitch + ((size_t)d0 + c * 4) * sizeof(float);
-                    *reinterpret_cast<u32x4*>(xq + xq_off<float, DC>(q, c * 4)) = *reinterpret_cast<const u32x4*>(xcol + src);
-                    *reinterpret_cast<u32x4*>(vq + xq_off<float, DC>(q, c * 4)) = *reinterpret_cast<const u32x4*>(vcol + src);
-                }
-            }
+            if (PASS == 2 && NS == 1 && kc == 0) load_slices(xcol, vcol, d0);      // (one slice: its loads ride behind phase A)
             if (kc + 1 < nchunks) {
                 spx.fetch(xrow, pitch, (kc + 1) * 128, tid); sqx.fetch(xcol, pitch, (kc + 1) * 128, tid);
                 spv.fetch(vrow, pitch, (kc + 1) * 128, tid); sqv.fetch(vcol, pitch, (kc + 1) * 128, tid);
@@ -199,10 +204,18 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
             }
         }
         if (PASS == 2) {
-            __syncthreads();
             // ---------------- phase C: dG += M X_Q + W V_Q ----------------
-            bwd_gemm2<DC>(lds + L::kWM, lds + L::kXQ, wr, wc * (DC / 2), lane, acc2, (float*)nullptr);
-            bwd_gemm2<DC>(lds + L::kWW, lds + L::kVQ, wr, wc * (DC / 2), lane, acc2, (float*)nullptr);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                __syncthreads();      // the weight tiles are written (sl = 0) / every wave is past the product of slice sl - 1
+                if (NS > 1) {
+                    load_slices(xcol, vcol, d0 + sl * DC);
+                    __syncthreads();
+                }
+                f32x16(&acc)[DC / 64] = *reinterpret_cast<f32x16(*)[DC / 64]>(&acc2[sl * (DC / 64)]);
+                bwd_gemm2<DC>(lds + L::kWM, lds + L::kXQ, wr, wc * (DC / 2), lane, acc, (float*)nullptr);
+                bwd_gemm2<DC>(lds + L::kWW, lds + L::kVQ, wr, wc * (DC / 2), lane, acc, (float*)nullptr);
+            }
         }
     }
     if (PASS == 1) {
@@ -217,10 +230,12 @@ __global__ void __launch_bounds__(256) hvp_kernel(const float* X, const float* V
     }
     float* gslice = out + (size_t)blockIdx.z * 2 * g.bpad * g.Dpad;
 #pragma unroll
-    for (int dt = 0; dt < (PASS == 2 ? DC / 64 : 1); ++dt)
+    for (int sl = 0; sl < (PASS == 2 ? NS : 1); ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + wc * (DC / 2) + 32 * dt + l31] = acc2[dt][r];
+        for (int dt = 0; dt < (PASS == 2 ? DC / 64 : 1); ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gslice[(size_t)(row0 + 32 * wr + frag_row(r, half)) * g.Dpad + d0 + sl * DC + wc * (DC / 2) + 32 * dt + l31] = acc2[sl * (DC / 64) + dt][r];
 }
 
 // dZ slices -> drz = -rz dZ / Z and dwrz = w drz.  1 / Z = rz / omega (omega = the row's loss weight; 1 without sample weights): a row of weight 0

@@ -145,3 +145,20 @@ def test_double_backward_in_every_input_dtype(dtype, tol):
     assert got[0].dtype == dtype and got[1].dtype == dtype
     scale = max(want[0].abs().max().item(), want[1].abs().max().item())
     assert (got[0].double() - want[0]).abs().max().item() <= tol * scale and (got[1].double() - want[1]).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("B,D", [(24, 300), (40, 520)])
+def test_double_backward_over_rows_wider_than_one_slice(B, D):
+    """Dpad = 512 / 768: the product pass owns two 256-column output slices per block (the tile's S and T evaluated once) resp. three blocks of one."""
+    v, t = orc.make_inputs("randn", B, D, 8)
+    uv, ut = orc.make_inputs("randn", B, D, 1008)
+
+    def run(loss_fn):
+        vv, tt = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        gv, gt = torch.autograd.grad(loss_fn(vv, tt), (vv, tt), create_graph=True)
+        s = (uv.double() * gv.double()).sum() + (ut.double() * gt.double()).sum()
+        return [x.double() for x in torch.autograd.grad(s, (vv, tt))]
+    got = run(lambda a, b: crossclr_amd.crossclr_loss(a, b, 0.05, 0.8, compute_mode="fp32"))
+    want = run(lambda a, b: orc.eager_loss(a, b, 0.05, 0.8))
+    scale = max(want[0].abs().max().item(), want[1].abs().max().item())
+    assert (got[0] - want[0]).abs().max().item() <= 3e-4 * scale and (got[1] - want[1]).abs().max().item() <= 3e-4 * scale
