@@ -256,7 +256,7 @@ def secondary_lines(dev):
             ex_frac = round(4.0 * rows * rows * dim * (1.0 + (256.0 if st["fast_path"] else 128.0) / (2.0 * rows)) / (st[dom] * 1e-3) / 1e12 / peak, 4)
         out[name] = {"ms_per_step_event_median": round(ms, 4), "pairs_per_s": rows * rows / (ms * 1e-3), "loss": float(loss.detach()),
                      "dominant_kernel_frac_executed": ex_frac,
-                     "loss_delta_vs_reference": abs(float(loss) - golden) if golden is not None else None,
+                     "loss_delta_vs_reference": abs(float(loss.detach()) - golden) if golden is not None else None,
                      "dominant_kernel": ("forward" if fwd_only else "backward") + (" (saved exponentials)" if st.get("saved_path") and not fwd_only else ""),
                      "dominant_kernel_ms": round(st[dom], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
                      "dominant_kernel_frac_of_peak": round(tf / peak, 4), "peak_tflops": peak,
@@ -292,6 +292,37 @@ def secondary_lines(dev):
         "dominant_kernel_frac_of_peak": round(tf / PEAK_BF16_TFLOPS, 4), "peak_tflops": PEAK_BF16_TFLOPS,
         "workload": "rank 0 of 2 through the C-ABI on one GPU: b=8192 rows/rank, D=1536, bf16, tau=0.03, the 16384 x 16384 block against the other "
                     "rank: generic forward that saves + saved backward; median of 5 launches"}
+    # round 6: the double backward (create_graph=True) at the headline shape -- forward + backward + crossclr_second_order (closed form on the
+    # device, exact fp32) behind a bf16 step; what the reference does with 12 GB of float64 [B, 2B] tensors per autograd level
+    v, t = make_inputs(8192, 512, 1234)
+    v, t = v.to(dev).requires_grad_(True), t.to(dev).requires_grad_(True)
+    crit = crossclr_amd.CrossCLR_onlyIntraModality(TAU, NEG_W, compute_mode="bf16").to(dev)
+
+    def penalty_step():
+        gv, gt = torch.autograd.grad(crit(v, t), (v, t), create_graph=True)
+        return torch.autograd.grad((gv.double() ** 2).sum() + (gt.double() ** 2).sum(), (v, t))[0]
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    ms, pv = timed(penalty_step, n=5, warm=2)
+    out["second_order_b8192_gradient_penalty"] = {
+        "ms_per_step_event_median": round(ms, 3), "peak_memory_mib_above_inputs": round((torch.cuda.max_memory_allocated(dev) - base) / 2 ** 20, 1),
+        "finite": bool(torch.isfinite(pv).all()),
+        "workload": "b=8192 D=512: loss -> autograd.grad(create_graph=True) -> gradient of ||dL/dv||^2 + ||dL/dt||^2 (bf16 first-order step, exact-fp32 "
+                    "closed-form double backward: crossclr_second_order; (3 + 3 + 2) tiled products of 2 (2b)^2 D + the fp32 first-order pieces)"}
+    # round 6: the reference's other loss (MaxMargin_coot, loss.py:17-41), exact fp32, forward + backward from the saved hinge mask
+    im, s = make_inputs(8192, 512, 77)
+    im = torch.nn.functional.normalize(im, dim=1).to(dev).requires_grad_(True)
+    s = torch.nn.functional.normalize(s, dim=1).to(dev).requires_grad_(True)
+
+    def mm_step():
+        im.grad = s.grad = None
+        loss = crossclr_amd.max_margin_loss(im, s, 0.1, compute_mode="fp32")
+        loss.backward()
+        return loss
+    ms, loss = timed(mm_step, n=7, warm=3)
+    out["maxmargin_fp32_b8192_fwd_bwd"] = {"ms_per_step_event_median": round(ms, 4), "loss": float(loss.detach()),
+                                            "workload": "MaxMargin_coot(margin=0.1) b=8192 D=512 exact fp32 fwd+bwd (one score pass for both directions that "
+                                                        "also saves the hinge mask; backward = one product with the mask)"}
     return out
 
 
