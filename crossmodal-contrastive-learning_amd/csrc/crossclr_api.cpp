@@ -167,7 +167,7 @@ extern "C" int crossclr_make_plan(int b, int D, int world, int rank, int mode, c
     }
 #endif
     if (!plan->fast_path && dpad > 256) dpad = round_up(D, 256);  // generic backward slices D by 256
-    // wide bf16 plans (1024 < D <= 4096): generic forward, but its exponentials are saved for the D-slice backward, which runs as 3 ... 8
+    // wide bf16 plans (1024 < D <= 8192): generic forward, but its exponentials are saved for the D-slice backward, which runs as 3 ... 16
     // column parts of 384 / 512 columns -- the operand is padded to parts x columns
     bool wide = false;
 #ifndef CROSSCLR_NO_FAST
@@ -1756,7 +1756,7 @@ static size_t step_max_stash_bytes() {
 static bool step_use_xf(const crossclr_plan* p) {
     const char* e = getenv("CROSSCLR_XF_WIDTHS");
     if (!e) {
-        static const int widths[] = {512, 768, 1024, 1152, 1536, 2048, 2560, 3072, 4096};
+        static const int widths[] = {512, 768, 1024, 1152, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192};
         bool in = false;
         for (int w : widths) in = in || p->Dpad == w;
         return in && p->bpad >= (p->Dpad <= 512 ? 2048 : 4096);

@@ -231,7 +231,7 @@ static inline int fast_dpad(int D) {
 }
 
 // bf16 plans beyond the register-resident forward (D > 1024): the generic tiled forward saves its exponentials in the register-resident
-// layout and the D-slice saved backward runs as XP column parts of 384 / 512 columns (blockIdx.z) -- Dpad = XP x part, XP = 3 ... 8
+// layout and the D-slice saved backward runs as XP column parts of 384 / 512 columns (blockIdx.z) -- Dpad = XP x part, XP = 3 ... 16 (D <= 8192)
 static inline int wide_bf16_dpad(int D) {
     if (D <= 1024) return 0;
     if (D <= 1152) return 1152;     // 3 x 384
@@ -240,6 +240,9 @@ static inline int wide_bf16_dpad(int D) {
     if (D <= 2560) return 2560;     // 5 x 512
     if (D <= 3072) return 3072;     // 6 x 512
     if (D <= 4096) return 4096;     // 8 x 512
+    if (D <= 5120) return 5120;     // 10 x 512   (round 6: up to 16 parts -- the part count only sets the row pitch of the operand and the gradient)
+    if (D <= 6144) return 6144;     // 12 x 512
+    if (D <= 8192) return 8192;     // 16 x 512
     return 0;
 }
 
@@ -1192,6 +1195,9 @@ CROSSCLR_LEAF int launch_saved_wide(const SavedLaunch& a) {
         case 2560: CROSSCLR_LBW(32, 5); break;
         case 3072: CROSSCLR_LBW(32, 6); break;
         case 4096: CROSSCLR_LBW(32, 8); break;
+        case 5120: CROSSCLR_LBW(32, 10); break;
+        case 6144: CROSSCLR_LBW(32, 12); break;
+        case 8192: CROSSCLR_LBW(32, 16); break;
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_LBW
@@ -1227,6 +1233,9 @@ CROSSCLR_LEAF int launch_saved_wide_xfp(const SavedLaunch& a) {
         case 2560: CROSSCLR_LBWP(32, 5); break;
         case 3072: CROSSCLR_LBWP(32, 6); break;
         case 4096: CROSSCLR_LBWP(32, 8); break;
+        case 5120: CROSSCLR_LBWP(32, 10); break;
+        case 6144: CROSSCLR_LBWP(32, 12); break;
+        case 8192: CROSSCLR_LBWP(32, 16); break;
         default: return CROSSCLR_E_ARG;
     }
 #undef CROSSCLR_LBWP

@@ -422,7 +422,7 @@ _MAX_STASH_BYTES = int(float(os.environ.get("CROSSCLR_MAX_STASH_GB", "8")) * (1 
 # crossclr_normalize_xf +1.5 us at D = 512 and +5 us at D = 1024 (+8 at B = 2048, where its 16-row blocks no longer fill the chip), so small
 # batches keep the plain pair: default = Dpad in {512, 768, 1024} with at least 2048 (D <= 512) / 4096 (wider) padded rows.
 # CROSSCLR_XF_WIDTHS="128,256,384,512" (or "" for none) overrides the widths and drops the row floor (tuning / tests).
-_XF_WIDTHS_DEFAULT = frozenset((512, 768, 1024, 1152, 1536, 2048, 2560, 3072, 4096))     # (beyond 1024: wide plans, pair kernel only)
+_XF_WIDTHS_DEFAULT = frozenset((512, 768, 1024, 1152, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192))     # (beyond 1024: wide plans, pair kernel only)
 
 
 # The fragment-major backwards move their column tiles with hand-counted inline-asm loads, and two schedules of that idea that compiled

@@ -474,7 +474,10 @@ def test_sharded_host_path_with_real_collectives_on_one_gpu(monkeypatch):
     (640, 2000, "bf16"),    # 4 parts of 512
     (384, 2300, "bf16"),    # 5 parts (Dpad = 2560)
     (256, 4096, "bf16"),    # 8 parts
-    (200, 4500, "bf16"),    # beyond 4096: the recomputing generic backward
+    (200, 4500, "bf16"),    # 10 parts (Dpad = 5120; round 6: the saved D-slice backward up to D = 8192)
+    (300, 6000, "bf16"),    # 12 parts
+    (130, 8192, "bf16"),    # 16 parts
+    (100, 8300, "bf16"),    # beyond 8192: the recomputing generic backward
     (777, 200, "fp32"),     # generic fp32, Dpad = 256
     (1024, 768, "fp32"),    # generic fp32, three backward slices
     (3000, 512, "auto"),    # auto -> bf16 (global batch >= 1024)

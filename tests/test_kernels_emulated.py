@@ -208,7 +208,10 @@ def test_plan_geometry():
     assert p.bwd_slices == 2 and p.gbuf_bytes == 2 * 2 * 8192 * 1536 * 4     # 128 row blocks x 3 parts x 2 slices = 3 rounds of 256
     assert nat.make_plan(8192, 2048, 1, 0, nat.MODE_BF16).bwd_slices == 1
     p = nat.make_plan(100, 5000, 1, 0, nat.MODE_BF16)
-    assert (p.Dpad, p.fast_path, p.stash_bytes) == (5120, 0, 0)  # beyond 4096: the recomputing generic backward
+    assert (p.Dpad, p.fast_path) == (5120, 0) and p.stash_bytes > 0 and p.xf_bytes == p.operand_bytes      # round 6: 10 / 12 / 16 column parts up to D = 8192
+    assert [nat.make_plan(100, d, 1, 0, nat.MODE_BF16).Dpad for d in (4097, 6000, 8192)] == [5120, 6144, 8192]
+    p = nat.make_plan(100, 9000, 1, 0, nat.MODE_BF16)
+    assert (p.fast_path, p.stash_bytes) == (0, 0)  # beyond 8192: the recomputing generic backward
     assert nat.make_plan(100, 512, 1, 0, nat.MODE_BF16).fast_bwd == 1 and nat.make_plan(100, 512, 1, 0, nat.MODE_FP32).fast_bwd == 0
     with pytest.raises(nat.CrossCLRNativeError):
         nat.make_plan(0, 16, 1, 0, nat.MODE_FP32)
@@ -483,9 +486,9 @@ def test_double_backward_matches_the_reference_and_never_returns_a_constant():
     assert a.grad is not None
 
 
-@pytest.mark.parametrize("B,D,weighted", [(40, 1100, False), (70, 1030, True)])
+@pytest.mark.parametrize("B,D,weighted", [(40, 1100, False), (70, 1030, True), (24, 4700, False)])
 def test_wide_bf16_plans_save_their_exponentials(B, D, weighted, monkeypatch):
-    """1024 < D <= 4096, bf16: the generic symmetric forward leaves bf16 records in the register-resident layout (128-row blocks) and the
+    """1024 < D <= 8192, bf16: the generic symmetric forward leaves bf16 records in the register-resident layout (128-row blocks) and the
     D-slice saved backward runs as column parts of 384 / 512 columns -- against the streaming float64 oracle (reference: loss.py:83-112,
     shape-agnostic) and against the recomputing generic backward of the same library (CROSSCLR_DISABLE_SAVE=1)."""
     v, t = orc.make_inputs("randn", B, D, 77 + B)
