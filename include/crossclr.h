@@ -76,7 +76,7 @@ typedef struct crossclr_plan {
     size_t stash_bytes;     /* ABI 3: bytes of the saved-exponentials buffer of crossclr_forward_save (0: not available
                                for this plan -- use crossclr_forward / crossclr_backward, which recompute) */
     size_t xf_bytes;        /* ABI 4: bytes of the fragment-major copy of the packed operand that crossclr_normalize_xf / crossclr_pack_xf
-                               write and crossclr_backward_saved_xf reads (0: not available -- Dpad > 1024, fp32 plans) */
+                               write and crossclr_backward_saved_xf / _xfp read (0: not available -- fp32 plans, bf16 plans beyond D = 8192) */
 } crossclr_plan;
 
 int crossclr_abi_version(void);
@@ -258,7 +258,7 @@ int crossclr_backward_saved_s(const crossclr_plan* plan, const void* xhat, const
  * Exact-fp32 plans (round 4): the same three entry points with with_colsums = 0 -- the generic forward over the rank range leaves its fp32
  * fragments (4 KiB per 32 x 32 fragment: 1 GiB per rank at b = 8192, up to 16 GiB; crossclr_rect_stash_bytes says 0 beyond) and
  * crossclr_backward_rect_saved is the gradient product alone (bwd_saved32_kernel<..., RECT>).
- * Wide bf16 plans (1024 < D <= 4096, round 4): the same three entry points with with_colsums = 0 as well -- the generic forward over the rank
+ * Wide bf16 plans (1024 < D <= 8192; round 4, extended from 4096 in round 6): the same three entry points with with_colsums = 0 as well -- the generic forward over the rank
  * range leaves bf16 records in the rectangular layout (2 KiB per 32 x 32 tile: 0.5 GiB per rank at b = 8192) and the backward is the
  * D-slice kernel in column parts (fast_bwd_dsl_kernel<..., MODE 1, XP, 4>): 13.9 ms of recompute per 8192 x 8192 block at D = 1536 gone.   */
 size_t crossclr_rect_stash_bytes(const crossclr_plan* plan, int nranks);
