@@ -192,6 +192,9 @@ def main():
     # backward's pair kernel meet reference-generated numbers directly (round-4 review: they were checked against the streaming oracle only)
     metas.append(case("g10_b2048_d1024", "randn", 2048, 1024, 31, full=False))
     metas.append(case("g10_b2048_d1536", "randn", 2048, 1536, 32, full=False))
+    # round 6: wide plans beyond 4096 (10 and 12 column parts of the saved D-slice backward; the second one at a batch the pair kernel takes)
+    metas.append(case("g10_b1024_d5000", "randn", 1024, 5000, 33, full=False))
+    metas.append(case("g10_b4096_d6000", "randn", 4096, 6000, 34, full=False))
     # G7: large
     if args.large:
         metas.append(case("g7_b4096_d512_s1234", "randn", 4096, 512, 1234, full=False))
