@@ -239,6 +239,22 @@ class _OperandExchange:
         n = xhat.numel()
         piece = lambda r: xcols[r * n:(r + 1) * n]
         piece(rank).copy_(xhat)
+        # gloo has no device path for send / recv (its collectives stage device tensors through pinned memory, its point-to-point operations
+        # hand the raw pointer to the socket layer: the HOST then writes device memory behind the GPU's L2, and a block launched right after
+        # can read lines the L2 still holds from the buffer's previous life -- seen once in ~40 runs of tests/test_gpu_ranks_share_gpu.py).
+        # Ranks that share one GPU over gloo (tests, `bench.py --share-gpu`) therefore stage these transfers themselves: pinned host
+        # buffers on the wire, a stream-ordered copy into the gathered operand once a slice has landed.  RCCL and CPU tensors: untouched.
+        self._staged = xhat.is_cuda and dist.get_backend(group) == "gloo"
+        self._copies_first, self._copies_rest, self._copies_peer = [], [], {}
+        if self._staged:
+            xsend = xhat.cpu()
+            def recv_target(r, copies):
+                buf = torch.empty(n, dtype=xhat.dtype, pin_memory=True)
+                copies.append((piece(r), buf))
+                return buf
+        else:
+            xsend = xhat
+            recv_target = lambda r, copies: piece(r)
         others = [(rank + d) % world for d in range(1, world)]
         early = [r for r in others if r in first_peers]
         late = [r for r in others if r not in first_peers]
@@ -249,8 +265,8 @@ class _OperandExchange:
             def post(peers):
                 for r in peers:
                     d = (r - rank) % world
-                    ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group),
-                           dist.P2POp(dist.isend, xhat, to_global((rank - d) % world), group)]
+                    ops = [dist.P2POp(dist.irecv, recv_target(r, self._copies_peer.setdefault(r, [])), to_global(r), group),
+                           dist.P2POp(dist.isend, xsend, to_global((rank - d) % world), group)]
                     self._peer[r] = dist.batch_isend_irecv(ops)
             post(early)
             if defer_late:
@@ -262,27 +278,37 @@ class _OperandExchange:
         offs_early = {(q - rank) % world for q in early}
         send_early = [(rank - d) % world for d in sorted(offs_early)]
         send_late = [r for r in others if r not in send_early]
-        def post(recv_from, send_to, works):
-            ops = [dist.P2POp(dist.irecv, piece(r), to_global(r), group) for r in recv_from]
-            ops += [dist.P2POp(dist.isend, xhat, to_global(r), group) for r in send_to]
+        def post(recv_from, send_to, works, copies):
+            ops = [dist.P2POp(dist.irecv, recv_target(r, copies), to_global(r), group) for r in recv_from]
+            ops += [dist.P2POp(dist.isend, xsend, to_global(r), group) for r in send_to]
             if ops:
                 works.extend(dist.batch_isend_irecv(ops))
-        post(early, send_early, self._first)
+        post(early, send_early, self._first, self._copies_first)
         if defer_late:
-            self._deferred = lambda: post(late, send_late, self._rest)
+            self._deferred = lambda: post(late, send_late, self._rest, self._copies_rest)
         else:
-            post(late, send_late, self._rest)
+            post(late, send_late, self._rest, self._copies_rest)
+
+    @staticmethod
+    def _land(copies):
+        """(ranks sharing one GPU over gloo) the slices that have arrived in pinned host buffers go to their place, in stream order"""
+        for dst, buf in copies:
+            dst.copy_(buf, non_blocking=True)
+        del copies[:]
 
     def wait_peer(self, r):
         """The slice of rank r has landed (p2p_each: exactly that; otherwise: the batch it travels in)."""
         if self.mode == "p2p_each":
             _traced_wait("operands:peer", self._peer.pop(r, None))
+            self._land(self._copies_peer.pop(r, []))
         else:
             self.wait_forward()
 
     def wait_forward(self):
         _traced_wait("operands:forward", self._first)
         self._first = []
+        if self.mode != "allgather":
+            self._land(self._copies_first)
 
     def finish(self):
         """Everything that was REQUESTED has landed (deferred slices stay unrequested): buffers may be released."""
@@ -298,8 +324,11 @@ class _OperandExchange:
         self.wait_forward()
         _traced_wait("operands:late", self._rest)
         self._rest = []
+        if self.mode != "allgather":
+            self._land(self._copies_rest)
         for r in list(self._peer):
             _traced_wait("operands:peer", self._peer.pop(r))
+            self._land(self._copies_peer.pop(r, []))
 
 
 # the pairs scheme's column-sum exchange: (device, process group, stream, world, rank, n2, npairs) -> (outbox, inbox, send / receive split
