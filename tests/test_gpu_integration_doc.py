@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _stub():
+def _stub(with_namespace=False):
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     m = re.search(r"```python\nimport ctypes, torch\n(.*?)```", text, re.S)
     assert m, "the binding example is missing from INTEGRATION.md"
@@ -25,6 +25,11 @@ def _stub():
     code = "import ctypes, torch\n" + body.replace('ctypes.CDLL("libcrossclr_hip.so")', f'ctypes.CDLL("{nat.library_path()}")')
     ns = {}
     exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    if with_namespace:
+        m2 = re.search(r"```python\n(class CrossCLRGrad.*?)```", text, re.S)
+        assert m2, "the double-backward binding is missing from INTEGRATION.md"
+        exec(compile(m2.group(1), "INTEGRATION.md (double backward)", "exec"), ns)
+        return ns
     return ns["CrossCLRStep"]
 
 
@@ -55,3 +60,34 @@ def test_the_documented_binding_is_the_module_bit_for_bit():
     (2.0 * want).backward()
     assert got.item() == want.item()
     assert torch.equal(va.grad, vb.grad) and torch.equal(ta.grad, tb.grad)
+
+
+def test_the_documented_double_backward_binding_matches_the_reference_golden():
+    """INTEGRATION.md's second block: the step's backward recorded as a node whose backward is crossclr_second_order -- the Hessian-vector
+    product of the reference's own double backward (tests/golden/so_b64_d256_s0: BASELINE config 1's shape and hyper-parameters)."""
+    import json
+    from oracle import crossclr_oracle as orc
+    ns = _stub(with_namespace=True)
+    step, grad_node = ns["CrossCLRStep"], ns["CrossCLRGrad"]
+
+    class Step2(step):          # what the prose under the block says: dispatch to the node when a graph through the backward is wanted
+        @staticmethod
+        def backward(ctx, grad_out):
+            if torch.is_grad_enabled():
+                v, t = ctx.saved_tensors
+                lay = ctx.state[1]
+                gv, gt = grad_node.apply(v, t, grad_out, ctx, lay.temperature, lay.negative_weight)
+                return gv, gt, None, None, None
+            return step.backward(ctx, grad_out)
+    m = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "so_index.json")))["cases"]}["so_b64_d256_s0"]
+    want = dict(np.load(os.path.join(ROOT, "tests", "golden", "so_b64_d256_s0.npz")))
+    v, t = orc.make_inputs(m["kind"], m["B"], m["D"], m["seed"])
+    uv, ut = orc.make_inputs("randn", m["B"], m["D"], m["cotangent_seed"])
+    vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    loss = Step2.apply(vd, td, m["temperature"], m["negative_weight"], 0)
+    gv, gt = torch.autograd.grad(loss, (vd, td), create_graph=True)
+    s = (uv.cuda().double() * gv.double()).sum() + (ut.cuda().double() * gt.double()).sum()
+    hv, ht = torch.autograd.grad(s, (vd, td))
+    scale = max(np.abs(want["hv"]).max(), np.abs(want["ht"]).max())
+    assert np.abs(gv.detach().cpu().numpy() - want["gv"]).max() <= 2e-5 * max(np.abs(want["gv"]).max(), np.abs(want["gt"]).max())
+    assert np.abs(hv.cpu().double().numpy() - want["hv"]).max() <= 2e-4 * scale and np.abs(ht.cpu().double().numpy() - want["ht"]).max() <= 2e-4 * scale
