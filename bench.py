@@ -123,8 +123,19 @@ def cpu_baseline(b, d, fwd_only=False):
             cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
     except OSError:
         pass
+    # SURVEY.md 8(d) also asks for the reference's own CPU-runnable case (BASELINE config 1: B = 64, D = 256): median of 20 steps
+    small = None
+    if not fwd_only:
+        vs, ts = make_inputs(64, 256, 1234)
+        ts_ = []
+        for i in range(21):
+            t0 = time.perf_counter()
+            ls, _, _ = orc.eager_loss_and_grads(vs, ts, TAU, NEG_W)
+            ts_.append(time.perf_counter() - t0)
+        ts_ = sorted(ts_[1:])
+        small = {"B": 64, "D": 256, "seconds_per_step": ts_[len(ts_) // 2], "pairs_per_s": 64 * 64 / ts_[len(ts_) // 2], "loss": float(ls.detach())}
     return {"value": bb * bb / best, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": cpu_model,
+            "cpu_model": cpu_model, "config1_b64_d256": small,
             "samples_per_s": bb / best, "seconds_per_step": best, "seconds_all_steps": [round(x, 4) for x in times],
             "host_cpus": os.cpu_count(),
             "loss": float(loss.detach()),
@@ -261,6 +272,26 @@ def secondary_lines(dev):
                      "dominant_kernel_ms": round(st[dom], 4), "dominant_kernel_algorithmic_tflops": round(tf, 2),
                      "dominant_kernel_frac_of_peak": round(tf / peak, 4), "peak_tflops": peak,
                      "workload": f"b={rows} D={dim} {mode} {'fwd' if fwd_only else 'fwd+bwd'}" + (" + influential-sample weights" if influential else "")}
+    # BASELINE config 1 (the reference's own CPU-runnable case, B = 64, D = 256, exact fp32): a launch-bound step -- what it costs is the host
+    # path (five launches + autograd), see cpu_baseline.config1_b64_d256 for the same step through the reference's ops on this box's CPU
+    v1, t1 = make_inputs(64, 256, 1234)
+    v1, t1 = v1.to(dev).requires_grad_(True), t1.to(dev).requires_grad_(True)
+    crit1 = crossclr_amd.CrossCLR_onlyIntraModality(TAU, NEG_W, compute_mode="fp32").to(dev)
+
+    def step1():
+        v1.grad = t1.grad = None
+        l = crit1(v1, t1)
+        l.backward()
+        return l
+    for _ in range(50):
+        step1()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        l1 = step1()
+    torch.cuda.synchronize(dev)
+    out["config1_fp32_b64_d256_fwd_bwd"] = {"ms_per_step_wall": round((time.perf_counter() - t0) / 200 * 1e3, 4), "loss": float(l1.detach()),
+                                             "workload": "b=64 D=256 fp32 fwd+bwd, wall over 200 steps (host-bound: module call + autograd + five launches)"}
     case("fp32_b8192_fwd_bwd", 8192, 512, "fp32", False, False, GOLDEN_LOSS_B8192_SEED1234)
     case("config2_fp32_fwd_b4096", 4096, 512, "fp32", True, False, GOLDEN_LOSS_B4096_SEED1234)
     case("d1024_bf16_fwd_bwd", 8192, 1024, "bf16", False, False, None)
